@@ -1,0 +1,93 @@
+"""ctypes binding of libdgmesh_hip.so (the C ABI declared in include/dgmesh_hip.h).
+
+The HIP library is the product: there is NO fallback.  If it cannot be loaded every entry point raises,
+so a GPU box can never silently run something else.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdgmesh_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_c = ctypes
+_vp = _c.c_void_p
+ALLOC_FN = _c.CFUNCTYPE(_c.c_void_p, _c.c_void_p, _c.c_size_t)
+
+
+class StateLayout(_c.Structure):
+    """Mirror of dgm_state_layout (include/dgmesh_hip.h)."""
+    _fields_ = [(n, _c.c_size_t) for n in (
+        "rec", "depth", "radii", "tiles_touched", "offs", "cov3D", "clamped", "block_sums", "block_offs", "hist",
+        "tile_count", "tile_offset", "big_list", "counters", "geometry_bytes",
+        "keys", "point_list", "inv", "slab", "binning_bytes",
+        "final_T", "n_contrib", "ranges", "nproc", "image_bytes")] + [
+        (n, _c.c_int) for n in ("tiles_x", "tiles_y", "n_chunks", "chunk_size")]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/dgmesh_hip.h
+_f, _i = _c.c_float, _c.c_int
+SYMBOLS = {
+    "dgm_abi_version": (_i, []),
+    "dgm_last_error": (_c.c_char_p, []),
+    "dgm_rasterize_forward": (_i, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp,
+                                   _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp,
+                                   _c.POINTER(_i)]),
+    "dgm_rasterize_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dgm_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "dgm_geometry_bytes": (_c.c_size_t, [_i, _i, _i]),
+    "dgm_binning_bytes": (_c.c_size_t, [_i]),
+    "dgm_image_bytes": (_c.c_size_t, [_i, _i]),
+    "dgm_describe_state": (_i, [_i, _i, _i, _i, _c.POINTER(StateLayout)]),
+    "dgm_set_profiling": (None, [_i]),
+    "dgm_get_stage_ms": (_i, [_c.POINTER(_f), _i]),
+    "dgm_stage_name": (_c.c_char_p, [_i]),
+    "dgm_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("building libdgmesh_hip.so failed:\n" + out.stdout[-4000:])
+    if verbose:
+        print(out.stdout)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(dg-mesh_amd has no CPU or PyTorch fallback for its kernels)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        if handle.dgm_abi_version() != 1:
+            raise RuntimeError("libdgmesh_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError(lib().dgm_last_error().decode() or "libdgmesh_hip error")
+
+
+STAGE_COUNT = 8
+
+
+def stage_ms():
+    buf = (_f * STAGE_COUNT)()
+    n = lib().dgm_get_stage_ms(buf, STAGE_COUNT)
+    return {lib().dgm_stage_name(i).decode(): float(buf[i]) for i in range(n)}

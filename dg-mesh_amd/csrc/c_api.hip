@@ -1,0 +1,394 @@
+// extern "C" entry points of libdgmesh_hip.so (see include/dgmesh_hip.h for the contract and the reference
+// interfaces each one replaces).  Host orchestration only: stream-ordered kernel launches, argument checks
+// with the reference's error points (DGR/rasterize_points.cu:57-59, rasterizer_impl.cu:242-245), optional
+// hipEvent stage timing.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+
+#include "dgm_common.hpp"
+
+namespace dgm {
+// preprocess.hip
+void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* means3D, const float* scales,
+                           float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                           const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
+                           const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
+                           int gridx, int gridy, int prefiltered, int* radii_out, float* rec, float* depth,
+                           int* radii_int, unsigned* tiles_touched, float* cov3Ds, uint8_t* clamped,
+                           unsigned* block_sums, unsigned* counters);
+void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
+// binning.hip
+int binning_lds_limit_tiles();
+void launch_scan_blocks(hipStream_t st, int n, const unsigned* in, unsigned* out, unsigned* total);
+hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
+                        const unsigned* tiles_touched, float* rec, const unsigned* block_offs, unsigned* offs,
+                        unsigned* hist);
+void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
+                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count);
+hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
+                          const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
+                          const unsigned* tile_offset, unsigned long long* keys);
+hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, unsigned long long* keys,
+                            const float* rec, unsigned* point_list, unsigned* inv, const unsigned* big_list,
+                            const unsigned* big_count);
+// render.hip
+void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
+                       int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
+                       unsigned* n_contrib);
+void launch_render_bwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
+                       int gridx, const float* bg, const float* rec, const float* final_T, const unsigned* n_contrib,
+                       const float* dL_dpix, float* slab, unsigned* nproc);
+// preprocess_bwd.hip
+void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
+                           const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
+                           float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
+                           const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                           const float* rec, const unsigned* tiles_touched, const unsigned* offs, const unsigned* inv,
+                           const float* slab, const uint2* ranges, const unsigned* nproc, float* dL_dmean2D,
+                           float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                           float* dL_dsh, float* dL_dscale, float* dL_drot);
+// knn.hip
+size_t knn_scratch_bytes(int P);
+void launch_knn(hipStream_t st, int P, const float* pts, float* dists, char* scratch);
+}  // namespace dgm
+
+using namespace dgm;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local bool g_profile = false;
+thread_local float g_stage_ms[DGM_STAGE_COUNT] = {0};
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define DGM_HIP(call)                                                                                \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Records hipEvents around stages on the caller's stream when profiling is on.
+struct StageTimer {
+    hipStream_t st;
+    bool on;
+    hipEvent_t ev[2 * DGM_STAGE_COUNT];
+    bool used[DGM_STAGE_COUNT];
+    explicit StageTimer(hipStream_t s) : st(s), on(g_profile) {
+        memset(used, 0, sizeof(used));
+        if (on)
+            for (auto& e : ev) hipEventCreate(&e);
+    }
+    void begin(int s) {
+        if (on) {
+            hipEventRecord(ev[2 * s], st);
+            used[s] = true;
+        }
+    }
+    void end(int s) {
+        if (on) hipEventRecord(ev[2 * s + 1], st);
+    }
+    void finish() {
+        if (!on) return;
+        hipStreamSynchronize(st);
+        for (int s = 0; s < DGM_STAGE_COUNT; s++)
+            if (used[s]) hipEventElapsedTime(&g_stage_ms[s], ev[2 * s], ev[2 * s + 1]);
+        for (auto& e : ev) hipEventDestroy(e);
+        on = false;
+    }
+    ~StageTimer() { finish(); }
+};
+
+int check_launch(const char* what, bool debug, hipStream_t st) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
+    if (debug) {  // CHECK_CUDA(.., debug): synchronise and throw (DGR/cuda_rasterizer/auxiliary.h:166-173)
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
+    }
+    return 0;
+}
+#define DGM_CHECK(what)                               \
+    do {                                              \
+        if (check_launch(what, debug != 0, st)) return 1; \
+    } while (0)
+
+// knn scratch arena (grow-only, per process; simple-knn is an init-time / anchoring-time call)
+std::mutex g_knn_mu;
+char* g_knn_scratch = nullptr;
+size_t g_knn_cap = 0;
+
+}  // namespace
+
+extern "C" {
+
+int dgm_abi_version(void) { return DGM_ABI_VERSION; }
+const char* dgm_last_error(void) { return g_err.c_str(); }
+
+void dgm_set_profiling(int enabled) { g_profile = enabled != 0; }
+int dgm_get_stage_ms(float* ms, int capacity) {
+    int n = capacity < DGM_STAGE_COUNT ? capacity : DGM_STAGE_COUNT;
+    for (int i = 0; i < n; i++) ms[i] = g_stage_ms[i];
+    return n;
+}
+const char* dgm_stage_name(int s) {
+    static const char* names[DGM_STAGE_COUNT] = {"preprocess_fwd", "bin_count",  "bin_scan",   "bin_scatter",
+                                                 "tile_sort",      "render_fwd", "render_bwd", "preprocess_bwd"};
+    return (s >= 0 && s < DGM_STAGE_COUNT) ? names[s] : "?";
+}
+
+size_t dgm_geometry_bytes(int P, int width, int height) {
+    dgm_state_layout L;
+    compute_layout(P, width, height, 0, &L);
+    return L.geometry_bytes;
+}
+size_t dgm_binning_bytes(int R) {
+    dgm_state_layout L;
+    compute_layout(0, 16, 16, R, &L);
+    return L.binning_bytes;
+}
+size_t dgm_image_bytes(int width, int height) {
+    dgm_state_layout L;
+    compute_layout(0, width, height, 0, &L);
+    return L.image_bytes;
+}
+int dgm_describe_state(int P, int width, int height, int R, dgm_state_layout* out) {
+    if (!out) return fail("dgm_describe_state: out is NULL");
+    compute_layout(P, width, height, R, out);
+    return 0;
+}
+
+int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                          dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                          int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                          const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                          int* radii, int debug, void* stream, int* num_rendered) {
+    hipStream_t st = (hipStream_t)stream;
+    if (num_rendered) *num_rendered = 0;
+    if (P < 0 || width <= 0 || height <= 0) return fail("rasterize_forward: bad sizes P=%d W=%d H=%d", P, width, height);
+    if (!geom_alloc || !binning_alloc || !image_alloc) return fail("rasterize_forward: allocator callback is NULL");
+    if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color)
+        return fail("rasterize_forward: NULL required pointer");
+    dgm_state_layout L;
+    compute_layout(P, width, height, 0, &L);
+    const int gridx = L.tiles_x, gridy = L.tiles_y, tiles = gridx * gridy;
+    if (gridx > DGM_MAX_GRID_DIM || gridy > DGM_MAX_GRID_DIM)
+        return fail("rasterize_forward: image %dx%d exceeds %d tiles per axis", width, height, DGM_MAX_GRID_DIM);
+    if (tiles > binning_lds_limit_tiles())
+        return fail("rasterize_forward: %d tiles exceed the LDS histogram capacity (%d)", tiles, binning_lds_limit_tiles());
+
+    char* img = image_alloc(image_ctx, L.image_bytes);
+    if (!img) return fail("rasterize_forward: image allocator returned NULL");
+    img = align_ptr(img);
+    float* final_T = (float*)(img + L.final_T);
+    unsigned* n_contrib = (unsigned*)(img + L.n_contrib);
+    uint2* ranges = (uint2*)(img + L.ranges);
+
+    if (P == 0) {  // reference: kernels skipped, rendered = 0, out_color stays 0 (rasterize_points.cu:68,81)
+        DGM_HIP(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), st));
+        return 0;
+    }
+    if (!means3D || !opacities) return fail("rasterize_forward: NULL required pointer");
+    if (!colors_precomp && !shs)  // reference: needs one of them (python wrapper raises, __init__.py:191-192)
+        return fail("rasterize_forward: provide either SHs or precomputed colors");
+    if (!cov3D_precomp && (!scales || !rotations))
+        return fail("rasterize_forward: provide either scale/rotation pair or precomputed 3D covariance");
+    if (shs && !colors_precomp && (D + 1) * (D + 1) > M)
+        return fail("rasterize_forward: SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
+    if (shs && !colors_precomp && D > 3) return fail("rasterize_forward: SH degree %d > 3 unsupported", D);
+    if (rotations && (((uintptr_t)rotations) & 15)) return fail("rasterize_forward: rotations must be 16-byte aligned");
+
+    char* geom = geom_alloc(geom_ctx, L.geometry_bytes);
+    if (!geom) return fail("rasterize_forward: geometry allocator returned NULL");
+    geom = align_ptr(geom);
+    float* rec = (float*)(geom + L.rec);
+    float* depth = (float*)(geom + L.depth);
+    int* radii_int = (int*)(geom + L.radii);
+    unsigned* tiles_touched = (unsigned*)(geom + L.tiles_touched);
+    unsigned* offs = (unsigned*)(geom + L.offs);
+    float* cov3D = (float*)(geom + L.cov3D);
+    uint8_t* clamped = (uint8_t*)(geom + L.clamped);
+    unsigned* block_sums = (unsigned*)(geom + L.block_sums);
+    unsigned* block_offs = (unsigned*)(geom + L.block_offs);
+    unsigned* hist = (unsigned*)(geom + L.hist);
+    unsigned* tile_count = (unsigned*)(geom + L.tile_count);
+    unsigned* tile_offset = (unsigned*)(geom + L.tile_offset);
+    unsigned* big_list = (unsigned*)(geom + L.big_list);
+    unsigned* counters = (unsigned*)(geom + L.counters);
+
+    StageTimer tm(st);
+    DGM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), st));
+
+    tm.begin(DGM_STAGE_PREPROCESS);
+    launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                          colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, gridx,
+                          gridy, prefiltered, radii, rec, depth, radii_int, tiles_touched, cov3D, clamped, block_sums,
+                          counters);
+    DGM_CHECK("preprocess_fwd");
+    const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
+    launch_scan_blocks(st, nblk, block_sums, block_offs, counters);
+    DGM_CHECK("scan_blocks");
+    tm.end(DGM_STAGE_PREPROCESS);
+
+    // R is needed on the host to size the binning buffer (rasterizer_impl.cu:281 does the same read-back)
+    unsigned R_host = 0;
+    DGM_HIP(hipMemcpyAsync(&R_host, counters, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    DGM_HIP(hipStreamSynchronize(st));
+    if (R_host > 0x7fffffffu) return fail("rasterize_forward: %u tile instances overflow int", R_host);
+    const int R = (int)R_host;
+    if (num_rendered) *num_rendered = R;
+    if (debug) {
+        unsigned flags = 0;
+        DGM_HIP(hipMemcpy(&flags, counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (flags & 1u) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
+
+    compute_layout(P, width, height, R, &L);
+    char* bin = binning_alloc(binning_ctx, L.binning_bytes);
+    if (!bin) return fail("rasterize_forward: binning allocator returned NULL");
+    bin = align_ptr(bin);
+    unsigned long long* keys = (unsigned long long*)(bin + L.keys);
+    unsigned* point_list = (unsigned*)(bin + L.point_list);
+    unsigned* inv = (unsigned*)(bin + L.inv);
+
+    tm.begin(DGM_STAGE_BIN_COUNT);
+    DGM_HIP(launch_count(st, P, L.chunk_size, L.n_chunks, tiles, gridx, tiles_touched, rec, block_offs, offs, hist));
+    DGM_CHECK("count_tiles");
+    tm.end(DGM_STAGE_BIN_COUNT);
+
+    tm.begin(DGM_STAGE_BIN_SCAN);
+    launch_tile_scan(st, tiles, L.n_chunks, hist, tile_count, tile_offset, ranges, big_list, counters + 2);
+    DGM_CHECK("tile_scan");
+    tm.end(DGM_STAGE_BIN_SCAN);
+
+    if (R > 0) {
+        tm.begin(DGM_STAGE_BIN_SCATTER);
+        DGM_HIP(launch_scatter(st, P, L.chunk_size, L.n_chunks, tiles, gridx, tiles_touched, rec, depth, hist,
+                               tile_offset, keys));
+        DGM_CHECK("scatter");
+        tm.end(DGM_STAGE_BIN_SCATTER);
+
+        tm.begin(DGM_STAGE_TILE_SORT);
+        DGM_HIP(launch_tile_sort(st, tiles, gridx, ranges, keys, rec, point_list, inv, big_list, counters + 2));
+        DGM_CHECK("tile_sort");
+        tm.end(DGM_STAGE_TILE_SORT);
+    }
+
+    tm.begin(DGM_STAGE_RENDER_FWD);
+    launch_render_fwd(st, tiles, ranges, point_list, width, height, gridx, rec, background, out_color, final_T,
+                      n_contrib);
+    DGM_CHECK("render_fwd");
+    tm.end(DGM_STAGE_RENDER_FWD);
+    tm.finish();
+    return 0;
+}
+
+int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                           const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                           float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                           char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                           float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                           float* dL_dscale, float* dL_drot, int debug, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (P <= 0) return 0;  // rasterize_points.cu:161
+    if (width <= 0 || height <= 0 || R < 0) return fail("rasterize_backward: bad sizes");
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("rasterize_backward: NULL state buffer");
+    if (!dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale ||
+        !dL_drot)
+        return fail("rasterize_backward: NULL gradient pointer");
+    if ((((uintptr_t)dL_dconic) & 15) || (((uintptr_t)dL_drot) & 15))
+        return fail("rasterize_backward: dL_dconic / dL_drot must be 16-byte aligned");
+    dgm_state_layout L;
+    compute_layout(P, width, height, R, &L);
+    const int gridx = L.tiles_x, tiles = L.tiles_x * L.tiles_y;
+    char* geom = align_ptr(geom_buffer);
+    char* bin = align_ptr(binning_buffer);
+    char* img = align_ptr(image_buffer);
+    const float* rec = (const float*)(geom + L.rec);
+    const int* radii_int = (const int*)(geom + L.radii);
+    const unsigned* tiles_touched = (const unsigned*)(geom + L.tiles_touched);
+    const unsigned* offs = (const unsigned*)(geom + L.offs);
+    const float* cov3D = (const float*)(geom + L.cov3D);
+    const uint8_t* clamped = (const uint8_t*)(geom + L.clamped);
+    const unsigned* point_list = (const unsigned*)(bin + L.point_list);
+    const unsigned* inv = (const unsigned*)(bin + L.inv);
+    float* slab = (float*)(bin + L.slab);
+    const float* final_T = (const float*)(img + L.final_T);
+    const unsigned* n_contrib = (const unsigned*)(img + L.n_contrib);
+    const uint2* ranges = (const uint2*)(img + L.ranges);
+    unsigned* nproc = (unsigned*)(img + L.nproc);
+    if (!radii) radii = radii_int;  // rasterizer_impl.cu:375-378
+
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    StageTimer tm(st);
+    tm.begin(DGM_STAGE_RENDER_BWD);
+    launch_render_bwd(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib, dL_dpix,
+                      slab, nproc);
+    DGM_CHECK("render_bwd");
+    tm.end(DGM_STAGE_RENDER_BWD);
+
+    tm.begin(DGM_STAGE_PREPROCESS_BWD);
+    const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : cov3D;  // rasterizer_impl.cu:411
+    // with precomputed colours the SH branch is skipped (backward.cu:390: `if (shs)`)
+    launch_preprocess_bwd(st, P, D, M, gridx, means3D, radii, colors_precomp ? nullptr : shs, clamped, scales, rotations,
+                          scale_modifier, cov3D_ptr, viewmatrix, projmatrix, campos, focal_x, focal_y, tan_fovx,
+                          tan_fovy, rec, tiles_touched, offs, inv, slab, ranges, nproc, dL_dmean2D, dL_dconic,
+                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    DGM_CHECK("preprocess_bwd");
+    tm.end(DGM_STAGE_PREPROCESS_BWD);
+    tm.finish();
+    return 0;
+}
+
+int dgm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream) {
+    (void)projmatrix;
+    if (P <= 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail("mark_visible: NULL pointer");
+    launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("mark_visible: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, void* stream) {
+    if (P <= 0) return 0;
+    if (!points || !mean_dists) return fail("knn_mean_dist2: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_knn_mu);
+    const size_t need = knn_scratch_bytes(P);
+    if (need > g_knn_cap) {
+        if (g_knn_scratch) {
+            DGM_HIP(hipDeviceSynchronize());
+            DGM_HIP(hipFree(g_knn_scratch));
+            g_knn_scratch = nullptr;
+            g_knn_cap = 0;
+        }
+        DGM_HIP(hipMalloc((void**)&g_knn_scratch, need));
+        g_knn_cap = need;
+    }
+    launch_knn(st, P, points, mean_dists, g_knn_scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("knn_mean_dist2: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

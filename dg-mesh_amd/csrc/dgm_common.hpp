@@ -1,0 +1,139 @@
+// Shared host/device declarations of libdgmesh_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/dgmesh_hip.h"
+
+#define DGM_TILE 16          // BLOCK_X = BLOCK_Y of the reference (config.h:16-17): keeps tile ids / ranges identical
+#define DGM_REC_STRIDE 12    // floats per splat record (48 B = 3 x float4)
+#define DGM_SLAB_STRIDE 12   // floats per per-instance gradient row
+#define DGM_PRE_BLOCK 256    // Gaussians per preprocess workgroup (also the granularity of block_sums)
+#define DGM_BIN_THREADS 512  // threads of a binning chunk workgroup
+#define DGM_MAX_CHUNKS 256   // chunk workgroups = rows of the per-chunk tile histogram
+#define DGM_MAX_GRID_DIM 1023  // tiles per axis that fit the 10-bit rect packing
+
+namespace dgm {
+
+struct Layout : dgm_state_layout {};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Pure function of (P, W, H, R): backward re-derives every pointer from the same three chunks.
+static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* L) {
+    const size_t A = 256;
+    const int tx = (W + DGM_TILE - 1) / DGM_TILE, ty = (H + DGM_TILE - 1) / DGM_TILE;
+    const size_t tiles = (size_t)tx * ty;
+    const size_t Pz = (size_t)(P > 0 ? P : 0), Rz = (size_t)(R > 0 ? R : 0);
+    const size_t nblk = (Pz + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
+    // chunk = contiguous run of Gaussians owned by one binning workgroup; multiple of DGM_BIN_THREADS
+    size_t chunk = (Pz + DGM_MAX_CHUNKS - 1) / DGM_MAX_CHUNKS;
+    chunk = align_up(chunk ? chunk : 1, DGM_BIN_THREADS);
+    size_t nchunks = (Pz + chunk - 1) / chunk;
+    if (nchunks == 0) nchunks = 1;
+    L->tiles_x = tx;
+    L->tiles_y = ty;
+    L->n_chunks = (int)nchunks;
+    L->chunk_size = (int)chunk;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = align_up(o + bytes, A);
+        return at;
+    };
+    L->rec = take(Pz * DGM_REC_STRIDE * 4);
+    L->depth = take(Pz * 4);
+    L->radii = take(Pz * 4);
+    L->tiles_touched = take(Pz * 4);
+    L->offs = take(Pz * 4);
+    L->cov3D = take(Pz * 24);
+    L->clamped = take(Pz);
+    L->block_sums = take(nblk * 4);
+    L->block_offs = take(nblk * 4);
+    L->hist = take(nchunks * tiles * 4);
+    L->tile_count = take(tiles * 4);
+    L->tile_offset = take((tiles + 1) * 4);
+    L->big_list = take(tiles * 4);
+    L->counters = take(8 * 4);
+    L->geometry_bytes = o + A;
+    o = 0;
+    L->keys = take(Rz * 8);
+    L->point_list = take(Rz * 4);
+    L->inv = take(Rz * 4);
+    L->slab = take(Rz * DGM_SLAB_STRIDE * 4);
+    L->binning_bytes = o + A;
+    o = 0;
+    L->final_T = take((size_t)W * H * 4);
+    L->n_contrib = take((size_t)W * H * 4);
+    L->ranges = take(tiles * 8);
+    L->nproc = take(tiles * 4);
+    L->image_bytes = o + A;
+}
+
+static inline char* align_ptr(char* p, size_t a = 256) {
+    return (char*)(((uintptr_t)p + a - 1) / a * a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// float -> int with the GPU conversion semantics the parity definition fixes (truncate toward
+// zero, saturate, NaN -> 0) -- identical to oracle f2i_sat.
+__device__ __forceinline__ int f2i_sat(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+__device__ __forceinline__ unsigned f2u_sat(float f) {
+    if (f != f) return 0u;
+    if (f >= 4294967296.0f) return 4294967295u;
+    if (f <= 0.0f) return 0u;
+    return (unsigned)f;
+}
+
+// rect packing: xmin | ymin << 10 | width << 20  (all < 1024)
+__device__ __forceinline__ unsigned pack_rect(unsigned xmin, unsigned ymin, unsigned w) {
+    return xmin | (ymin << 10) | (w << 20);
+}
+__device__ __forceinline__ void unpack_rect(unsigned r, unsigned& xmin, unsigned& ymin, unsigned& w) {
+    xmin = r & 1023u;
+    ymin = (r >> 10) & 1023u;
+    w = r >> 20;
+}
+
+// exp() of the blend loops.  v_exp_f32 on x*log2(e): relative error ~1e-6 on the range the blend
+// loop uses (power in [-6, 0]); forward and backward share it so T replays consistently.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// wave-wide inclusive scan / sum through ds_bpermute-free shuffles (light kernels only)
+__device__ __forceinline__ unsigned wave_inclusive_scan_u32(unsigned v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+#endif  // __HIPCC__
+}  // namespace dgm

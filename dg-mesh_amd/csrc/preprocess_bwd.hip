@@ -1,0 +1,384 @@
+// Per-Gaussian backward for gfx950: gathers the per-instance gradient rows written by render_bwd and
+// back-propagates through conic -> cov2D -> cov3D -> (scale, rotation), the projection of the mean, and the
+// SH colour evaluation.  ONE kernel, one thread per Gaussian, every output written exactly once.
+//
+// Replaces the 9 fp32 atomicAdd per (pixel, splat) of the reference's renderCUDA backward
+// (DGR/cuda_rasterizer/backward.cu:523-554) by a deterministic gather, and fuses computeCov2DCUDA
+// (backward.cu:144-274) with preprocessCUDA<3> backward (backward.cu:347-396; helpers :20-139 SH,
+// :278-341 cov3D, auxiliary.h:107-117 dnormvdv).
+//
+// Gather: Gaussian g owns instances k = 0..tiles_touched-1 (row-major over its tile rectangle); instance k
+// sits at slot inv[offs[g]+k] of the tile list; render_bwd wrote a row for it iff
+// slot - ranges[tile].x < nproc[tile].  Rows are summed in ascending k (fixed order => reproducible grads).
+//
+// The SH block (192 B in, 192 B out per Gaussian) goes through LDS both ways so that global traffic is
+// coalesced 16-byte accesses (same scheme as preprocess.hip).
+#include "dgm_common.hpp"
+
+namespace dgm {
+
+__constant__ float kbSH_C0 = 0.28209479177387814f;
+__constant__ float kbSH_C1 = 0.4886025119029199f;
+__constant__ float kbSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                 -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kbSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+
+__global__ void __launch_bounds__(DGM_PRE_BLOCK)
+preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ means3D, const int* __restrict__ radii,
+                      const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
+                      const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
+                      const float* __restrict__ cov3Ds, const float* __restrict__ vm, const float* __restrict__ proj,
+                      const float* __restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy,
+                      const float* __restrict__ rec, const unsigned* __restrict__ tiles_touched,
+                      const unsigned* __restrict__ offs, const unsigned* __restrict__ inv,
+                      const float* __restrict__ slab, const uint2* __restrict__ ranges,
+                      const unsigned* __restrict__ nproc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+                      float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+                      float* __restrict__ dL_drot) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int base = blockIdx.x * DGM_PRE_BLOCK;
+    const int cnt = min(DGM_PRE_BLOCK, P - base);
+    const int idx = base + threadIdx.x;
+    const int n_sh = (D + 1) * (D + 1);
+    const bool use_sh = shs != nullptr && M > 0;
+    const int L = 3 * M;            // full row: gradients of unused coefficients are written as zeros
+    const int stride = L | 1;
+    if (use_sh) {
+        // stage the whole (cnt, M, 3) block, coalesced
+        const int total = cnt * L;
+        const float* src = shs + (size_t)base * L;
+        if ((L & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            for (int i = threadIdx.x; i < (total >> 2); i += DGM_PRE_BLOCK) {
+                const float4 v = s4[i];
+                const int e = i << 2;
+                const int g = e / L, k = e - g * L;
+                float* d = lds + g * stride + k;
+                d[0] = v.x;
+                d[1] = v.y;
+                d[2] = v.z;
+                d[3] = v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < total; i += DGM_PRE_BLOCK) {
+                const int g = i / L, k = i - g * L;
+                lds[g * stride + k] = src[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    if (idx < P) {
+        const bool live = radii[idx] > 0;
+        float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const float4 r2 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[2];
+            unsigned xmin, ymin, w;
+            unpack_rect(__float_as_uint(r2.y), xmin, ymin, w);
+            const unsigned n = tiles_touched[idx], o = offs[idx];
+            unsigned x = 0, y = 0;
+            for (unsigned k = 0; k < n; k++) {
+                const unsigned slot = inv[o + k];
+                const unsigned tile = (ymin + y) * (unsigned)gridx + xmin + x;
+                if (++x == w) {
+                    x = 0;
+                    y++;
+                }
+                if (slot - ranges[tile].x < nproc[tile]) {
+                    const float4* row = reinterpret_cast<const float4*>(slab + (size_t)slot * DGM_SLAB_STRIDE);
+                    const float4 a = row[0], b = row[1];
+                    const float c = row[2].x;
+                    acc[0] += a.x;
+                    acc[1] += a.y;
+                    acc[2] += a.z;
+                    acc[3] += a.w;
+                    acc[4] += b.x;
+                    acc[5] += b.y;
+                    acc[6] += b.z;
+                    acc[7] += b.w;
+                    acc[8] += c;
+                }
+            }
+        }
+        // outputs of the blend backward (reference: atomically accumulated arrays)
+        dL_dcolor[3 * idx + 0] = acc[0];
+        dL_dcolor[3 * idx + 1] = acc[1];
+        dL_dcolor[3 * idx + 2] = acc[2];
+        dL_dmean2D[3 * idx + 0] = acc[3];
+        dL_dmean2D[3 * idx + 1] = acc[4];
+        dL_dmean2D[3 * idx + 2] = 0.f;
+        reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(acc[5], acc[6], 0.f, acc[7]);
+        dL_dopacity[idx] = acc[8];
+
+        float dmean[3] = {0.f, 0.f, 0.f};
+        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dscale[3] = {0.f, 0.f, 0.f};
+        float drot[4] = {0.f, 0.f, 0.f, 0.f};
+        float* my_sh = lds + threadIdx.x * stride;
+        if (live) {
+            const float m0 = means3D[3 * idx], m1 = means3D[3 * idx + 1], m2 = means3D[3 * idx + 2];
+            // ---- computeCov2DCUDA (backward.cu:144-274) ----
+            {
+                float c3[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) c3[i] = cov3Ds[6 * idx + i];
+                float t0 = vm[0] * m0 + vm[4] * m1 + vm[8] * m2 + vm[12];
+                float t1 = vm[1] * m0 + vm[5] * m1 + vm[9] * m2 + vm[13];
+                const float t2 = vm[2] * m0 + vm[6] * m1 + vm[10] * m2 + vm[14];
+                const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+                const float txtz = t0 / t2, tytz = t1 / t2;
+                t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+                t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+                const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+                const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+                const float J00 = h_x / t2, J20 = -(h_x * t0) / (t2 * t2);
+                const float J11 = h_y / t2, J21 = -(h_y * t1) / (t2 * t2);
+                float Tm[3][2];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    Tm[r][0] = vm[4 * r + 0] * J00 + vm[4 * r + 2] * J20;
+                    Tm[r][1] = vm[4 * r + 1] * J11 + vm[4 * r + 2] * J21;
+                }
+                const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+                float U[2][3];
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) U[r][k] = Tm[0][r] * V[k][0] + Tm[1][r] * V[k][1] + Tm[2][r] * V[k][2];
+                const float a = U[0][0] * Tm[0][0] + U[0][1] * Tm[1][0] + U[0][2] * Tm[2][0] + 0.3f;
+                const float b = U[1][0] * Tm[0][0] + U[1][1] * Tm[1][0] + U[1][2] * Tm[2][0];
+                const float c = U[1][0] * Tm[0][1] + U[1][1] * Tm[1][1] + U[1][2] * Tm[2][1] + 0.3f;
+                const float g0 = acc[5], g1 = acc[6], g2 = acc[7];
+                const float denom = a * c - b * b;
+                float dL_da = 0, dL_db = 0, dL_dc = 0;
+                const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+                // GLM T[i][j] = Tm[j][i]
+#define TT(i_, j_) (Tm[j_][i_])
+                if (denom2inv != 0) {
+                    dL_da = denom2inv * (-c * c * g0 + 2 * b * c * g1 + (denom - a * c) * g2);
+                    dL_dc = denom2inv * (-a * a * g2 + 2 * a * b * g1 + (denom - a * c) * g0);
+                    dL_db = denom2inv * 2 * (b * c * g0 - (denom + 2 * b * b) * g1 + a * b * g2);
+                    dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+                    dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+                    dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+                    dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db +
+                              2 * TT(1, 0) * TT(1, 1) * dL_dc;
+                    dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db +
+                              2 * TT(1, 0) * TT(1, 2) * dL_dc;
+                    dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db +
+                              2 * TT(1, 1) * TT(1, 2) * dL_dc;
+                }
+                // TV(i,k) = sum_j T[i][j] * Vrk[k][j]
+#define TV(i_, k_) (TT(i_, 0) * V[k_][0] + TT(i_, 1) * V[k_][1] + TT(i_, 2) * V[k_][2])
+                const float dL_dT00 = 2 * TV(0, 0) * dL_da + TV(1, 0) * dL_db;
+                const float dL_dT01 = 2 * TV(0, 1) * dL_da + TV(1, 1) * dL_db;
+                const float dL_dT02 = 2 * TV(0, 2) * dL_da + TV(1, 2) * dL_db;
+                const float dL_dT10 = 2 * TV(1, 0) * dL_dc + TV(0, 0) * dL_db;
+                const float dL_dT11 = 2 * TV(1, 1) * dL_dc + TV(0, 1) * dL_db;
+                const float dL_dT12 = 2 * TV(1, 2) * dL_dc + TV(0, 2) * dL_db;
+#undef TV
+#undef TT
+                // GLM W[i][j] = vm[4*j + i]
+                const float dL_dJ00 = vm[0] * dL_dT00 + vm[4] * dL_dT01 + vm[8] * dL_dT02;
+                const float dL_dJ02 = vm[2] * dL_dT00 + vm[6] * dL_dT01 + vm[10] * dL_dT02;
+                const float dL_dJ11 = vm[1] * dL_dT10 + vm[5] * dL_dT11 + vm[9] * dL_dT12;
+                const float dL_dJ12 = vm[2] * dL_dT10 + vm[6] * dL_dT11 + vm[10] * dL_dT12;
+                const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+                const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+                const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+                const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t0) * tz3 * dL_dJ02 +
+                                     (2 * h_y * t1) * tz3 * dL_dJ12;
+                dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+                dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+                dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+            }
+            // ---- projection of the mean (backward.cu:370-387) ----
+            {
+                const float hw = proj[3] * m0 + proj[7] * m1 + proj[11] * m2 + proj[15];
+                const float m_w = 1.0f / (hw + 0.0000001f);
+                const float mul1 = (proj[0] * m0 + proj[4] * m1 + proj[8] * m2 + proj[12]) * m_w * m_w;
+                const float mul2 = (proj[1] * m0 + proj[5] * m1 + proj[9] * m2 + proj[13]) * m_w * m_w;
+                const float gx = acc[3], gy = acc[4];
+                dmean[0] += (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
+                dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
+                dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
+            }
+            // ---- SH colour (backward.cu:20-139); reads this thread's LDS row, then overwrites it with dL_dsh ----
+            if (use_sh) {
+                const float d0 = m0 - campos[0], d1 = m1 - campos[1], d2 = m2 - campos[2];
+                const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                const float x = d0 / len, y = d1 / len, z = d2 / len;
+                const uint8_t cl = clamped[idx];
+                float dRGB[3] = {(cl & 1) ? 0.f : acc[0], (cl & 2) ? 0.f : acc[1], (cl & 4) ? 0.f : acc[2]};
+                float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+                float Bk[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) Bk[k] = 0.f;
+                Bk[0] = kbSH_C0;
+#define S(k_) my_sh[3 * (k_) + ch]
+                if (D > 0) {
+                    Bk[1] = -kbSH_C1 * y;
+                    Bk[2] = kbSH_C1 * z;
+                    Bk[3] = -kbSH_C1 * x;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dx[ch] = -kbSH_C1 * S(3);
+                        dy[ch] = -kbSH_C1 * S(1);
+                        dz[ch] = kbSH_C1 * S(2);
+                    }
+                    if (D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        Bk[4] = kbSH_C2[0] * xy;
+                        Bk[5] = kbSH_C2[1] * yz;
+                        Bk[6] = kbSH_C2[2] * (2.f * zz - xx - yy);
+                        Bk[7] = kbSH_C2[3] * xz;
+                        Bk[8] = kbSH_C2[4] * (xx - yy);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            dx[ch] += kbSH_C2[0] * y * S(4) + kbSH_C2[2] * 2.f * -x * S(6) + kbSH_C2[3] * z * S(7) +
+                                      kbSH_C2[4] * 2.f * x * S(8);
+                            dy[ch] += kbSH_C2[0] * x * S(4) + kbSH_C2[1] * z * S(5) + kbSH_C2[2] * 2.f * -y * S(6) +
+                                      kbSH_C2[4] * 2.f * -y * S(8);
+                            dz[ch] += kbSH_C2[1] * y * S(5) + kbSH_C2[2] * 2.f * 2.f * z * S(6) + kbSH_C2[3] * x * S(7);
+                        }
+                        if (D > 2) {
+                            Bk[9] = kbSH_C3[0] * y * (3.f * xx - yy);
+                            Bk[10] = kbSH_C3[1] * xy * z;
+                            Bk[11] = kbSH_C3[2] * y * (4.f * zz - xx - yy);
+                            Bk[12] = kbSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                            Bk[13] = kbSH_C3[4] * x * (4.f * zz - xx - yy);
+                            Bk[14] = kbSH_C3[5] * z * (xx - yy);
+                            Bk[15] = kbSH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++) {
+                                dx[ch] += (kbSH_C3[0] * S(9) * 3.f * 2.f * xy + kbSH_C3[1] * S(10) * yz +
+                                           kbSH_C3[2] * S(11) * -2.f * xy + kbSH_C3[3] * S(12) * -3.f * 2.f * xz +
+                                           kbSH_C3[4] * S(13) * (-3.f * xx + 4.f * zz - yy) +
+                                           kbSH_C3[5] * S(14) * 2.f * xz + kbSH_C3[6] * S(15) * 3.f * (xx - yy));
+                                dy[ch] += (kbSH_C3[0] * S(9) * 3.f * (xx - yy) + kbSH_C3[1] * S(10) * xz +
+                                           kbSH_C3[2] * S(11) * (-3.f * yy + 4.f * zz - xx) +
+                                           kbSH_C3[3] * S(12) * -3.f * 2.f * yz + kbSH_C3[4] * S(13) * -2.f * xy +
+                                           kbSH_C3[5] * S(14) * -2.f * yz + kbSH_C3[6] * S(15) * -3.f * 2.f * xy);
+                                dz[ch] += (kbSH_C3[1] * S(10) * xy + kbSH_C3[2] * S(11) * 4.f * 2.f * yz +
+                                           kbSH_C3[3] * S(12) * 3.f * (2.f * zz - xx - yy) +
+                                           kbSH_C3[4] * S(13) * 4.f * 2.f * xz + kbSH_C3[5] * S(14) * (xx - yy));
+                            }
+                        }
+                    }
+                }
+#undef S
+                // constant indices only (a runtime-indexed Bk[] would be demoted to scratch memory)
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < M) {
+                        const float bk = k < n_sh ? Bk[k] : 0.f;
+                        my_sh[3 * k + 0] = bk * dRGB[0];
+                        my_sh[3 * k + 1] = bk * dRGB[1];
+                        my_sh[3 * k + 2] = bk * dRGB[2];
+                    }
+                }
+                for (int k = 48; k < L; k++) my_sh[k] = 0.f;
+                const float dd0 = dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2];
+                const float dd1 = dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2];
+                const float dd2 = dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2];
+                // dnormvdv (auxiliary.h:107-117)
+                const float sum2 = d0 * d0 + d1 * d1 + d2 * d2;
+                const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+                dmean[0] += ((+sum2 - d0 * d0) * dd0 - d1 * d0 * dd1 - d2 * d0 * dd2) * invsum32;
+                dmean[1] += (-d0 * d1 * dd0 + (sum2 - d1 * d1) * dd1 - d2 * d1 * dd2) * invsum32;
+                dmean[2] += (-d0 * d2 * dd0 - d1 * d2 * dd1 + (sum2 - d2 * d2) * dd2) * invsum32;
+            }
+            // ---- cov3D -> scale / rotation (backward.cu:278-341) ----
+            if (scales != nullptr) {
+                const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2],
+                            z = rotations[4 * idx + 3];
+                float Rm[3][3];
+                Rm[0][0] = 1.f - 2.f * (y * y + z * z);
+                Rm[1][0] = 2.f * (x * y - r * z);
+                Rm[2][0] = 2.f * (x * z + r * y);
+                Rm[0][1] = 2.f * (x * y + r * z);
+                Rm[1][1] = 1.f - 2.f * (x * x + z * z);
+                Rm[2][1] = 2.f * (y * z - r * x);
+                Rm[0][2] = 2.f * (x * z - r * y);
+                Rm[1][2] = 2.f * (y * z + r * x);
+                Rm[2][2] = 1.f - 2.f * (x * x + y * y);
+                const float s[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
+                                    scale_modifier * scales[3 * idx + 2]};
+                const float Dm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                        {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                        {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+                float G[3][3], Hh[3][3];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        G[a][b] = (2.0f * (s[a] * Rm[a][0])) * Dm[0][b] + (2.0f * (s[a] * Rm[a][1])) * Dm[1][b] +
+                                  (2.0f * (s[a] * Rm[a][2])) * Dm[2][b];
+                    }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    dscale[k] = Rm[k][0] * G[k][0] + Rm[k][1] * G[k][1] + Rm[k][2] * G[k][2];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) Hh[k][j] = G[k][j] * s[k];
+                }
+#define Mt(i_, j_) Hh[i_][j_]
+                drot[0] = 2 * z * (Mt(0, 1) - Mt(1, 0)) + 2 * y * (Mt(2, 0) - Mt(0, 2)) + 2 * x * (Mt(1, 2) - Mt(2, 1));
+                drot[1] = 2 * y * (Mt(1, 0) + Mt(0, 1)) + 2 * z * (Mt(2, 0) + Mt(0, 2)) + 2 * r * (Mt(1, 2) - Mt(2, 1)) -
+                          4 * x * (Mt(2, 2) + Mt(1, 1));
+                drot[2] = 2 * x * (Mt(1, 0) + Mt(0, 1)) + 2 * r * (Mt(2, 0) - Mt(0, 2)) + 2 * z * (Mt(1, 2) + Mt(2, 1)) -
+                          4 * y * (Mt(2, 2) + Mt(0, 0));
+                drot[3] = 2 * r * (Mt(0, 1) - Mt(1, 0)) + 2 * x * (Mt(2, 0) + Mt(0, 2)) + 2 * y * (Mt(1, 2) + Mt(2, 1)) -
+                          4 * z * (Mt(1, 1) + Mt(0, 0));
+#undef Mt
+            }
+        } else if (use_sh) {
+            for (int k = 0; k < L; k++) my_sh[k] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) dL_dmean3D[3 * idx + i] = dmean[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) dL_dscale[3 * idx + i] = dscale[i];
+        reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }
+    if (use_sh && dL_dsh != nullptr) {
+        __syncthreads();
+        const int total = cnt * L;
+        float* dst = dL_dsh + (size_t)base * L;
+        if ((L & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            for (int i = threadIdx.x; i < (total >> 2); i += DGM_PRE_BLOCK) {
+                const int e = i << 2;
+                const int g = e / L, k = e - g * L;
+                const float* s = lds + g * stride + k;
+                d4[i] = make_float4(s[0], s[1], s[2], s[3]);
+            }
+        } else {
+            for (int i = threadIdx.x; i < total; i += DGM_PRE_BLOCK) {
+                const int g = i / L, k = i - g * L;
+                dst[i] = lds[g * stride + k];
+            }
+        }
+    }
+}
+
+void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
+                           const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
+                           float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
+                           const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                           const float* rec, const unsigned* tiles_touched, const unsigned* offs, const unsigned* inv,
+                           const float* slab, const uint2* ranges, const unsigned* nproc, float* dL_dmean2D,
+                           float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                           float* dL_dsh, float* dL_dscale, float* dL_drot) {
+    const size_t lds_bytes = (shs != nullptr && M > 0) ? (size_t)DGM_PRE_BLOCK * ((3 * M) | 1) * sizeof(float) : 16;
+    const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, gridx, means3D,
+                       radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, viewmatrix, projmatrix, campos,
+                       focal_x, focal_y, tan_fovx, tan_fovy, rec, tiles_touched, offs, inv, slab, ranges, nproc,
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+}
+
+}  // namespace dgm

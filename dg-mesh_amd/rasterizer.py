@@ -1,0 +1,238 @@
+"""Drop-in replacement of the `diff_gaussian_rasterization` Python package on top of libdgmesh_hip.so.
+
+Same names, argument order, return values and error behaviour as the reference:
+  DGR/diff_gaussian_rasterization/__init__.py:21-220   (rasterize_gaussians, _RasterizeGaussians,
+                                                        GaussianRasterizationSettings, GaussianRasterizer)
+  DGR/rasterize_points.cu:35-217 / rasterize_points.h   (the three functions the pybind module `_C` exports)
+(DGR/ = /root/reference/dgmesh/submodules/diff-gaussian-rasterization/.)
+
+PyTorch is plumbing here: it owns device memory, the stream and autograd bookkeeping.  All arithmetic happens
+in the HIP library; tensors are handed over as raw device pointers through ctypes.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+NUM_CHANNELS = 3  # DGR/cuda_rasterizer/config.h:15
+
+
+def _ptr(t):
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.numel() == 0:
+        return t
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor (dg-mesh_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t.contiguous()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _resizer(t):
+    """resizeFunctional (DGR/rasterize_points.cu:27-33): grow a byte tensor, hand back its device pointer."""
+    def cb(_ctx, nbytes):
+        t.resize_(int(nbytes))
+        return t.data_ptr()
+    return _lib.ALLOC_FN(cb)
+
+
+class _CModule:
+    """Stands in for the pybind extension `diff_gaussian_rasterization._C` (DGR/ext.cpp:15-18)."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                            prefiltered, debug):
+        if means3D.ndimension() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
+        L = _lib.lib()
+        P, H, W = means3D.size(0), int(image_height), int(image_width)
+        dev = means3D.device
+        means3D = _f32c(means3D, "means3D")
+        background, colors, opacity = _f32c(background, "background"), _f32c(colors, "colors"), _f32c(opacity, "opacity")
+        scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
+        sh = _f32c(sh, "sh")
+        out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty((0,), dtype=torch.uint8, device=dev)
+        binning = torch.empty((0,), dtype=torch.uint8, device=dev)
+        img = torch.empty((0,), dtype=torch.uint8, device=dev)
+        M = sh.size(1) if sh is not None and sh.numel() != 0 else 0
+        rendered = ctypes.c_int(0)
+        cbs = (_resizer(geom), _resizer(binning), _resizer(img))
+        with torch.cuda.device(dev):
+            _lib.check(L.dgm_rasterize_forward(
+                cbs[0], None, cbs[1], None, cbs[2], None, P, int(degree), M, _ptr(background), W, H, _ptr(means3D),
+                _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                int(bool(prefiltered)), _ptr(out_color), _ptr(radii), int(bool(debug)), _stream(),
+                ctypes.byref(rendered)))
+        return rendered.value, out_color, radii, geom, binning, img
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+        L = _lib.lib()
+        P = means3D.size(0)
+        H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+        dev = means3D.device
+        means3D = _f32c(means3D, "means3D")
+        background, colors = _f32c(background, "background"), _f32c(colors, "colors")
+        scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
+        sh, dL = _f32c(sh, "sh"), _f32c(dL_dout_color, "dL_dout_color")
+        radii = radii.contiguous()
+        M = sh.size(1) if sh is not None and sh.numel() != 0 else 0
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        # the library overwrites every element; only dL_dsh needs zeros when the SH branch is off
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors = new(P, 3), new(P, 3), new(P, NUM_CHANNELS)
+        dL_dconic, dL_dopacity, dL_dcov3D = new(P, 2, 2), new(P, 1), new(P, 6)
+        dL_dscales, dL_drotations = new(P, 3), new(P, 4)
+        sh_active = M > 0 and (colors is None or colors.numel() == 0)
+        dL_dsh = new(P, M, 3) if sh_active else torch.zeros((P, M, 3), dtype=torch.float32, device=dev)
+        if P != 0:
+            with torch.cuda.device(dev):
+                _lib.check(L.dgm_rasterize_backward(
+                    P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                    _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer),
+                    _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL), _ptr(dL_dmeans2D), _ptr(dL_dconic),
+                    _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
+                    _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)), _stream()))
+            if scales is None or scales.numel() == 0:
+                dL_dscales.zero_()
+                dL_drotations.zero_()
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        P = means3D.size(0)
+        present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+        if P != 0:
+            means3D = _f32c(means3D, "means3D")
+            viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
+            with torch.cuda.device(means3D.device):
+                _lib.check(_lib.lib().dgm_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix),
+                                                       _ptr(present), _stream()))
+        return present
+
+
+_C = _CModule()
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+            try:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        num_rendered = ctx.num_rendered
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
+            ctx.saved_tensors
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+                geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                grads = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            grads = _C.rasterize_gaussians_backward(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = grads
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

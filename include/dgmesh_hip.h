@@ -1,0 +1,154 @@
+/*
+ * dgmesh_hip.h -- C ABI of libdgmesh_hip.so, the MI355X (gfx950) implementation of the
+ * DG-Mesh training hot path: differentiable 3D-Gaussian rasterizer, simple-knn, fused
+ * deformation MLP.
+ *
+ * This header is the drop-in boundary.  Every entry point replaces one interface of the
+ * reference (paths relative to /root/reference/dgmesh/submodules/):
+ *
+ *   dgm_rasterize_forward   <- CudaRasterizer::Rasterizer::forward
+ *                              diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:35-59
+ *                              (impl rasterizer_impl.cu:198-336), reached from Python through
+ *                              RasterizeGaussiansCUDA, rasterize_points.cu:35-114
+ *   dgm_rasterize_backward  <- CudaRasterizer::Rasterizer::backward, rasterizer.h:61-85
+ *                              (impl rasterizer_impl.cu:340-434); RasterizeGaussiansBackwardCUDA,
+ *                              rasterize_points.cu:117-196
+ *   dgm_mark_visible        <- CudaRasterizer::Rasterizer::markVisible, rasterizer.h:28-33
+ *                              (impl rasterizer_impl.cu:141-153); markVisible, rasterize_points.cu:198-217
+ *   dgm_knn_mean_dist2      <- SimpleKNN::knn, simple-knn/simple_knn.h:16-19 (impl simple_knn.cu:185-221);
+ *                              distCUDA2, simple-knn/spatial.cu:15-26
+ *   dgm_mlp_*               <- DeformNetwork* / AppearanceNetwork forward+backward,
+ *                              dgmesh/utils/time_utils.py:58-323 (plain nn.Linear there)
+ *
+ * Conventions (same as the reference unless stated):
+ *   - all `const float*` / `float*` / `int*` arguments are DEVICE pointers; optional inputs are
+ *     passed as NULL exactly where the reference receives data_ptr()==nullptr from a 0-element
+ *     tensor (colors_precomp, cov3D_precomp, shs, scales, rotations);
+ *   - matrices are the reference's transposed (row-vector) 4x4 fp32, i.e. column-major for the
+ *     kernels (dgmesh/scene/cameras.py:60-71);
+ *   - scratch memory is caller-owned: forward obtains three opaque byte buffers through
+ *     allocator callbacks (the reference's std::function<char*(size_t)>), backward receives the
+ *     same three pointers back.  Their layout is private to this library (dgm_describe_state
+ *     exposes it for the parity tests only);
+ *   - every function returns 0 on success, non-zero on error (message via dgm_last_error());
+ *     the reference throws std::runtime_error / AT_ERROR at the same points;
+ *   - `stream` is a hipStream_t (NULL = default stream).  Unlike the reference (legacy default
+ *     stream everywhere) all work is enqueued on the caller's stream;
+ *   - outputs are fully OVERWRITTEN (the reference accumulates into pre-zeroed tensors); callers
+ *     need not zero-fill out_color, radii or any dL_d* array.
+ */
+#ifndef DGMESH_HIP_H
+#define DGMESH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGM_ABI_VERSION 1
+
+/* Allocator callback: must return a device pointer to at least `bytes` bytes (128-byte aligned),
+ * valid until the matching backward has run.  Mirrors resizeFunctional, rasterize_points.cu:27-33. */
+typedef char* (*dgm_alloc_fn)(void* ctx, size_t bytes);
+
+int dgm_abi_version(void);
+const char* dgm_last_error(void);
+
+/* ---- rasterizer ------------------------------------------------------------------------- */
+
+/* P Gaussians, D = active SH degree, M = SH coefficients per Gaussian (0 if shs == NULL).
+ * out_color: (3,H,W) fp32.  radii: (P) int32 or NULL.  *num_rendered receives R (host int),
+ * which costs one 4-byte device->host read-back exactly like rasterizer_impl.cu:281. */
+int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                          dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                          int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                          const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                          int* radii, int debug, void* stream, int* num_rendered);
+
+/* Gradient outputs (all fully written): dL_dmean2D (P,3), dL_dconic (P,4: slots x,y,w used),
+ * dL_dopacity (P), dL_dcolor (P,3), dL_dmean3D (P,3), dL_dcov3D (P,6), dL_dsh (P,M,3) or NULL when
+ * M == 0, dL_dscale (P,3), dL_drot (P,4). */
+int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                           const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                           float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                           char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                           float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                           float* dL_dscale, float* dL_drot, int debug, void* stream);
+
+/* present: (P) bytes, 1 = view-space z > 0.2 */
+int dgm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream);
+
+/* Sizes of the three scratch buffers (what the allocator callbacks will be asked for). */
+size_t dgm_geometry_bytes(int P, int width, int height);
+size_t dgm_binning_bytes(int R);
+size_t dgm_image_bytes(int width, int height);
+
+/* Byte offsets of the arrays inside the scratch buffers -- TEST/INTROSPECTION ONLY. */
+typedef struct {
+    /* geometry buffer */
+    size_t rec;           /* float[P][12]: x, y, conic a, b, c, opacity, r, g, b, rect(u32), offs(u32), 0 */
+    size_t depth;         /* float[P]   view-space z */
+    size_t radii;         /* int[P]     */
+    size_t tiles_touched; /* u32[P]     */
+    size_t offs;          /* u32[P]     EXCLUSIVE scan of tiles_touched (reference stores the inclusive scan) */
+    size_t cov3D;         /* float[P][6] */
+    size_t clamped;       /* u8[P]      bit ch set = colour channel ch clamped at 0 */
+    size_t block_sums;    /* u32[ceil(P/256)] */
+    size_t block_offs;    /* u32[ceil(P/256)] */
+    size_t hist;          /* u32[n_chunks][tiles] */
+    size_t tile_count;    /* u32[tiles] */
+    size_t tile_offset;   /* u32[tiles+1] */
+    size_t big_list;      /* u32[tiles] worklist of tiles with more than 2048 instances */
+    size_t counters;      /* u32[8]: [0] = num_rendered, [1] = error flags, [2] = big_list length */
+    size_t geometry_bytes;
+    /* binning buffer */
+    size_t keys;       /* u64[R]  (depth_bits << 32 | gaussian), grouped by tile, unsorted within a tile */
+    size_t point_list; /* u32[R]  gaussian ids, by tile then depth then id: identical to the reference's */
+    size_t inv;        /* u32[R]  inv[offs[g] + k] = slot of g's k-th tile instance in point_list */
+    size_t slab;       /* float[R][12] per-instance gradient rows written by backward */
+    size_t binning_bytes;
+    /* image buffer */
+    size_t final_T;   /* float[H*W] */
+    size_t n_contrib; /* u32[H*W] */
+    size_t ranges;    /* uint2[tiles] */
+    size_t nproc;     /* u32[tiles] instances replayed by backward */
+    size_t image_bytes;
+    int tiles_x, tiles_y, n_chunks, chunk_size;
+} dgm_state_layout;
+
+int dgm_describe_state(int P, int width, int height, int R, dgm_state_layout* out);
+
+/* Per-stage device timings (ms) of the most recent forward/backward on this thread, measured with
+ * hipEvents on the caller's stream.  Enable with dgm_set_profiling(1) (adds event records and one
+ * stream sync per call).  names: see DGM_STAGE_* . Returns the number of stages written. */
+enum {
+    DGM_STAGE_PREPROCESS = 0,
+    DGM_STAGE_BIN_COUNT,
+    DGM_STAGE_BIN_SCAN,
+    DGM_STAGE_BIN_SCATTER,
+    DGM_STAGE_TILE_SORT,
+    DGM_STAGE_RENDER_FWD,
+    DGM_STAGE_RENDER_BWD,
+    DGM_STAGE_PREPROCESS_BWD,
+    DGM_STAGE_COUNT
+};
+void dgm_set_profiling(int enabled);
+int dgm_get_stage_ms(float* ms, int capacity);
+const char* dgm_stage_name(int stage);
+
+/* ---- simple-knn --------------------------------------------------------------------------- */
+
+/* points: (P,3) fp32 device; mean_dists: (P) fp32 device = mean of the 3 smallest squared distances. */
+int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGMESH_HIP_H */

@@ -1,0 +1,285 @@
+"""GPU parity tests of the HIP rasterizer (through the reference-shaped `_C` API over the C ABI) against the
+CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): tile / splat indices bit-exact; rendered RGB, alpha (final_T) and gradients
+within 1e-4 fp32.  Concretely:
+  * radii, tile rects, tiles_touched, offsets, num_rendered, point_list, ranges, depth bits, means2D, conic,
+    cov3D, rgb, clamp flags: EXACT (np.array_equal) -- the preprocess kernel follows the canonical op order;
+  * n_contrib: exact on every pixel the oracle does not flag `fragile` (a blend decision within rounding
+    distance of its threshold, where exp()/FMA differences may legitimately flip it);
+  * out_color / final_T: |err| <= 1e-4 on pixels without a fragile alpha decision;
+  * gradients: max|err| <= 1e-4 * max|ref| per tensor (plus 1e-4 relative), deterministic run to run.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_backward, oracle_forward, raster_args
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def check_forward(orc, a, f_hip, exact_geom=True):
+    f = oracle_forward(orc, a)
+    P = a["means3D"].shape[0]
+    assert f_hip["num_rendered"] == f["num_rendered"]
+    assert np.array_equal(f_hip["radii"], f["radii"])
+    if P == 0:
+        return f
+    g = f["geom"]
+    vis = g["radii"] > 0
+    assert np.array_equal(f_hip["radii_int"], g["radii"])
+    assert np.array_equal(f_hip["tiles_touched"], g["tiles_touched"])
+    incl = f["binning"]["point_offsets"]
+    assert np.array_equal(f_hip["offs"], incl - g["tiles_touched"])  # exclusive vs the reference's inclusive scan
+    assert np.array_equal(f_hip["rec_offs"][vis], f_hip["offs"][vis])
+    assert np.array_equal(f_hip["depths"].view(np.uint32), g["depths"].view(np.uint32))
+    if exact_geom:
+        for name in ("means2D", "conic_opacity", "rgb"):
+            assert np.array_equal(f_hip[name][vis].view(np.uint32), g[name][vis].view(np.uint32)), name
+        if a["cov3D_precomp"] is None:
+            alive = g["cov3D"].any(1)
+            assert np.array_equal(f_hip["cov3D"][alive].view(np.uint32), g["cov3D"][alive].view(np.uint32))
+        if a["colors_precomp"] is None:
+            cl = g["clamped"][:, 0] | (g["clamped"][:, 1] << 1) | (g["clamped"][:, 2] << 2)
+            assert np.array_equal(f_hip["clamped"][vis], cl[vis])
+    b = f["binning"]
+    assert np.array_equal(f_hip["ranges"], b["ranges"])
+    assert np.array_equal(f_hip["point_list"], b["point_list"])
+    # inverse map consistency: inv[offs[g]+k] is the slot holding g in the k-th tile of its rectangle
+    if f["num_rendered"]:
+        inv = f_hip["inv"]
+        assert np.array_equal(np.sort(inv), np.arange(f["num_rendered"], dtype=np.uint32))
+        owner = np.repeat(np.arange(P, dtype=np.uint32), g["tiles_touched"])
+        assert np.array_equal(f_hip["point_list"][inv], owner)
+    img = f["img"]
+    frag = img["fragile"]
+    assert frag.mean() < 0.05
+    ok_n = frag == 0
+    assert np.array_equal(f_hip["n_contrib"][ok_n], img["n_contrib"][ok_n])
+    ok_c = (frag & 1) == 0
+    err = np.abs(f_hip["color"] - f["color"])
+    assert err[:, ok_c].max() <= 1e-4, err[:, ok_c].max()
+    assert np.abs(f_hip["final_T"] - img["final_T"])[ok_c].max() <= 1e-4
+    # fragile pixels may differ by one threshold decision: bounded by alpha*T <= ~1/255 per decision
+    assert err.max() <= 0.05
+    return f
+
+
+def check_backward(orc, a, f_or, f_hip, seed=0, tol=1e-4):
+    H, W = a["H"], a["W"]
+    dL = np.random.RandomState(seed).randn(3, H, W).astype(np.float32)
+    # mask the loss on fragile pixels (and their forward state differs legitimately)
+    dL[:, f_or["img"]["fragile"] != 0] = 0
+    g_or = oracle_backward(orc, f_or, a, dL)
+    g_hip = G.hip_backward(a, f_hip, dL)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations",
+              "dL_dcolors"):
+        ref = g_or[k].reshape(g_hip[k].shape) if g_or[k].size else g_or[k]
+        if ref.size == 0:
+            continue
+        if k == "dL_dcolors" and a["colors_precomp"] is None:
+            pass  # still defined: gradient w.r.t. the SH-evaluated colour
+        err = np.abs(g_hip[k].astype(np.float64) - ref.astype(np.float64))
+        bound = tol * np.abs(ref).max() + tol * np.abs(ref)
+        bad = err > bound
+        assert not bad.any(), f"{k}: {bad.sum()} elements, worst rel-to-max {G.rel_to_max(g_hip[k], ref):.3e}"
+    return g_hip
+
+
+@pytest.mark.parametrize("kind,P,W,H,seed", [
+    ("init", 3000, 200, 136, 1),
+    ("aniso", 2500, 123, 77, 2),       # W, H not multiples of 16
+    ("trained", 4000, 160, 160, 3),    # early termination
+    ("init", 20000, 400, 400, 0),      # BASELINE cfg1
+])
+def test_forward_backward_parity(orc, syn, kind, P, W, H, seed):
+    a = raster_args(syn, P, W, H, seed=seed, kind=kind)
+    f_hip = G.hip_forward(a)
+    f_or = check_forward(orc, a, f_hip)
+    check_backward(orc, a, f_or, f_hip, seed=seed)
+
+
+def test_cfg2_full_size(orc, syn):
+    """BASELINE cfg2 (800x800, 100k Gaussians): full-size parity against the oracle."""
+    c = syn.CONFIGS["cfg2"]
+    cam = syn.config_camera("cfg2", frame=3)
+    a = raster_args(syn, c["P"], c["W"], c["H"], seed=0, kind="init", cam=cam)
+    f_hip = G.hip_forward(a)
+    f_or = check_forward(orc, a, f_hip)
+    check_backward(orc, a, f_or, f_hip)
+
+
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_large_configs_binning_exact(orc, syn, cfg):
+    """cfg4 (1080x1920 portrait, off-centre K, 300k) / cfg5 (1024^2, 500k): integer pipeline exact vs oracle;
+    blend checked through size-independent properties (bg linearity, T in [0,1], n_contrib <= range)."""
+    c = syn.CONFIGS[cfg]
+    cam = syn.config_camera(cfg, frame=7)
+    rng = np.random.RandomState(1)
+    xyz = ((rng.rand(c["P"], 3) * 2 - 1) * c.get("extent", 1.3)).astype(np.float32)
+    d2 = np.full(c["P"], (2.6 / c["P"] ** (1 / 3.0)) ** 2 * 0.3, np.float32)  # analytic stand-in for 3-NN d2
+    g = syn.make_gaussians(c["P"], seed=1, dist2=d2, extent=c.get("extent", 1.3))
+    act = syn.activate(g)
+    a = dict(bg=np.ones(3, np.float32), means3D=act["means3D"], colors_precomp=None, opacities=act["opacities"],
+             scales=act["scales"], rotations=act["rotations"], scale_modifier=1.0, cov3D_precomp=None,
+             viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+             tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2), H=c["H"], W=c["W"], sh=act["shs"],
+             degree=3, campos=cam.camera_center)
+    f_hip = G.hip_forward(a)
+    P, W, H = c["P"], c["W"], c["H"]
+    geom = orc.preprocess_fwd(P, 3, 16, a["means3D"], a["scales"], 1.0, a["rotations"], a["opacities"], a["sh"], None,
+                              None, a["viewmatrix"], a["projmatrix"], a["campos"], W, H, a["tanfovx"], a["tanfovy"])
+    b = orc.bin_tiles(P, W, H, geom)
+    assert f_hip["num_rendered"] == b["num_rendered"]
+    assert np.array_equal(f_hip["radii"], geom["radii"])
+    assert np.array_equal(f_hip["tiles_touched"], geom["tiles_touched"])
+    assert np.array_equal(f_hip["ranges"], b["ranges"])
+    assert np.array_equal(f_hip["point_list"], b["point_list"])
+    gx = (W + 15) // 16
+    yy, xx = np.mgrid[0:H, 0:W]
+    tl = (yy // 16) * gx + xx // 16
+    assert np.all(f_hip["n_contrib"] <= (b["ranges"][tl, 1] - b["ranges"][tl, 0]))
+    assert np.all((f_hip["final_T"] >= 0) & (f_hip["final_T"] <= 1))
+    a0 = dict(a)
+    a0["bg"] = np.zeros(3, np.float32)
+    f0 = G.hip_forward(a0)
+    np.testing.assert_allclose(f_hip["color"], f0["color"] + f_hip["final_T"][None], atol=3e-7)
+    # gradients exist, are finite and reproducible
+    dL = np.random.RandomState(0).randn(3, H, W).astype(np.float32)
+    g1 = G.hip_backward(a, f_hip, dL)
+    g2 = G.hip_backward(a, f_hip, dL)
+    for k in g1:
+        assert np.isfinite(g1[k]).all()
+        assert np.array_equal(g1[k], g2[k]), f"{k} not deterministic"
+
+
+def test_edge_cases(orc, syn):
+    W = H = 64
+    a = raster_args(syn, 500, W, H, seed=4)
+    # P == 0 (rasterize_points.cu:81): image = 0, no state
+    a0 = dict(a)
+    for k in ("means3D", "opacities", "scales", "rotations", "sh"):
+        a0[k] = a[k][:0]
+    f = G.hip_forward(a0)
+    assert f["num_rendered"] == 0 and np.all(f["color"] == 0) and f["radii"].shape == (0,)
+    # everything behind the camera: R == 0, image = background
+    a1 = dict(a)
+    a1["means3D"] = (a["means3D"] * 0.01 + a["campos"][None] * 1.5).astype(np.float32)
+    f = G.hip_forward(a1)
+    f_or = check_forward(orc, a1, f)
+    assert f["num_rendered"] == 0 and np.allclose(f["color"], 1.0)
+    gb = G.hip_backward(a1, f, np.ones((3, H, W), np.float32))
+    assert all(np.all(v == 0) for v in gb.values())
+    # one Gaussian
+    a2 = dict(a)
+    for k in ("means3D", "opacities", "scales", "rotations", "sh"):
+        a2[k] = a[k][:1]
+    a2["means3D"] = np.zeros((1, 3), np.float32)
+    f = G.hip_forward(a2)
+    check_backward(orc, a2, check_forward(orc, a2, f), f)
+
+
+def test_big_tile_lists(orc, syn):
+    """> 2048 and > 16384 instances in one tile: LDS big-class sort and the global-memory fallback."""
+    for P, W, H in [(3000, 48, 48), (17000, 32, 32)]:
+        a = raster_args(syn, P, W, H, seed=6, kind="init", extent=0.4)
+        a["scales"] = (a["scales"] * 0 + 0.5).astype(np.float32)   # every Gaussian covers the whole image
+        a["opacities"] = (a["opacities"] * 0 + 0.004).astype(np.float32)
+        f_hip = G.hip_forward(a)
+        f_or = oracle_forward(orc, a)
+        assert (f_or["binning"]["ranges"][:, 1] - f_or["binning"]["ranges"][:, 0]).max() >= min(P, 16385) * 0.9
+        assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+        assert np.array_equal(f_hip["ranges"], f_or["binning"]["ranges"])
+
+
+def test_depth_ties_sorted_by_index(orc, syn):
+    """Equal depths: order must be ascending Gaussian index (what the reference's stable sort produces)."""
+    a = raster_args(syn, 600, 96, 96, seed=8)
+    a["means3D"][:, :] = a["means3D"][:1]          # all on one point -> identical depth bits
+    a["means3D"] += 0
+    f_hip = G.hip_forward(a)
+    f_or = oracle_forward(orc, a)
+    assert f_or["num_rendered"] > 0
+    assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+
+
+@pytest.mark.parametrize("variant", ["colors_precomp", "cov3D_precomp", "deg0", "deg1", "deg2", "black_bg"])
+def test_optional_inputs(orc, syn, variant):
+    a = raster_args(syn, 2000, 128, 96, seed=9, kind="aniso")
+    if variant == "colors_precomp":
+        a["colors_precomp"] = np.random.RandomState(0).rand(2000, 3).astype(np.float32)
+        a["sh"] = None
+    elif variant == "cov3D_precomp":
+        f0 = oracle_forward(orc, a)
+        a["cov3D_precomp"] = f0["geom"]["cov3D"].copy()
+        a["cov3D_precomp"][~f0["geom"]["cov3D"].any(1)] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32)
+        a["scales"] = None
+        a["rotations"] = None
+    elif variant.startswith("deg"):
+        a["degree"] = int(variant[3])
+    elif variant == "black_bg":
+        a["bg"] = np.zeros(3, np.float32)
+    f_hip = G.hip_forward(a)
+    f_or = check_forward(orc, a, f_hip)
+    check_backward(orc, a, f_or, f_hip)
+
+
+def test_module_api_autograd(orc, syn):
+    """The nn.Module / autograd.Function surface: same call as R/gaussian_renderer/__init__.py:66-114."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H, P = 160, 112, 3000
+    a = raster_args(syn, P, W, H, seed=11, kind="aniso", bg=(0.2, 0.4, 0.6))
+    dev = "cuda"
+    leaf = {k: torch.tensor(a[k], device=dev, requires_grad=True) for k in ("means3D", "opacities", "scales", "rotations", "sh")}
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=a["tanfovx"], tanfovy=a["tanfovy"], bg=torch.tensor(a["bg"], device=dev),
+        scale_modifier=1.0, viewmatrix=torch.tensor(a["viewmatrix"], device=dev),
+        projmatrix=torch.tensor(a["projmatrix"], device=dev), sh_degree=3, campos=torch.tensor(a["campos"], device=dev),
+        prefiltered=False, debug=False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    img, radii = rast(means3D=leaf["means3D"], means2D=means2D, shs=leaf["sh"], colors_precomp=None,
+                      opacities=leaf["opacities"], scales=leaf["scales"], rotations=leaf["rotations"], cov3D_precomp=None)
+    f_or = oracle_forward(orc, a)
+    assert radii.dtype == torch.int32 and np.array_equal(radii.cpu().numpy(), f_or["radii"])
+    dL = np.random.RandomState(3).randn(3, H, W).astype(np.float32)
+    dL[:, f_or["img"]["fragile"] != 0] = 0
+    (img * torch.tensor(dL, device=dev)).sum().backward()
+    g_or = oracle_backward(orc, f_or, a, dL)
+    pairs = [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),
+             ("rotations", "dL_drotations"), ("sh", "dL_dsh")]
+    for k, gk in pairs:
+        assert G.rel_to_max(leaf[k].grad.cpu().numpy(), g_or[gk].reshape(leaf[k].shape)) < 1e-4, k
+    assert G.rel_to_max(means2D.grad.cpu().numpy(), g_or["dL_dmeans2D"]) < 1e-4
+    vis = rast.markVisible(leaf["means3D"].detach())
+    assert np.array_equal(vis.cpu().numpy(), orc.mark_visible(a["means3D"], a["viewmatrix"], a["projmatrix"]))
+    with pytest.raises(Exception):
+        rast(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"], scales=leaf["scales"],
+             rotations=leaf["rotations"])  # neither shs nor colors
+    with pytest.raises(RuntimeError):
+        pkgR = __import__("diff_gaussian_rasterization")
+        pkgR._C.rasterize_gaussians(rs.bg, leaf["means3D"].detach()[:, :2], torch.empty(0), leaf["opacities"].detach(),
+                                    leaf["scales"].detach(), leaf["rotations"].detach(), 1.0, torch.empty(0),
+                                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, leaf["sh"].detach(), 3,
+                                    rs.campos, False, False)
+
+
+def test_knn_exact(orc, syn):
+    from simple_knn._C import distCUDA2
+    rng = np.random.RandomState(0)
+    for P in (1, 2, 3, 7, 5000, 100000):
+        pts = ((rng.rand(P, 3) * 2 - 1) * 1.3).astype(np.float32)
+        if P > 100:
+            pts[: P // 20] = pts[P // 20: 2 * (P // 20)]
+        got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
+        want = orc.knn(pts)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), P
+    # non-uniform (surface-like) cloud
+    v = rng.randn(30000, 3)
+    pts = (v / np.linalg.norm(v, axis=1, keepdims=True) * 0.8).astype(np.float32)
+    got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), orc.knn(pts).view(np.uint32))
