@@ -68,6 +68,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(dg-mesh_amd has no CPU or PyTorch fallback for its kernels)")
+        # torch must be imported first: it ships its own libamdhip64 and all device pointers / streams we are
+        # handed belong to that runtime.  Loading ours first would put a second HIP runtime in the process.
+        import torch  # noqa: F401
+
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)  # AttributeError here = header and library out of sync

@@ -22,13 +22,19 @@
 //    its slot in the tile list (coalesced).  A later per-Gaussian kernel gathers its rows through the
 //    inverse map, which also makes the gradient summation order deterministic (the reference's is not);
 //  * backward replays only the first max(n_contrib) instances of the tile instead of the whole list.
+#include <stdlib.h>
+
 #include "dgm_common.hpp"
 
 namespace dgm {
 
-struct QuadBox {
-    float x0, y0;  // pixel coordinates of the tile origin
-};
+// Make a wave-uniform 64-bit value provably uniform (SGPR pair) for the scalar bit loops.  NB: the builtin
+// returns a signed int -- widen through `unsigned`, or the low half is sign-extended into the high half.
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
 
 // Which of the tile's four 8x8 quadrants can receive alpha >= 1/255 from this splat?
 // alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o);  the ellipse {q <= tau} has the
@@ -53,6 +59,7 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float a, flo
     return m;
 }
 
+template <bool CULL, int MODE = 0>
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
@@ -78,7 +85,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     bool done = !inside;
 
     for (int i = 0; i < rounds; i++) {
-        if (__syncthreads_and(done)) break;  // also orders the previous round's LDS reads before the refill
+        if (MODE & 1) {
+            __syncthreads();
+        } else if (__syncthreads_and(done)) break;  // also orders the previous round's LDS reads before the refill
         const int at = (i << 8) + threadIdx.x;
         unsigned qm = 0;
         if (at < n) {
@@ -89,7 +98,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             sA[threadIdx.x] = r0;
             sB[threadIdx.x] = r1;
             sC[threadIdx.x] = cb;
-            qm = quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx0, ty0);
+            qm = CULL ? quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx0, ty0) : 15u;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -97,13 +106,12 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             if (lane == 0) sMask[wv][q] = bal;
         }
         __syncthreads();
-        if (__ballot(!done) == 0ull) continue;  // whole quadrant finished: keep helping with staging only
+        if (!(MODE & 2) && __ballot(!done) == 0ull) continue;  // whole quadrant finished: keep helping with staging only
         const unsigned base = (unsigned)(i << 8);
 #pragma unroll 1
         for (int sw = 0; sw < 4; sw++) {
             unsigned long long m = sMask[sw][wv];
-            m = __builtin_amdgcn_readfirstlane((unsigned)m) |
-                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(m >> 32)) << 32);
+            m = uniform_u64(m);
             while (m) {
                 const int j = (sw << 6) + __builtin_ctzll(m);
                 m &= m - 1;
@@ -250,8 +258,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 #pragma unroll 1
         for (int sw = 0; sw < 4; sw++) {
             unsigned long long m = sMask[sw][wv];
-            m = __builtin_amdgcn_readfirstlane((unsigned)m) |
-                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(m >> 32)) << 32);
+            m = uniform_u64(m);
             while (m) {
                 const int j = (sw << 6) + __builtin_ctzll(m);
                 m &= m - 1;
@@ -325,8 +332,23 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
                        unsigned* n_contrib) {
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                       out_color, final_T, n_contrib);
+    static const bool no_cull = getenv("DGM_NO_CULL") != nullptr;  // debugging aid: blend every staged splat
+    const char* mode = getenv("DGM_FWD_MODE");
+    if (mode && mode[0] == '1')
+        hipLaunchKernelGGL((render_fwd_kernel<true, 1>), dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
+                           bg, out_color, final_T, n_contrib);
+    else if (mode && mode[0] == '2')
+        hipLaunchKernelGGL((render_fwd_kernel<true, 2>), dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
+                           bg, out_color, final_T, n_contrib);
+    else if (mode && mode[0] == '3')
+        hipLaunchKernelGGL((render_fwd_kernel<true, 3>), dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
+                           bg, out_color, final_T, n_contrib);
+    else if (no_cull)
+        hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
+                           bg, out_color, final_T, n_contrib);
+    else
+        hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
+                           bg, out_color, final_T, n_contrib);
 }
 
 void launch_render_bwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
