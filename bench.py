@@ -1,0 +1,202 @@
+"""bench.py -- DG-Mesh train-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic frame per rank: deformation MLP -> differentiable
+Gaussian rasterizer (forward) -> deform_back MLP + cycle loss -> 0.8 L1 + 0.2 (1-SSIM) -> backward through the
+rasterizer and both MLPs -> (N>1: one flat-bucket RCCL all-reduce) -> Adam updates.  Workload = BASELINE config
+"D-NeRF jumpingjacks, 800x800, ~100k Gaussians, single MI355X, deformation MLP on" (cfg2), synthetic data.
+Frames shard across ranks (weak scaling: every rank renders its own 800x800 frame each step).
+
+Rank 0 prints ONE JSON line.  `value` = frames trained per second over all ranks, inputs resident in HBM.
+`roofline` describes the dominant hand-written kernel (render backward), timed with hipEvents recorded on the
+launch stream inside the timed region (deferred read-out, no extra sync).  `cpu_baseline` = the same step on
+the host cores (oracle rasterizer + PyTorch-CPU MLPs), rank 0 at N=1 only, on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+WORKLOAD = "cfg2"
+
+
+def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0):
+    syn = importlib.import_module("dg-mesh_amd.synthetic")
+    S = importlib.import_module("dg-mesh_amd.scene")
+    D = importlib.import_module("dg-mesh_amd.deform")
+    T = importlib.import_module("dg-mesh_amd.trainer")
+    c = syn.CONFIGS[WORKLOAD]
+    P, W, H = c["P"], c["W"], c["H"]
+    rng = np.random.RandomState(seed)
+    xyz = ((rng.rand(P, 3) * 2 - 1) * 1.3).astype(np.float32)
+    rgb = rng.rand(P, 3).astype(np.float32)
+    g = S.GaussianModel(sh_degree=3, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    g.create_from_pcd(xyz, rgb, generator=gen)          # exercises simple-knn (distCUDA2)
+    with torch.no_grad():
+        g._features_rest.add_(0.05 * torch.randn(g._features_rest.shape, device=dev, generator=gen))
+    g.active_sh_degree = 3
+    gts = [torch.tensor(syn.gt_image(W, H, seed=i), device=dev) for i in range(n_gt)]
+    cams = [S.TorchCamera(syn.config_camera(WORKLOAD, frame=f, n_frames=n_frames), dev, gts[f % n_gt])
+            for f in range(n_frames)]
+    torch.manual_seed(seed)
+    deform = D.DeformModelNormal(is_blender=c["is_blender"], model_name="deform", device=dev, trunk_impl=mlp_impl)
+    deform_back = D.DeformModelNormal(is_blender=c["is_blender"], model_name="deform_back", device=dev, trunk_impl=mlp_impl)
+    # A freshly initialised head emits O(0.1) deltas, which would triple every Gaussian's extent (R 3M -> 7M) and
+    # measure a scene no trained model looks like.  Scale the output heads so the deformation field is small, as
+    # after convergence; the trunk (where the FLOPs are) is untouched.
+    with torch.no_grad():
+        for m in (deform.net, deform_back.net):
+            for head in (m.gaussian_warp, m.gaussian_rotation, m.gaussian_scaling, m.gaussian_normal):
+                head.weight.mul_(0.01)
+                head.bias.mul_(0.01)
+    bg = torch.tensor([1.0, 1.0, 1.0] if c["white_bg"] else [0.0, 0.0, 0.0], device=dev)
+    tr = T.Trainer(g, deform, deform_back, cams, background=bg, is_blender=c["is_blender"], rank=rank, world=world,
+                   seed=seed)
+    return tr, (P, W, H)
+
+
+def cpu_baseline(P, W, H, max_threads=32):
+    """The same train step on the host: oracle rasterizer (C, OpenMP) + the MLPs on PyTorch-CPU.  One step of the
+    full cfg2 workload is the bounded sample."""
+    syn = importlib.import_module("dg-mesh_amd.synthetic")
+    D = importlib.import_module("dg-mesh_amd.deform")
+    S = importlib.import_module("dg-mesh_amd.scene")
+    from oracle import oracle as orc
+
+    cores = min(os.cpu_count() or 1, max_threads)
+    orc.set_threads(cores)
+    torch.set_num_threads(cores)
+    g = syn.make_gaussians(P, seed=0, dist2=np.full(P, 4e-4, np.float32))
+    cam = syn.config_camera(WORKLOAD, frame=0)
+    gt = torch.tensor(syn.gt_image(W, H, 0))
+    torch.manual_seed(0)
+    nets = [D.DeformNetworkNormal(is_blender=True, trunk_impl="torch") for _ in range(2)]
+    params = [p for n in nets for p in n.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15)
+    xyz = torch.tensor(g["xyz"])
+    t_in = torch.tensor([[0.3]]).expand(P, -1)
+    tanx, tany = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    bg = np.ones(3, np.float32)
+    orc.lib()
+    t0 = time.time()
+    d_xyz, d_rot, d_scale, _ = nets[0](xyz, t_in)
+    a = syn.activate(g, d_xyz.detach().numpy(), d_rot.detach().numpy(), d_scale.detach().numpy())
+    f = orc.forward(bg, a["means3D"], None, a["opacities"], a["scales"], a["rotations"], 1.0, None,
+                    cam.world_view_transform, cam.full_proj_transform, tanx, tany, H, W, a["shs"], 3, cam.camera_center)
+    img = torch.tensor(f["color"], requires_grad=True)
+    loss_img = 0.8 * S.l1_loss(img, gt) + 0.2 * (1.0 - S.ssim(img, gt))
+    loss_img.backward()
+    gr = orc.backward(f, bg, a["means3D"], None, a["scales"], a["rotations"], 1.0, None, cam.world_view_transform,
+                      cam.full_proj_transform, tanx, tany, img.grad.numpy(), a["shs"], 3, cam.camera_center)
+    back = nets[1]((xyz + d_xyz).detach(), t_in)
+    cyc = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rot) + S.l1_loss(-back[2], d_scale)) / 3.0
+    surrogate = (d_xyz * torch.tensor(gr["dL_dmeans3D"])).sum() + (d_rot * torch.tensor(gr["dL_drotations"])).sum() + \
+        (d_scale * torch.tensor(gr["dL_dscales"])).sum()
+    (cyc + surrogate).backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"1 full {WORKLOAD} train step ({W}x{H}, P={P}, R={f['num_rendered']}): oracle rasterizer fwd+bwd "
+                      f"(C/OpenMP) + 2 deformation MLPs fwd+bwd + L1/SSIM + Adam on PyTorch-CPU, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mlp", default=os.environ.get("DGM_MLP_IMPL", "auto"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    L = importlib.import_module("dg-mesh_amd._lib")
+    mlp_impl = args.mlp
+    if mlp_impl == "auto":
+        mlp_impl = "hip" if hasattr(L.lib(), "dgm_mlp_forward") else "torch"
+
+    tr, (P, W, H) = build_scene(dev, rank, world, mlp_impl)
+    it0 = tr.opt.warm_up + 2000  # "deformation MLP on" phase (warm_up <= it < dpsr_iter)
+
+    for i in range(args.warmup):
+        tr.step(it0 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    L.lib().dgm_set_profiling(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    R_seen = []
+    for i in range(args.steps):
+        _, pkg = tr.step(it0 + args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stages = L.collect_stage_ms()
+    L.lib().dgm_set_profiling(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        # R of the last frame (all frames of the synthetic orbit are statistically alike)
+        R = int((pkg["radii"] > 0).sum().item())  # visible Gaussians (informational)
+        n_inst = int(importlib.import_module("dg-mesh_amd.rasterizer").LAST_NUM_RENDERED)  # tile instances R
+        bwd_ms, bwd_n = stages.get("render_bwd", (0.0, 0))
+        alg_bytes = 40.0 * n_inst + 20.0 * W * H + 36.0 * P  # render bwd per frame
+        achieved = (alg_bytes / (bwd_ms * 1e-3) / 1e9) if bwd_ms > 0 else 0.0
+        out = {
+            "metric": "train-step iters/sec (800x800, ~100k Gaussians)", "value": args.steps * world / elapsed,
+            "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "D-NeRF jumpingjacks-like cfg2: 800x800, P=100000 Gaussians, deformation MLP on "
+                                   "(deform + deform_back, is_blender), 1 frame per rank per step",
+                       "P": P, "W": W, "H": H, "num_rendered": n_inst, "visible": R, "mlp_impl": mlp_impl,
+                       "parallelism": f"dp{world} (frame-parallel, flat-bucket all-reduce {tr.bucket.nbytes() / 1e6:.1f} MB)"},
+            "roofline": {"kernel": "render_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms, "launches": bwd_n},
+            "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(P, W, H)
+            except Exception as ex:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,7 @@ SYMBOLS = {
     "dgm_describe_state": (_i, [_i, _i, _i, _i, _c.POINTER(StateLayout)]),
     "dgm_set_profiling": (None, [_i]),
     "dgm_get_stage_ms": (_i, [_c.POINTER(_f), _i]),
+    "dgm_collect_stage_ms": (_i, [_c.POINTER(_f), _c.POINTER(_i), _i]),
     "dgm_stage_name": (_c.c_char_p, [_i]),
     "dgm_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp]),
 }
@@ -95,3 +96,11 @@ def stage_ms():
     buf = (_f * STAGE_COUNT)()
     n = lib().dgm_get_stage_ms(buf, STAGE_COUNT)
     return {lib().dgm_stage_name(i).decode(): float(buf[i]) for i in range(n)}
+
+
+def collect_stage_ms():
+    """Deferred profiling (dgm_set_profiling(2)): {stage: (avg_ms, launches)} since the mode was set."""
+    ms = (_f * STAGE_COUNT)()
+    cnt = (_i * STAGE_COUNT)()
+    n = lib().dgm_collect_stage_ms(ms, cnt, STAGE_COUNT)
+    return {lib().dgm_stage_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}

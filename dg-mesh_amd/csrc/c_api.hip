@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -61,8 +62,21 @@ using namespace dgm;
 namespace {
 
 thread_local std::string g_err;
-thread_local bool g_profile = false;
-thread_local float g_stage_ms[DGM_STAGE_COUNT] = {0};
+// Profiling state is process-wide: PyTorch runs backward on its own autograd thread, and forward + backward of
+// one step must land in the same table.
+std::atomic<int> g_profile{0};  // 0 off, 1 immediate (syncs the stream every call), 2 deferred (no sync)
+float g_stage_ms[DGM_STAGE_COUNT] = {0};
+std::mutex g_prof_mu;
+
+// deferred mode: event pairs are parked here and only read by dgm_collect_stage_ms() after the caller has
+// synchronised, so the timed region contains no extra synchronisation.
+struct EventPair {
+    hipEvent_t a, b;
+};
+constexpr int kMaxDeferred = 4096;
+EventPair g_deferred[DGM_STAGE_COUNT][kMaxDeferred];
+int g_deferred_n[DGM_STAGE_COUNT] = {0};
+int g_deferred_created[DGM_STAGE_COUNT] = {0};
 
 int fail(const char* fmt, ...) {
     char buf[1024];
@@ -83,30 +97,48 @@ int fail(const char* fmt, ...) {
 // Records hipEvents around stages on the caller's stream when profiling is on.
 struct StageTimer {
     hipStream_t st;
-    bool on;
+    int mode;
     hipEvent_t ev[2 * DGM_STAGE_COUNT];
     bool used[DGM_STAGE_COUNT];
-    explicit StageTimer(hipStream_t s) : st(s), on(g_profile) {
+    explicit StageTimer(hipStream_t s) : st(s), mode(g_profile) {
         memset(used, 0, sizeof(used));
-        if (on)
-            for (auto& e : ev) hipEventCreate(&e);
+        if (mode == 1)
+            for (auto& e : ev) (void)hipEventCreate(&e);
     }
     void begin(int s) {
-        if (on) {
-            hipEventRecord(ev[2 * s], st);
+        if (mode == 1) {
+            (void)hipEventRecord(ev[2 * s], st);
+            used[s] = true;
+        } else if (mode == 2) {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            if (g_deferred_n[s] >= kMaxDeferred) return;
+            const int i = g_deferred_n[s];
+            if (i >= g_deferred_created[s]) {
+                (void)hipEventCreate(&g_deferred[s][i].a);
+                (void)hipEventCreate(&g_deferred[s][i].b);
+                g_deferred_created[s] = i + 1;
+            }
+            (void)hipEventRecord(g_deferred[s][i].a, st);
             used[s] = true;
         }
     }
     void end(int s) {
-        if (on) hipEventRecord(ev[2 * s + 1], st);
+        if (mode == 1) {
+            (void)hipEventRecord(ev[2 * s + 1], st);
+        } else if (mode == 2 && used[s]) {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            (void)hipEventRecord(g_deferred[s][g_deferred_n[s]].b, st);
+            g_deferred_n[s]++;
+            used[s] = false;
+        }
     }
     void finish() {
-        if (!on) return;
-        hipStreamSynchronize(st);
+        if (mode != 1) return;
+        (void)hipStreamSynchronize(st);
         for (int s = 0; s < DGM_STAGE_COUNT; s++)
-            if (used[s]) hipEventElapsedTime(&g_stage_ms[s], ev[2 * s], ev[2 * s + 1]);
-        for (auto& e : ev) hipEventDestroy(e);
-        on = false;
+            if (used[s]) (void)hipEventElapsedTime(&g_stage_ms[s], ev[2 * s], ev[2 * s + 1]);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        mode = 0;
     }
     ~StageTimer() { finish(); }
 };
@@ -137,7 +169,31 @@ extern "C" {
 int dgm_abi_version(void) { return DGM_ABI_VERSION; }
 const char* dgm_last_error(void) { return g_err.c_str(); }
 
-void dgm_set_profiling(int enabled) { g_profile = enabled != 0; }
+void dgm_set_profiling(int mode) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_profile = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    if (g_profile == 2)
+        for (int s = 0; s < DGM_STAGE_COUNT; s++) g_deferred_n[s] = 0;
+}
+int dgm_collect_stage_ms(float* avg_ms, int* counts, int capacity) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = capacity < DGM_STAGE_COUNT ? capacity : DGM_STAGE_COUNT;
+    for (int s = 0; s < n; s++) {
+        double tot = 0;
+        int ok = 0;
+        for (int i = 0; i < g_deferred_n[s]; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, g_deferred[s][i].a, g_deferred[s][i].b) == hipSuccess) {
+                tot += ms;
+                ok++;
+            }
+        }
+        avg_ms[s] = ok ? (float)(tot / ok) : 0.f;
+        if (counts) counts[s] = ok;
+        g_deferred_n[s] = 0;
+    }
+    return n;
+}
 int dgm_get_stage_ms(float* ms, int capacity) {
     int n = capacity < DGM_STAGE_COUNT ? capacity : DGM_STAGE_COUNT;
     for (int i = 0; i < n; i++) ms[i] = g_stage_ms[i];

@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import _lib
 
 NUM_CHANNELS = 3  # DGR/cuda_rasterizer/config.h:15
+LAST_NUM_RENDERED = 0  # num_rendered of the most recent forward (read by bench.py for the roofline bytes)
 
 
 def _ptr(t):
@@ -82,6 +83,8 @@ class _CModule:
                 _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), _ptr(out_color), _ptr(radii), int(bool(debug)), _stream(),
                 ctypes.byref(rendered)))
+        global LAST_NUM_RENDERED
+        LAST_NUM_RENDERED = rendered.value
         return rendered.value, out_color, radii, geom, binning, img
 
     @staticmethod
@@ -115,9 +118,6 @@ class _CModule:
                     _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL), _ptr(dL_dmeans2D), _ptr(dL_dconic),
                     _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
                     _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)), _stream()))
-            if scales is None or scales.numel() == 0:
-                dL_dscales.zero_()
-                dL_drotations.zero_()
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
     @staticmethod

@@ -1,0 +1,271 @@
+"""The slice of the reference's scene layer that the training inner loop touches, with the same names.
+
+  GaussianModel   <- R/scene/gaussian_model_dpsr_dynamic_anchor.py:46-149 (parameters, activations, getters),
+                     :155-184 (create_from_pcd), :186-236 (training_setup / update_learning_rate),
+                     :679-682 (add_densification_stats)
+  render()        <- R/gaussian_renderer/__init__.py:32-119 (same signature, same returned dict)
+  l1_loss / ssim  <- R/utils/loss_utils.py:18-19, 32-76
+(R/ = /root/reference/dgmesh/.)  Mesh branch (DPSR / DiffMC / nvdiffrast), densification surgery, PLY I/O and
+dataset readers are out of scope.
+"""
+import math
+from math import exp
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .deform import get_expon_lr_func
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+C0 = 0.28209479177387814
+
+
+def RGB2SH(rgb):
+    return (rgb - 0.5) / C0
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+class GaussianModel:
+    """Parameter store with the attribute surface render() and the optimiser step use."""
+
+    def __init__(self, sh_degree=3, device="cuda"):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.device = device
+        self._xyz = self._features_dc = self._features_rest = None
+        self._scaling = self._rotation = self._opacity = self._normal = None
+        self.max_radii2D = self.xyz_gradient_accum = self.denom = None
+        self.optimizer = None
+        self.spatial_lr_scale = 5
+        self.scaling_activation = torch.exp
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = F.normalize
+
+    # -- getters (gaussian_model_dpsr_dynamic_anchor.py:122-149) --
+    @property
+    def get_scaling(self):
+        return self.scaling_activation(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    @property
+    def get_normal(self):
+        return self._normal
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    def create_from_pcd(self, points, colors, normals=None, generator=None):
+        """points (P,3), colors (P,3) in [0,1] (numpy).  Scales from simple-knn exactly as :165-166."""
+        from .knn import distCUDA2
+
+        dev = self.device
+        pts = torch.tensor(np.asarray(points), dtype=torch.float32, device=dev)
+        fused_color = RGB2SH(torch.tensor(np.asarray(colors), dtype=torch.float32, device=dev))
+        P = pts.shape[0]
+        features = torch.zeros((P, 3, (self.max_sh_degree + 1) ** 2), dtype=torch.float32, device=dev)
+        features[:, :3, 0] = fused_color
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.rand((P, 4), device=dev, generator=generator)
+        rots[:, 0] = 1
+        opacities = inverse_sigmoid(0.1 * torch.ones((P, 1), dtype=torch.float, device=dev))
+        if normals is not None:
+            nrm = torch.tensor(np.asarray(normals), dtype=torch.float32, device=dev)
+        else:
+            nrm = torch.rand((P, 3), device=dev, generator=generator)
+        self.load_raw(pts, features[:, :, 0:1].transpose(1, 2).contiguous(),
+                      features[:, :, 1:].transpose(1, 2).contiguous(), scales, rots, opacities, nrm)
+
+    def load_raw(self, xyz, f_dc, f_rest, scaling, rotation, opacity, normal=None):
+        dev = self.device
+        mk = lambda t: nn.Parameter(torch.as_tensor(t, dtype=torch.float32, device=dev).contiguous().requires_grad_(True))
+        self._xyz, self._features_dc, self._features_rest = mk(xyz), mk(f_dc), mk(f_rest)
+        self._scaling, self._rotation, self._opacity = mk(scaling), mk(rotation), mk(opacity)
+        P = self._xyz.shape[0]
+        self._normal = mk(normal if normal is not None else torch.zeros(P, 3))
+        self.max_radii2D = torch.zeros((P,), device=dev)
+
+    def parameters(self):
+        return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation,
+                self._normal]
+
+    def training_setup(self, training_args):
+        """Adam groups of gaussian_model_dpsr_dynamic_anchor.py:186-212 (eps 1e-15)."""
+        P = self._xyz.shape[0]
+        self.percent_dense = training_args.percent_dense
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=self.device)
+        self.denom = torch.zeros((P, 1), device=self.device)
+        self.spatial_lr_scale = 5
+        lr_xyz = training_args.position_lr_init * self.spatial_lr_scale
+        groups = [
+            {"params": [self._xyz], "lr": lr_xyz, "name": "xyz"},
+            {"params": [self._features_dc], "lr": training_args.feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": training_args.feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": training_args.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": training_args.scaling_lr * self.spatial_lr_scale, "name": "scaling"},
+            {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
+            {"params": [self._normal], "lr": training_args.rotation_lr * 100, "name": "normal"},
+        ]  # (the reference's 8th group, density_thres, belongs to the DPSR mesh branch: out of scope)
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        steps = training_args.position_lr_max_steps
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=lr_xyz, lr_final=training_args.position_lr_final * self.spatial_lr_scale,
+            lr_delay_mult=training_args.position_lr_delay_mult, max_steps=steps)
+        # NB the reference applies the "normal" schedule built from rotation_lr and the "rotation" schedule built
+        # from 100 * rotation_lr (gaussian_model_dpsr_dynamic_anchor.py:214-236); mirrored as is.
+        self.normal_scheduler_args = get_expon_lr_func(lr_init=training_args.rotation_lr,
+                                                       lr_final=training_args.rotation_lr * 0.1, lr_delay_mult=0.01,
+                                                       max_steps=steps)
+        self.rotation_scheduler_args = get_expon_lr_func(lr_init=training_args.rotation_lr * 100,
+                                                         lr_final=training_args.rotation_lr * 100 * 0.1,
+                                                         lr_delay_mult=0.01, max_steps=steps)
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            if group["name"] == "xyz":
+                group["lr"] = self.xyz_scheduler_args(iteration)
+            elif group["name"] == "normal":
+                group["lr"] = self.normal_scheduler_args(iteration)
+            elif group["name"] == "rotation":
+                group["lr"] = self.rotation_scheduler_args(iteration)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
+                                                              keepdim=True)
+        self.denom[update_filter] += 1
+
+
+class PipelineParams:
+    """R/arguments/__init__.py:95-100."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+class OptimizationParams:
+    """The optimiser constants of R/arguments/__init__.py:103-154 that the Gaussian branch uses."""
+    iterations = 40_000
+    warm_up = 3_000
+    position_lr_init = 0.00016
+    position_lr_final = 0.0000016
+    position_lr_delay_mult = 0.01
+    position_lr_max_steps = 40_000
+    apperance_lr_init = 0.00016
+    apperance_lr_final = 0.0000016
+    apperance_lr_delay_mult = 0.01
+    apperance_lr_max_steps = 40_000
+    deform_lr_max_steps = 40_000
+    feature_lr = 0.0025
+    opacity_lr = 0.05
+    scaling_lr = 0.001
+    rotation_lr = 0.001
+    percent_dense = 0.01
+    lambda_dssim = 0.2
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, is_6dof=False, scaling_modifier=1.0,
+           override_color=None):
+    """R/gaussian_renderer/__init__.py:32-119.  viewpoint_camera needs FoVx, FoVy, image_height, image_width,
+    world_view_transform, full_proj_transform, camera_center (torch tensors on the GPU)."""
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
+                                          device=pc.get_xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    if is_6dof:
+        if torch.is_tensor(d_xyz) is False:
+            means3D = pc.get_xyz
+        else:
+            hom = torch.cat([pc.get_xyz, torch.ones_like(pc.get_xyz[:, :1])], -1)
+            out = torch.bmm(d_xyz, hom.unsqueeze(-1)).squeeze(-1)
+            means3D = out[..., :3] / out[..., 3:]
+    else:
+        means3D = pc.get_xyz + d_xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    scales = pc.get_scaling + d_scaling
+    rotations = pc.get_rotation + d_rotation
+    shs = None
+    colors_precomp = override_color
+    if colors_precomp is None:
+        shs = pc.get_features
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii}
+
+
+def l1_loss(network_output, gt):
+    return torch.abs((network_output - gt)).mean()
+
+
+_WINDOWS = {}
+
+
+def _window(window_size, channel, like):
+    key = (window_size, channel, like.device, like.dtype)
+    if key not in _WINDOWS:
+        g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
+        g = (g / g.sum()).unsqueeze(1)
+        w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+        _WINDOWS[key] = w2.expand(channel, 1, window_size, window_size).contiguous().to(like)
+    return _WINDOWS[key]
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """R/utils/loss_utils.py:45-76 (the window is cached instead of rebuilt every call)."""
+    channel = img1.size(-3)
+    window = _window(window_size, channel, img1)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+
+
+class TorchCamera:
+    """GPU-resident view of synthetic.Camera with the attribute names of R/scene/cameras.py:18-71."""
+
+    def __init__(self, cam, device, original_image=None):
+        self.FoVx, self.FoVy = cam.FoVx, cam.FoVy
+        self.image_width, self.image_height = cam.image_width, cam.image_height
+        self.world_view_transform = torch.tensor(cam.world_view_transform, device=device)
+        self.full_proj_transform = torch.tensor(cam.full_proj_transform, device=device)
+        self.camera_center = torch.tensor(cam.camera_center, device=device)
+        self.fid = torch.tensor([cam.fid], dtype=torch.float32, device=device)
+        self.original_image = None if original_image is None else torch.as_tensor(original_image, device=device).clamp(0.0, 1.0)

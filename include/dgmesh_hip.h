@@ -125,9 +125,13 @@ typedef struct {
 
 int dgm_describe_state(int P, int width, int height, int R, dgm_state_layout* out);
 
-/* Per-stage device timings (ms) of the most recent forward/backward on this thread, measured with
- * hipEvents on the caller's stream.  Enable with dgm_set_profiling(1) (adds event records and one
- * stream sync per call).  names: see DGM_STAGE_* . Returns the number of stages written. */
+/* Per-stage device timings, measured with hipEvents recorded on the caller's stream around each stage.
+ * dgm_set_profiling(1): immediate -- every forward/backward call synchronises the stream and
+ *     dgm_get_stage_ms() returns the durations of the most recent call;
+ * dgm_set_profiling(2): deferred -- calls only record events (no synchronisation inside a timed region);
+ *     after the caller has synchronised, dgm_collect_stage_ms() returns the average duration and the
+ *     number of launches of every stage since the mode was set (and resets them);
+ * dgm_set_profiling(0): off.  State is process-wide (PyTorch runs backward on its own thread). */
 enum {
     DGM_STAGE_PREPROCESS = 0,
     DGM_STAGE_BIN_COUNT,
@@ -139,8 +143,9 @@ enum {
     DGM_STAGE_PREPROCESS_BWD,
     DGM_STAGE_COUNT
 };
-void dgm_set_profiling(int enabled);
+void dgm_set_profiling(int mode);
 int dgm_get_stage_ms(float* ms, int capacity);
+int dgm_collect_stage_ms(float* avg_ms, int* counts, int capacity);
 const char* dgm_stage_name(int stage);
 
 /* ---- simple-knn --------------------------------------------------------------------------- */

@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define BLOCK_X 16 /* DGR/cuda_rasterizer/config.h:16-17 */
 #define BLOCK_Y 16
@@ -430,9 +433,21 @@ void orc_render_bwd(int P, const uint32_t* ranges, const uint32_t* point_list, i
                     const uint32_t* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dconic,
                     float* dL_dopacity, float* dL_dcolors) {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
-    double* acc = (double*)calloc((size_t)P * 9, sizeof(double));
+    /* thread-private binary64 accumulators (<= 32 threads), reduced in thread order afterwards */
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+    if (nthreads > 32) nthreads = 32;
+#endif
+    double* acc_all = (double*)calloc((size_t)nthreads * P * 9, sizeof(double));
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (int tile = 0; tile < gx * gy; tile++) {
+        int tid_ = 0;
+#ifdef _OPENMP
+        tid_ = omp_get_thread_num();
+#endif
+        double* acc = acc_all + (size_t)tid_ * P * 9;
         int tx = tile % gx, ty = tile / gx;
         uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
         if (r0 == r1) continue;
@@ -487,7 +502,9 @@ void orc_render_bwd(int P, const uint32_t* ranges, const uint32_t* point_list, i
             }
     }
     for (int i = 0; i < P; i++) {
-        const double* a = acc + (size_t)i * 9;
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < nthreads; t++)
+            for (int k = 0; k < 9; k++) a[k] += acc_all[((size_t)t * P + i) * 9 + k];
         dL_dcolors[3 * i] = (float)a[0];
         dL_dcolors[3 * i + 1] = (float)a[1];
         dL_dcolors[3 * i + 2] = (float)a[2];
@@ -500,7 +517,7 @@ void orc_render_bwd(int P, const uint32_t* ranges, const uint32_t* point_list, i
         dL_dconic[4 * i + 3] = (float)a[7];
         dL_dopacity[i] = (float)a[8];
     }
-    free(acc);
+    free(acc_all);
 }
 
 /* DGR/cuda_rasterizer/backward.cu:144-274 (computeCov2DCUDA).  Writes dL_dcov (P,6) and ASSIGNS
