@@ -26,6 +26,12 @@ class StateLayout(_c.Structure):
         (n, _c.c_int) for n in ("tiles_x", "tiles_y", "n_chunks", "chunk_size")]
 
 
+class MlpParams(_c.Structure):
+    """Mirror of dgm_mlp_params (include/dgmesh_hip.h)."""
+    _fields_ = [(n, _c.c_int) for n in ("n_layers", "width", "emb_dim", "t_dim", "skip_layer", "n_out")] + [
+        ("W", _vp * 8), ("b", _vp * 8), ("Wh", _vp), ("bh", _vp)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/dgmesh_hip.h
 _f, _i = _c.c_float, _c.c_int
 SYMBOLS = {
@@ -46,6 +52,9 @@ SYMBOLS = {
     "dgm_collect_stage_ms": (_i, [_c.POINTER(_f), _c.POINTER(_i), _i]),
     "dgm_stage_name": (_c.c_char_p, [_i]),
     "dgm_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp]),
+    "dgm_mlp_workspace_bytes": (_c.c_size_t, [_i]),
+    "dgm_mlp_forward": (_i, [_c.POINTER(MlpParams), _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dgm_mlp_backward": (_i, [_c.POINTER(MlpParams), _i, _vp, _i, _vp, _vp * 8, _vp * 8, _vp, _vp, _vp, _vp]),
 }
 
 _LIB = None

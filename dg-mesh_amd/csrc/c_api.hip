@@ -60,8 +60,14 @@ void launch_knn(hipStream_t st, int P, const float* pts, float* dists, char* scr
 using namespace dgm;
 
 namespace {
-
 thread_local std::string g_err;
+}
+namespace dgm {
+void set_last_error(const char* msg) { g_err = msg ? msg : ""; }
+}  // namespace dgm
+
+namespace {
+
 // Profiling state is process-wide: PyTorch runs backward on its own autograd thread, and forward + backward of
 // one step must land in the same table.
 std::atomic<int> g_profile{0};  // 0 off, 1 immediate (syncs the stream every call), 2 deferred (no sync)

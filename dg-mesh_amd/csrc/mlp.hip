@@ -1,0 +1,667 @@
+// Deformation / appearance MLP trunk for gfx950 on the fp32 matrix cores.
+//
+// Replaces the nn.Linear + F.relu chain of DeformNetwork* / AppearanceNetwork (R/utils/time_utils.py:104-129,
+// 178-204, 252-266, 310-323): positional encoding of x, 8 x 256 ReLU layers with the skip re-injection of
+// [PE(x), t_emb] before layer 5, linear heads -- forward and backward (dX, dW, db, dt_emb).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: bitwise a k-ordered fmaf chain), so results
+// match an fp32 reference to rounding; no reduced precision anywhere.
+//
+// MI355X design:
+//  * one GEMM kernel shape for every 256-wide layer: 128 x 256 output tile per 512-thread workgroup, 8 waves
+//    as 2 (rows) x 4 (cols), each wave 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs); K is consumed in
+//    16-deep stages that are register-staged global -> LDS with one barrier per stage (loads of stage s+1 are
+//    in flight while stage s is multiplied); A is stored k-major in LDS with row stride 130 (130 = 2 mod 8 makes
+//    both the transposing ds_write_b32 and the fragment ds_read_b32 conflict free), B rows are 256 floats;
+//  * the skip layer reads its input as TWO K-segments ([emb | h4]) -- the concatenation is never materialised;
+//  * bias + ReLU are the forward epilogue; the backward-data epilogue multiplies by the ReLU mask of the layer
+//    BELOW, so each backward GEMM directly emits the next layer's pre-masked gradient;
+//  * weight gradients reduce over the 100k rows: row chunks of 512 x 128-wide K slabs per workgroup write
+//    partial [Kp x 256] tiles that a second kernel sums in fixed order (deterministic, no atomics); bias
+//    gradients ride along as column sums of the same G tiles;
+//  * t is the same for every row in training, so dL/dt_emb = db . W[:, t-columns] (no per-row GEMM); the general
+//    per-row case has its own small kernel.
+#include "dgm_common.hpp"
+
+namespace dgm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int MLP_W = 256;     // trunk width (the reference hard-codes W=256)
+static constexpr int MLP_EMB = 96;    // padded width of [PE(x) | t_emb]: 63 + 30 (blender) or 63 + 21, zero padded
+static constexpr int MLP_XE = 63;     // PE(x) width: 3 + 3*2*10
+static constexpr int GM = 64, GK = 16, GAP = 66;  // GEMM tile rows, K stage, padded LDS row stride of A (= 2 mod 8)
+static constexpr int DW_ROWS = 512;   // rows per dW chunk
+static constexpr int DW_SLAB = 128;   // K columns per dW workgroup
+static constexpr int HD_ROWS = 128;   // rows per head-gradient chunk
+
+// ---- weight preparation -----------------------------------------------------------------------------------------
+// Wt (forward B operand): [Kp x 256] with Wt[k][j] = W[j][src(k)], zero rows for padding.
+//   layer 0: Kp = 96,  src(k) = k for k < emb_dim
+//   skip   : Kp = 352, src(k) = k for k < emb_dim ; src(k) = k - 96 + emb_dim for k >= 96
+//   others : Kp = 256, src(k) = k
+// Wd (backward-data B operand): [256 x 256] with Wd[k][j] = W[k][hoff + j]   (hoff = emb_dim for the skip layer)
+__global__ void mlp_prep_kernel(int in_features, int Kp, int emb_dim, int is_skip, const float* __restrict__ W,
+                                float* __restrict__ Wt, float* __restrict__ Wd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < Kp * MLP_W) {
+        const int k = idx / MLP_W, j = idx % MLP_W;
+        int src = -1;
+        if (Kp == MLP_W) src = k;
+        else if (k < MLP_EMB) src = k < emb_dim ? k : -1;
+        else src = k - MLP_EMB + emb_dim;
+        Wt[idx] = src >= 0 ? W[(size_t)j * in_features + src] : 0.f;
+    }
+    if (Wd != nullptr && idx < MLP_W * MLP_W) {
+        const int k = idx / MLP_W, j = idx % MLP_W;
+        Wd[idx] = W[(size_t)k * in_features + (is_skip ? emb_dim : 0) + j];
+    }
+}
+
+// ---- positional encoding -------------------------------------------------------------------------------------------
+// emb[r] = [x, sin(x 2^0), cos(x 2^0), ..., sin(x 2^9), cos(x 2^9) | t_emb[r] | 0...]   (time_utils.py:24-55)
+__global__ void mlp_embed_kernel(int N, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride,
+                                 int T, float* __restrict__ emb) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * MLP_EMB) return;
+    const int r = (int)(idx / MLP_EMB), c = (int)(idx % MLP_EMB);
+    float v = 0.f;
+    if (c < 3) {
+        v = x[3 * r + c];
+    } else if (c < MLP_XE) {
+        const int q = (c - 3) / 6, w = (c - 3) % 6;
+        const float arg = x[3 * r + (w % 3)] * (float)(1 << q);
+        v = w < 3 ? sinf(arg) : cosf(arg);
+    } else if (c < MLP_XE + T) {
+        v = temb[(size_t)r * temb_stride + (c - MLP_XE)];
+    }
+    emb[idx] = v;
+}
+
+// ---- the 256-wide GEMM: C[M x 256] = [A1 | A2][M x (K1+K2)] * Bt[(K1+K2) x 256] ------------------------------------
+// EPI 0: C = relu(acc + bias), and the ReLU mask is saved as bits: mask[row][col / 32] bit (col % 32)
+// EPI 1: C = acc where the saved mask bit of the layer below is set, else 0  (backward data: the product is
+//        directly the gradient w.r.t. the pre-activation of the layer below)
+// 64 x 256 output tile per 256-thread workgroup (4 waves side by side, each 64 x 64 = 2 x 2 MFMA tiles): small
+// tiles keep the 100k-row problem balanced over 256 CUs (1563 tiles), 4 workgroups fit a CU.
+template <int EPI>
+__global__ void __launch_bounds__(256)
+mlp_gemm_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2, int K2,
+                const float* __restrict__ Bt, const float* __restrict__ bias, unsigned* __restrict__ mask,
+                float* __restrict__ C) {
+    __shared__ float As[2][GK * GAP];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * MLP_W];
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int m0 = blockIdx.x * GM;
+    const int nk = (K1 + K2) / GK;
+    const int a_row = tid >> 2, a_c4 = tid & 3;  // A tile: 64 rows x 4 float4
+    const int b_k0 = tid >> 6, b_j4 = tid & 63;  // B tile: rows b_k0 + {0,4,8,12}, 64 float4 per row
+    const bool a_ok = (m0 + a_row) < M;
+    // register staging of the next K stage (plain scalars + macros: an array or a by-reference lambda capture here
+    // is demoted to scratch memory by the compiler)
+    float4 ra, rb0, rb1, rb2, rb3;
+#define MLP_LOAD_STAGE(kt_)                                                                                          \
+    {                                                                                                                \
+        const int k_ = (kt_) * GK;                                                                                   \
+        const float* src_ = (k_ < K1) ? (A1 + (size_t)(m0 + a_row) * lda1 + k_)                                      \
+                                      : (A2 + (size_t)(m0 + a_row) * lda2 + (k_ - K1));                              \
+        ra = a_ok ? *reinterpret_cast<const float4*>(src_ + a_c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);             \
+        const float* bsrc_ = Bt + (size_t)(k_ + b_k0) * MLP_W + b_j4 * 4;                                            \
+        rb0 = *reinterpret_cast<const float4*>(bsrc_);                                                               \
+        rb1 = *reinterpret_cast<const float4*>(bsrc_ + 4 * MLP_W);                                                   \
+        rb2 = *reinterpret_cast<const float4*>(bsrc_ + 8 * MLP_W);                                                   \
+        rb3 = *reinterpret_cast<const float4*>(bsrc_ + 12 * MLP_W);                                                  \
+    }
+#define MLP_STORE_STAGE(buf_)                                                                                        \
+    {                                                                                                                \
+        float* a_ = As[buf_] + (a_c4 * 4) * GAP + a_row;                                                             \
+        a_[0] = ra.x;                                                                                                \
+        a_[GAP] = ra.y;                                                                                              \
+        a_[2 * GAP] = ra.z;                                                                                          \
+        a_[3 * GAP] = ra.w;                                                                                          \
+        float* b_ = Bs[buf_] + b_k0 * MLP_W + b_j4 * 4;                                                              \
+        *reinterpret_cast<float4*>(b_) = rb0;                                                                        \
+        *reinterpret_cast<float4*>(b_ + 4 * MLP_W) = rb1;                                                            \
+        *reinterpret_cast<float4*>(b_ + 8 * MLP_W) = rb2;                                                            \
+        *reinterpret_cast<float4*>(b_ + 12 * MLP_W) = rb3;                                                           \
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    MLP_LOAD_STAGE(0)
+    MLP_STORE_STAGE(0)
+    __syncthreads();
+    const int a_off = lane & 31, b_off = wn * 64 + (lane & 31), kh = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) MLP_LOAD_STAGE(kt + 1)
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; kk++) {
+            const int k = 2 * kk + kh;
+            const float a0 = as[k * GAP + a_off], a1 = as[k * GAP + a_off + 32];
+            const float b0 = bs[k * MLP_W + b_off], b1 = bs[k * MLP_W + b_off + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) MLP_STORE_STAGE(buf ^ 1)
+        __syncthreads();
+    }
+    // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int col = wn * 64 + nt * 32 + (lane & 31);
+            const int mword = wn * 2 + nt;  // 32-column group of this tile
+            const float bv = (EPI == 0) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float v = acc[mt][nt][r];
+                if (EPI == 0) {
+                    v = fmaxf(v + bv, 0.f);
+                    const unsigned long long bal = __ballot(v > 0.f);  // low half: row, high half: row + 4
+                    if ((lane & 31) == 0 && row < M) mask[(size_t)row * 8 + mword] = (unsigned)(bal >> (kh * 32));
+                } else {
+                    const unsigned bits = row < M ? mask[(size_t)row * 8 + mword] : 0u;
+                    v = ((bits >> (lane & 31)) & 1u) ? v : 0.f;
+                }
+                if (row < M) C[(size_t)row * MLP_W + col] = v;
+            }
+        }
+}
+
+#undef MLP_LOAD_STAGE
+#undef MLP_STORE_STAGE
+
+// ---- weight gradient: partial[chunk][k][j] = sum_{rows of chunk} X[row][k] * G[row][j] --------------------------------
+__global__ void __launch_bounds__(512)
+mlp_dw_kernel(int M, const float* __restrict__ X1, int ldx1, int K1, const float* __restrict__ X2, int ldx2, int K2,
+              const float* __restrict__ G, float* __restrict__ partial, float* __restrict__ partial_db) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][GK * DW_SLAB];
+    __shared__ __attribute__((aligned(16))) float Gs[2][GK * MLP_W];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 2, wn = wv & 3;
+    const int Kp = K1 + K2;
+    const int slab = blockIdx.x, chunk = blockIdx.y;
+    const int r0 = chunk * DW_ROWS;
+    const int nst = DW_ROWS / GK;
+    const int x_r = tid >> 5, x_c4 = tid & 31;      // X tile: 16 rows x 32 float4
+    const int g_r0 = tid >> 6, g_j4 = tid & 63;     // G tile: rows g_r0, g_r0 + 8
+    const int xk = slab * DW_SLAB + x_c4 * 4;       // concatenated K index of this thread's float4
+    float4 rx, rg0, rg1;
+    auto load_stage = [&](int st) {
+        const int row = r0 + st * GK;
+        const int rr = row + x_r;
+        rx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < M && xk < Kp)
+            rx = (xk < K1) ? *reinterpret_cast<const float4*>(X1 + (size_t)rr * ldx1 + xk)
+                           : *reinterpret_cast<const float4*>(X2 + (size_t)rr * ldx2 + (xk - K1));
+        const int ga = row + g_r0, gb = row + g_r0 + 8;
+        rg0 = ga < M ? *reinterpret_cast<const float4*>(G + (size_t)ga * MLP_W + g_j4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rg1 = gb < M ? *reinterpret_cast<const float4*>(G + (size_t)gb * MLP_W + g_j4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_stage = [&](int buf) {
+        *reinterpret_cast<float4*>(Xs[buf] + x_r * DW_SLAB + x_c4 * 4) = rx;
+        *reinterpret_cast<float4*>(Gs[buf] + g_r0 * MLP_W + g_j4 * 4) = rg0;
+        *reinterpret_cast<float4*>(Gs[buf] + (g_r0 + 8) * MLP_W + g_j4 * 4) = rg1;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float colsum = 0.f;  // bias gradient of column `tid` (slab 0, threads 0..255)
+    const bool do_db = (slab == 0) && (tid < MLP_W) && partial_db != nullptr;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    const int a_off = wm * 64 + (lane & 31), b_off = wn * 64 + (lane & 31), kh = lane >> 5;
+    for (int st = 0; st < nst; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_stage(st + 1);
+        const float* xs = Xs[buf];
+        const float* gs = Gs[buf];
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; kk++) {
+            const int k = 2 * kk + kh;  // row inside the stage = reduction index
+            const float a0 = xs[k * DW_SLAB + a_off], a1 = xs[k * DW_SLAB + a_off + 32];
+            const float b0 = gs[k * MLP_W + b_off], b1 = gs[k * MLP_W + b_off + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (do_db) {
+#pragma unroll
+            for (int r = 0; r < GK; r++) colsum += gs[r * MLP_W + tid];
+        }
+        if (st + 1 < nst) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = partial + (size_t)chunk * Kp * MLP_W;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int col = wn * 64 + nt * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k = slab * DW_SLAB + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (k < Kp) out[(size_t)k * MLP_W + col] = acc[mt][nt][r];
+            }
+        }
+    if (do_db) partial_db[(size_t)chunk * MLP_W + tid] = colsum;
+}
+
+// dW[j][dst(k)] = sum_chunks partial[c][k][j] (PyTorch (out, in) layout, padding rows dropped); db[j] likewise
+__global__ void mlp_reduce_dw_kernel(int chunks, int Kp, int in_features, int emb_dim, const float* __restrict__ partial,
+                                     const float* __restrict__ partial_db, float* __restrict__ dW, float* __restrict__ db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < Kp * MLP_W) {
+        const int k = idx / MLP_W, j = idx % MLP_W;
+        int dst;
+        if (Kp == MLP_W) dst = k;
+        else if (k < MLP_EMB) dst = k < emb_dim ? k : -1;
+        else dst = k - MLP_EMB + emb_dim;
+        if (dst >= 0) {
+            // sixteen independent partial sums keep sixteen loads in flight (a single dependent chain of
+            // `chunks` loads is latency bound); the order is still fixed
+            float sp[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) sp[u] = 0.f;
+            const float* src = partial + (size_t)k * MLP_W + j;
+            const size_t cs = (size_t)Kp * MLP_W;
+            int c = 0;
+            for (; c + 16 <= chunks; c += 16) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) sp[u] += src[(size_t)(c + u) * cs];
+            }
+            for (; c < chunks; c++) sp[0] += src[(size_t)c * cs];
+#pragma unroll
+            for (int u = 8; u >= 1; u >>= 1)
+#pragma unroll
+                for (int v = 0; v < u; v++) sp[v] += sp[v + u];
+            const float s = sp[0];
+            dW[(size_t)j * in_features + dst] = s;
+        }
+    }
+    if (idx < MLP_W && db != nullptr) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; c++) s += partial_db[(size_t)c * MLP_W + idx];
+        db[idx] = s;
+    }
+}
+
+// ---- small dense ops around the trunk ----------------------------------------------------------------------------------
+// out[r][c] (+)= sum_j A[r][j] * B(j, c) + bias[c],  j < 256, c < NC <= 16, B(j,c) = Bp[j*sj + c*sc].
+// Four lanes share a row (each covers 64 of the 256 inputs in 16-byte pieces), so a wave load instruction touches
+// 16 rows x 64 contiguous bytes.
+__global__ void __launch_bounds__(256)
+mlp_rows_small_kernel(int N, int NC, const float* __restrict__ A, const float* __restrict__ Bp, int sj, int sc,
+                      const float* __restrict__ bias, float* __restrict__ out, int ldo, int accumulate) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int r = gid >> 2, q = gid & 3;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) acc[c] = 0.f;
+    if (r < N) {
+        const float* a = A + (size_t)r * MLP_W;
+        for (int i = 0; i < 16; i++) {
+            const int j = (i * 4 + q) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(a + j);
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                if (c < NC) {
+                    const float* b = Bp + (size_t)j * sj + (size_t)c * sc;
+                    acc[c] += v.x * b[0] + v.y * b[sj] + v.z * b[2 * sj] + v.w * b[3 * sj];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        acc[c] += __shfl_xor(acc[c], 1, 64);
+        acc[c] += __shfl_xor(acc[c], 2, 64);
+    }
+    if (r < N && q == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            if (c < NC) {
+                float v = acc[c] + (bias ? bias[c] : 0.f);
+                if (accumulate) v += out[(size_t)r * ldo + c];
+                out[(size_t)r * ldo + c] = v;
+            }
+        }
+    }
+}
+
+// G7[r][c] = (sum_o dOut[r][o] * Wh[o][c]) * (Y7[r][c] > 0)
+__global__ void __launch_bounds__(256)
+mlp_heads_bwd_kernel(int N, int NC, const float* __restrict__ dOut, const float* __restrict__ Wh,
+                     const float* __restrict__ Y7, float* __restrict__ G7) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(gid >> 6), c4 = (int)(gid & 63);
+    if (r >= N) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+        if (o < NC) {
+            const float d = dOut[(size_t)r * NC + o];
+            const float4 w = *reinterpret_cast<const float4*>(Wh + (size_t)o * MLP_W + c4 * 4);
+            s.x += d * w.x;
+            s.y += d * w.y;
+            s.z += d * w.z;
+            s.w += d * w.w;
+        }
+    }
+    const float4 y = *reinterpret_cast<const float4*>(Y7 + (size_t)r * MLP_W + c4 * 4);
+    s.x = y.x > 0.f ? s.x : 0.f;
+    s.y = y.y > 0.f ? s.y : 0.f;
+    s.z = y.z > 0.f ? s.z : 0.f;
+    s.w = y.w > 0.f ? s.w : 0.f;
+    *reinterpret_cast<float4*>(G7 + (size_t)r * MLP_W + c4 * 4) = s;
+}
+
+// partial_Wh[chunk][o][c] = sum_rows dOut[r][o] * Y7[r][c] ; partial_bh[chunk][o] = sum_rows dOut[r][o]
+// (rows are consumed four at a time so that four Y7 loads are in flight per thread)
+__global__ void __launch_bounds__(256)
+mlp_heads_dw_kernel(int N, int NC, const float* __restrict__ dOut, const float* __restrict__ Y7,
+                    float* __restrict__ partial_W, float* __restrict__ partial_b) {
+    __shared__ float sd[64 * 16];
+    const int c = threadIdx.x, chunk = blockIdx.x;
+    const int r0 = chunk * HD_ROWS, r1 = min(N, r0 + HD_ROWS);
+    float acc[16], accb = 0.f;
+#pragma unroll
+    for (int o = 0; o < 16; o++) acc[o] = 0.f;
+    for (int rb = r0; rb < r1; rb += 64) {
+        const int nr = min(64, r1 - rb);
+        __syncthreads();
+        for (int i = c; i < 64 * 16; i += 256) {  // stage dOut rows (zero padded to 16 columns)
+            const int rr = i >> 4, o = i & 15;
+            sd[i] = (rr < nr && o < NC) ? dOut[(size_t)(rb + rr) * NC + o] : 0.f;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < nr; rr += 4) {
+            float y[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) y[u] = (rr + u < nr) ? Y7[(size_t)(rb + rr + u) * MLP_W + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float4* d4 = reinterpret_cast<const float4*>(sd + (rr + u) * 16);
+                const float4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
+                acc[0] += d0.x * y[u];
+                acc[1] += d0.y * y[u];
+                acc[2] += d0.z * y[u];
+                acc[3] += d0.w * y[u];
+                acc[4] += d1.x * y[u];
+                acc[5] += d1.y * y[u];
+                acc[6] += d1.z * y[u];
+                acc[7] += d1.w * y[u];
+                acc[8] += d2.x * y[u];
+                acc[9] += d2.y * y[u];
+                acc[10] += d2.z * y[u];
+                acc[11] += d2.w * y[u];
+                acc[12] += d3.x * y[u];
+                acc[13] += d3.y * y[u];
+                acc[14] += d3.z * y[u];
+                acc[15] += d3.w * y[u];
+            }
+        }
+        if (c < 16)
+            for (int rr = 0; rr < nr; rr++) accb += sd[rr * 16 + c];
+    }
+#pragma unroll
+    for (int o = 0; o < 16; o++)
+        if (o < NC) partial_W[((size_t)chunk * 16 + o) * MLP_W + c] = acc[o];
+    if (c < 16) partial_b[(size_t)chunk * 16 + c] = accb;
+}
+
+__global__ void mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W,
+                                        const float* __restrict__ partial_b, float* __restrict__ dWh,
+                                        float* __restrict__ dbh) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < NC * MLP_W) {
+        const int o = idx / MLP_W, c = idx % MLP_W;
+        float sp[16];  // sixteen loads in flight per thread; fixed summation order
+#pragma unroll
+        for (int u = 0; u < 16; u++) sp[u] = 0.f;
+        int k = 0;
+        for (; k + 16 <= chunks; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) sp[u] += partial_W[((size_t)(k + u) * 16 + o) * MLP_W + c];
+        }
+        for (; k < chunks; k++) sp[0] += partial_W[((size_t)k * 16 + o) * MLP_W + c];
+#pragma unroll
+        for (int u = 8; u >= 1; u >>= 1)
+#pragma unroll
+            for (int v = 0; v < u; v++) sp[v] += sp[v + u];
+        const float s = sp[0];
+        dWh[idx] = s;
+    }
+}
+
+// dbh[o] = sum_chunks partial_b[chunk][o]   (one workgroup: strided partial sums, then an LDS tree)
+__global__ void __launch_bounds__(256)
+mlp_reduce_bias16_kernel(int chunks, int NC, const float* __restrict__ partial_b, float* __restrict__ dbh) {
+    __shared__ float red[256][17];
+    float a[16];
+#pragma unroll
+    for (int o = 0; o < 16; o++) a[o] = 0.f;
+    for (int k = threadIdx.x; k < chunks; k += 256) {
+        const float4* p4 = reinterpret_cast<const float4*>(partial_b + (size_t)k * 16);
+        const float4 v0 = p4[0], v1 = p4[1], v2 = p4[2], v3 = p4[3];
+        a[0] += v0.x, a[1] += v0.y, a[2] += v0.z, a[3] += v0.w, a[4] += v1.x, a[5] += v1.y, a[6] += v1.z, a[7] += v1.w;
+        a[8] += v2.x, a[9] += v2.y, a[10] += v2.z, a[11] += v2.w, a[12] += v3.x, a[13] += v3.y, a[14] += v3.z, a[15] += v3.w;
+    }
+#pragma unroll
+    for (int o = 0; o < 16; o++) red[threadIdx.x][o] = a[o];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+#pragma unroll
+            for (int o = 0; o < 16; o++) red[threadIdx.x][o] += red[threadIdx.x + off][o];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < NC) dbh[threadIdx.x] = red[0][threadIdx.x];
+}
+
+// broadcast t: dtemb[c] = sum_j db0[j] W0[j][63+c] + db5[j] W5[j][63+c]   (one 256-thread block per column c)
+__global__ void __launch_bounds__(256)
+mlp_dtemb_bcast_kernel(int T, const float* __restrict__ db0, const float* __restrict__ W0, int in0,
+                       const float* __restrict__ db5, const float* __restrict__ W5, int in5, float* __restrict__ dtemb) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, j = threadIdx.x;
+    float v = db0[j] * W0[(size_t)j * in0 + MLP_XE + c] + db5[j] * W5[(size_t)j * in5 + MLP_XE + c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((j & 63) == 0) red[j >> 6] = v;
+    __syncthreads();
+    if (j == 0) dtemb[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace dgm
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+using namespace dgm;
+
+namespace dgm {
+void set_last_error(const char* msg);  // c_api.hip
+}
+namespace {
+int mlp_fail(const char* msg) {
+    dgm::set_last_error(msg);
+    return 1;
+}
+struct Ws {
+    float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb;
+    unsigned* mask[8];
+    size_t bytes;
+};
+Ws carve(char* base, int N) {
+    Ws w;
+    char* p = align_ptr(base);
+    auto take = [&](size_t b) {
+        char* at = p;
+        p = align_ptr(p + b);
+        return (float*)at;
+    };
+    const size_t n = (size_t)N;
+    const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
+    w.emb = take(n * MLP_EMB * 4);
+    for (int l = 0; l < 8; l++) w.Y[l] = take(n * MLP_W * 4);
+    for (int l = 0; l < 8; l++) w.mask[l] = (unsigned*)take(n * 8 * 4);
+    for (int l = 0; l < 8; l++) w.Wt[l] = take((size_t)(MLP_EMB + MLP_W) * MLP_W * 4);
+    for (int l = 0; l < 8; l++) w.Wd[l] = take((size_t)MLP_W * MLP_W * 4);
+    w.Ga = take(n * MLP_W * 4);
+    w.Gb = take(n * MLP_W * 4);
+    w.partial = take((size_t)chunks * (MLP_EMB + MLP_W) * MLP_W * 4);
+    w.partial_db = take((size_t)chunks * MLP_W * 4);
+    const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
+    w.partial_h = take((size_t)hchunks * 16 * MLP_W * 4);
+    w.partial_hb = take((size_t)hchunks * 16 * 4);
+    w.bytes = (size_t)(p - base) + 256;
+    return w;
+}
+int layer_in(const dgm_mlp_params* p, int l) {
+    if (l == 0) return p->emb_dim;
+    if (l == p->skip_layer) return p->emb_dim + MLP_W;
+    return MLP_W;
+}
+int layer_kp(const dgm_mlp_params* p, int l) {
+    if (l == 0) return MLP_EMB;
+    if (l == p->skip_layer) return MLP_EMB + MLP_W;
+    return MLP_W;
+}
+int check_params(const dgm_mlp_params* p) {
+    if (!p) return mlp_fail("mlp: params is NULL");
+    if (p->n_layers != 8 || p->width != MLP_W) return mlp_fail("mlp: only D=8, W=256 is supported (the reference's only configuration)");
+    if (p->emb_dim != MLP_XE + p->t_dim || p->emb_dim > MLP_EMB) return mlp_fail("mlp: emb_dim must be 63 + t_dim <= 96");
+    if (p->skip_layer != 5) return mlp_fail("mlp: skip re-injection must feed layer 5 (skips=[4])");
+    if (p->n_out < 1 || p->n_out > 16) return mlp_fail("mlp: 1..16 head outputs supported");
+    for (int l = 0; l < 8; l++)
+        if (!p->W[l] || !p->b[l]) return mlp_fail("mlp: NULL weight pointer");
+    if (!p->Wh || !p->bh) return mlp_fail("mlp: NULL head pointer");
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+size_t dgm_mlp_workspace_bytes(int N) {
+    Ws w = carve(nullptr, N > 0 ? N : 0);
+    return w.bytes;
+}
+
+int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float* temb, int temb_stride, char* workspace,
+                    float* out, void* stream) {
+    if (check_params(p)) return 1;
+    if (N <= 0) return 0;
+    if (!x || !temb || !workspace || !out) return mlp_fail("mlp_forward: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Ws w = carve(workspace, N);
+    for (int l = 0; l < 8; l++) {
+        const int Kp = layer_kp(p, l);
+        const int n = (Kp > MLP_W ? Kp : MLP_W) * MLP_W;
+        hipLaunchKernelGGL(mlp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, layer_in(p, l), Kp, p->emb_dim,
+                           l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
+    }
+    {
+        const size_t tot = (size_t)N * MLP_EMB;
+        hipLaunchKernelGGL(mlp_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, x, temb, temb_stride,
+                           p->t_dim, w.emb);
+    }
+    const int grid = (N + GM - 1) / GM;
+    for (int l = 0; l < 8; l++) {
+        const float *A1, *A2 = nullptr;
+        int lda1, K1, lda2 = 0, K2 = 0;
+        if (l == 0) {
+            A1 = w.emb, lda1 = MLP_EMB, K1 = MLP_EMB;
+        } else if (l == p->skip_layer) {
+            A1 = w.emb, lda1 = MLP_EMB, K1 = MLP_EMB, A2 = w.Y[l - 1], lda2 = MLP_W, K2 = MLP_W;
+        } else {
+            A1 = w.Y[l - 1], lda1 = MLP_W, K1 = MLP_W;
+        }
+        hipLaunchKernelGGL(mlp_gemm_kernel<0>, dim3(grid), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2, w.Wt[l], p->b[l],
+                           w.mask[l], w.Y[l]);
+    }
+    hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, p->n_out, w.Y[7], p->Wh, 1,
+                       MLP_W, p->bh, out, p->n_out, 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
+    return 0;
+}
+
+int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace, float* const* dW,
+                     float* const* db, float* dWh, float* dbh, float* dtemb, void* stream) {
+    if (check_params(p)) return 1;
+    if (N <= 0) return 0;
+    if (!dOut || !workspace || !dW || !db || !dWh || !dbh) return mlp_fail("mlp_backward: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Ws w = carve(workspace, N);
+    const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
+    const int grid = (N + GM - 1) / GM;
+    // heads
+    hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3((unsigned)(((size_t)N * 64 + 255) / 256)), dim3(256), 0, st, N, p->n_out,
+                       dOut, p->Wh, w.Y[7], w.Ga);
+    const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
+    hipLaunchKernelGGL(mlp_heads_dw_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, w.Y[7], w.partial_h,
+                       w.partial_hb);
+    hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3((p->n_out * MLP_W + 255) / 256), dim3(256), 0, st, hchunks, p->n_out,
+                       w.partial_h, w.partial_hb, dWh, dbh);
+    hipLaunchKernelGGL(mlp_reduce_bias16_kernel, dim3(1), dim3(256), 0, st, hchunks, p->n_out, w.partial_hb, dbh);
+    float* G = w.Ga;
+    float* Gn = w.Gb;
+    const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
+    for (int l = 7; l >= 0; l--) {
+        const float *X1, *X2 = nullptr;
+        int ldx1, K1, ldx2 = 0, K2 = 0;
+        if (l == 0) {
+            X1 = w.emb, ldx1 = MLP_EMB, K1 = MLP_EMB;
+        } else if (l == p->skip_layer) {
+            X1 = w.emb, ldx1 = MLP_EMB, K1 = MLP_EMB, X2 = w.Y[l - 1], ldx2 = MLP_W, K2 = MLP_W;
+        } else {
+            X1 = w.Y[l - 1], ldx1 = MLP_W, K1 = MLP_W;
+        }
+        const int Kp = K1 + K2;
+        const int slabs = (Kp + DW_SLAB - 1) / DW_SLAB;
+        hipLaunchKernelGGL(mlp_dw_kernel, dim3(slabs, chunks), dim3(512), 0, st, N, X1, ldx1, K1, X2, ldx2, K2, G, w.partial,
+                           w.partial_db);
+        hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, chunks, Kp, layer_in(p, l),
+                           p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
+        if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]
+            for (int c0 = 0; c0 < p->t_dim; c0 += 16)     // the small kernel handles 16 output columns per pass
+                hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N,
+                                   p->t_dim - c0 < 16 ? p->t_dim - c0 : 16, G, p->W[l] + MLP_XE + c0, layer_in(p, l), 1,
+                                   (const float*)nullptr, dtemb + c0, p->t_dim, l == 0 ? 1 : 0);
+        if (l >= 1) {
+            hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid), dim3(256), 0, st, N, G, MLP_W, MLP_W, (const float*)nullptr, 0,
+                               0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
+            float* t = G;
+            G = Gn;
+            Gn = t;
+        }
+    }
+    if (!per_row_t && dtemb != nullptr)
+        hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
+                           db[p->skip_layer], p->W[p->skip_layer], layer_in(p, p->skip_layer), dtemb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

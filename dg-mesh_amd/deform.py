@@ -90,15 +90,18 @@ class _TrunkNet(nn.Module):
             t_emb = self.timenet(t_emb)
         return t_emb
 
-    def trunk(self, x, t):
-        # t identical on every row (expanded view, R/train.py:158): evaluate the time branch on ONE row
+    def _time_rows(self, t):
+        """(t_emb, broadcast): t identical on every row (expanded view, R/train.py:158) -> evaluate the time branch
+        on ONE row and broadcast it."""
         if t.dim() == 2 and t.shape[0] > 1 and t.stride(0) == 0:
-            t_emb = self.time_embedding(t[:1]).expand(t.shape[0], -1)
-        else:
-            t_emb = self.time_embedding(t)
-        if self.trunk_impl == "hip":
-            from . import mlp_hip
-            return mlp_hip.trunk_forward(self, x, t_emb)
+            return self.time_embedding(t[:1]), True
+        return self.time_embedding(t), False
+
+    def trunk(self, x, t):
+        """PE(x) ++ t_emb -> 8 ReLU layers with the skip (time_utils.py:104-114), PyTorch ops."""
+        t_emb, bcast = self._time_rows(t)
+        if bcast:
+            t_emb = t_emb.expand(x.shape[0], -1)
         x_emb = positional_encoding(x, self.multires)
         h = torch.cat([x_emb, t_emb], dim=-1)
         for i, _ in enumerate(self.linear):
@@ -108,8 +111,18 @@ class _TrunkNet(nn.Module):
         return h
 
     def head_modules(self):
-        """Linear heads applied to the trunk output, in output-column order (used by the fused kernel)."""
+        """Linear heads applied to the trunk output, in output-column order."""
         raise NotImplementedError
+
+    def heads_out(self, x, t):
+        """Concatenated raw head outputs (N, sum of head widths)."""
+        heads = self.head_modules()
+        if self.trunk_impl == "hip":
+            from . import mlp_hip
+            t_emb, bcast = self._time_rows(t)
+            return mlp_hip.network_forward(self, heads, x, t_emb, bcast)
+        h = self.trunk(x, t)
+        return torch.cat([m(h) for m in heads], dim=-1)
 
 
 class DeformNetwork(_TrunkNet):
@@ -124,21 +137,23 @@ class DeformNetwork(_TrunkNet):
         self.gaussian_rotation = nn.Linear(W, 4)
         self.gaussian_scaling = nn.Linear(W, 3)
 
-    def _warp(self, h):
+    def head_modules(self):
+        warp = [self.branch_w, self.branch_v] if self.is_6dof else [self.gaussian_warp]
+        return warp + [self.gaussian_rotation, self.gaussian_scaling]
+
+    def _split(self, o):
         if self.is_6dof:
-            w = self.branch_w(h)
-            v = self.branch_v(h)
+            w, v, o = o[:, 0:3], o[:, 3:6], o[:, 6:]
             theta = torch.norm(w, dim=-1, keepdim=True)
             w = w / theta + 1e-5
             v = v / theta + 1e-5
-            return exp_se3(torch.cat([w, v], dim=-1), theta)
-        return self.gaussian_warp(h)
+            d_xyz = exp_se3(torch.cat([w, v], dim=-1), theta)
+        else:
+            d_xyz, o = o[:, 0:3], o[:, 3:]
+        return d_xyz, o[:, 0:4], o[:, 4:7], o[:, 7:]
 
     def forward(self, x, t):
-        h = self.trunk(x, t)
-        d_xyz = self._warp(h)
-        scaling = self.gaussian_scaling(h)
-        rotation = self.gaussian_rotation(h)
+        d_xyz, rotation, scaling, _ = self._split(self.heads_out(x, t))
         return d_xyz, rotation, scaling
 
 
@@ -148,12 +163,11 @@ class DeformNetworkNormal(DeformNetwork):
         super().__init__(D, W, input_ch, output_ch, multires, is_blender, is_6dof, trunk_impl)
         self.gaussian_normal = nn.Linear(W, 3)
 
+    def head_modules(self):
+        return super().head_modules() + [self.gaussian_normal]
+
     def forward(self, x, t):
-        h = self.trunk(x, t)
-        d_xyz = self._warp(h)
-        scaling = self.gaussian_scaling(h)
-        rotation = self.gaussian_rotation(h)
-        normal = self.gaussian_normal(h)
+        d_xyz, rotation, scaling, normal = self._split(self.heads_out(x, t))
         return d_xyz, rotation, scaling, normal
 
 
@@ -165,8 +179,11 @@ class DeformNetworkNormalSep(_TrunkNet):
         self.gaussian_normal.weight.data.zero_()
         self.gaussian_normal.bias.data.zero_()
 
+    def head_modules(self):
+        return [self.gaussian_normal]
+
     def forward(self, x, t):
-        return self.gaussian_normal(self.trunk(x, t))
+        return self.heads_out(x, t)
 
 
 class AppearanceNetwork(_TrunkNet):
@@ -174,8 +191,11 @@ class AppearanceNetwork(_TrunkNet):
         super().__init__(D, W, input_ch, output_ch, multires, is_blender, False, trunk_impl)
         self.color_warp = nn.Sequential(nn.Linear(W, 3), nn.Sigmoid())
 
+    def head_modules(self):
+        return [self.color_warp[0]]
+
     def forward(self, x, t):
-        return self.color_warp(self.trunk(x, t))
+        return self.color_warp[1](self.heads_out(x, t))
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):

@@ -153,6 +153,39 @@ const char* dgm_stage_name(int stage);
 /* points: (P,3) fp32 device; mean_dists: (P) fp32 device = mean of the 3 smallest squared distances. */
 int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, void* stream);
 
+/* ---- deformation / appearance MLP trunk ---------------------------------------------------------- */
+
+/* Weights in PyTorch nn.Linear layout (out_features, in_features), fp32, device pointers.
+ * Geometry is the reference's only one: D = 8 layers, W = 256, skips = [4] (layer 5 consumes
+ * [PE(x) | t_emb | h]), PE(x) = 63 columns, t_emb = t_dim columns (30 = timenet output for
+ * is_blender, 21 = PE(t) otherwise).  Heads are passed concatenated: Wh (n_out, 256), bh (n_out). */
+typedef struct {
+    int n_layers;   /* 8 */
+    int width;      /* 256 */
+    int emb_dim;    /* 63 + t_dim */
+    int t_dim;      /* 30 or 21 */
+    int skip_layer; /* 5 */
+    int n_out;      /* total head outputs, <= 16 */
+    const float* W[8];
+    const float* b[8];
+    const float* Wh;
+    const float* bh;
+} dgm_mlp_params;
+
+/* Bytes of the workspace that forward fills (embedding, the 8 post-ReLU activations, re-laid-out
+ * weights, scratch) and backward consumes; caller-owned, must stay alive between the two calls. */
+size_t dgm_mlp_workspace_bytes(int N);
+
+/* out (N, n_out) = heads(trunk(x (N,3), temb)).  temb: (N, t_dim) with row stride temb_stride floats,
+ * or ONE row broadcast to all N when temb_stride == 0 (t is identical for all rows in training). */
+int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float* temb, int temb_stride,
+                    char* workspace, float* out, void* stream);
+
+/* Given dOut (N, n_out): dW[l] / db[l] in the layout of W[l] / b[l], dWh, dbh, and dtemb
+ * ((t_dim) summed over rows when temb_stride == 0, else (N, t_dim)); dtemb may be NULL. */
+int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace,
+                     float* const* dW, float* const* db, float* dWh, float* dbh, float* dtemb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""Generates the committed golden fixtures.  Run HERE (the build container), where /root/reference exists:
+
+    python tests/golden/make_golden.py
+
+* mlp_*.npz  : outputs / gradients of the REFERENCE modules themselves (imported from
+               /root/reference/dgmesh/utils/time_utils.py) on seeded inputs, with their default initialisation under
+               torch.manual_seed(0).  tests/test_mlp.py rebuilds the same weights from the same seed with OUR
+               modules and must reproduce these numbers.
+* raster_small.npz : oracle outputs on a seeded scene (regression pin of oracle/dgr_oracle.c; the reference's CUDA
+               rasterizer cannot run in this container).
+Nothing under tests/ or bench.py reads /root/reference at run time.
+"""
+import hashlib
+import importlib
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def mlp_goldens():
+    sys.path.insert(0, "/root/reference/dgmesh")
+    from utils import time_utils as ref  # the reference itself
+
+    rng = np.random.RandomState(0)
+    N = 33
+    x = ((rng.rand(N, 3) * 2 - 1) * 1.3).astype(np.float32)
+    for cls in ("DeformNetwork", "DeformNetworkNormal", "DeformNetworkNormalSep", "AppearanceNetwork"):
+        for blender in (True, False):
+            torch.manual_seed(0)
+            net = getattr(ref, cls)(is_blender=blender)
+            if cls == "DeformNetworkNormalSep":  # zero-initialised head would make every gradient test vacuous
+                torch.manual_seed(1)
+                torch.nn.init.normal_(net.gaussian_normal.weight, std=0.05)
+            t = torch.tensor([[0.37]]).expand(N, -1)
+            out = net(torch.tensor(x), t)
+            outs = list(out) if isinstance(out, tuple) else [out]
+            g = torch.Generator().manual_seed(5)
+            loss = sum((o * torch.randn(o.shape, generator=g)).sum() for o in outs)
+            loss.backward()
+            rec = {f"out{i}": o.detach().numpy() for i, o in enumerate(outs)}
+            rec["x"] = x
+            rec["t"] = np.float32(0.37)
+            for name, p in net.named_parameters():
+                rec["psum/" + name] = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
+                if p.grad is not None:
+                    gr = p.grad.detach().numpy()
+                    rec["gnorm/" + name] = np.array([np.linalg.norm(gr.astype(np.float64))])
+                    rec["ghead/" + name] = gr.reshape(-1)[:24].copy()
+            np.savez_compressed(os.path.join(HERE, f"mlp_{cls}_{'blender' if blender else 'real'}.npz"), **rec)
+            print("wrote", cls, blender, [o.shape for o in outs])
+
+
+def raster_golden():
+    syn = importlib.import_module("dg-mesh_amd.synthetic")
+    from oracle import oracle as orc
+
+    P, W, H = 1500, 112, 80
+    g = syn.make_gaussians(P, seed=42, kind="aniso")
+    a = syn.activate(g)
+    cam = syn.make_camera(W, H, azimuth=0.9, elevation=0.3)
+    tanx, tany = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    bg = np.array([0.1, 0.5, 0.9], np.float32)
+    f = orc.forward(bg, a["means3D"], None, a["opacities"], a["scales"], a["rotations"], 1.0, None,
+                    cam.world_view_transform, cam.full_proj_transform, tanx, tany, H, W, a["shs"], 3, cam.camera_center)
+    dL = np.random.RandomState(7).randn(3, H, W).astype(np.float32)
+    gr = orc.backward(f, bg, a["means3D"], None, a["scales"], a["rotations"], 1.0, None, cam.world_view_transform,
+                      cam.full_proj_transform, tanx, tany, dL, a["shs"], 3, cam.camera_center)
+    h = lambda arr: np.frombuffer(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).digest()[:8], np.uint64)[0]
+    rec = dict(num_rendered=f["num_rendered"], radii=f["radii"], point_list_hash=h(f["binning"]["point_list"]),
+               ranges_hash=h(f["binning"]["ranges"]), n_contrib_hash=h(f["img"]["n_contrib"]),
+               color=f["color"][:, ::8, ::8].copy(), color_sum=np.float64(f["color"].astype(np.float64).sum()),
+               final_T_sum=np.float64(f["img"]["final_T"].astype(np.float64).sum()))
+    for k, v in gr.items():
+        rec["gnorm/" + k] = np.float64(np.linalg.norm(v.astype(np.float64)))
+        rec["ghead/" + k] = v.reshape(-1)[:32].copy()
+    np.savez_compressed(os.path.join(HERE, "raster_small.npz"), **rec)
+    print("wrote raster_small", f["num_rendered"])
+
+
+if __name__ == "__main__":
+    mlp_goldens()
+    raster_golden()

@@ -1,0 +1,11 @@
+"""Compact view of a rocprofv3 *_kernel_stats.csv: python tools/prof_summary.py <csv> [steps] [top]"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"# total kernel time {tot/1e6:.2f} ms = {tot/1e6/steps:.3f} ms/step over {steps} steps")
+print(f"# {'kernel':70s} {'calls':>6s} {'ms/step':>9s} {'avg_us':>9s} {'pct':>6s}")
+for r in rows[:top]:
+    n = r["Name"].replace("void ", "")
+    print(f"{n[:70]:70s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6/steps:9.3f} {float(r['AverageNs'])/1e3:9.1f} {float(r['Percentage']):6.2f}")
