@@ -52,6 +52,9 @@ SYMBOLS = {
     "dgm_collect_stage_ms": (_i, [_c.POINTER(_f), _c.POINTER(_i), _i]),
     "dgm_stage_name": (_c.c_char_p, [_i]),
     "dgm_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp]),
+    "dgm_image_loss_workspace_bytes": (_c.c_size_t, [_i, _i, _i]),
+    "dgm_image_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "dgm_image_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "dgm_mlp_workspace_bytes": (_c.c_size_t, [_i]),
     "dgm_mlp_forward": (_i, [_c.POINTER(MlpParams), _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_mlp_backward": (_i, [_c.POINTER(MlpParams), _i, _vp, _i, _vp, _vp * 8, _vp * 8, _vp, _vp, _vp, _vp]),

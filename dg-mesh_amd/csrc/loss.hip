@@ -1,0 +1,257 @@
+// Fused image loss for gfx950:  loss = (1 - lambda) * mean|I - G| + lambda * (1 - mean(SSIM(I, G)))
+//
+// Replaces, for the Gaussian-branch image loss of the train step (R/train.py:307-311), the PyTorch graph of
+// l1_loss + ssim (R/utils/loss_utils.py:18-19, 32-76): five grouped 11x11 Gaussian convolutions (window sigma 1.5,
+// zero padding 5) forward and their autograd backward -- 8 MIOpen convolutions of ~0.4 ms each on a 3x800x800
+// image -- by two HBM-bound kernels.
+//
+//   forward : one 16x16 pixel tile per workgroup per channel; the 26x26 haloed tiles of I and G go to LDS once, the
+//             five windowed moments (E[I], E[G], E[I^2], E[G^2], E[IG]) come from a separable pass through LDS, the
+//             SSIM map value and the three per-pixel partials (ds/dmu1_total, ds/dE11, ds/dE12) are formed in
+//             registers; partial sums per workgroup, summed in fixed order by a second tiny kernel (deterministic);
+//   backward: d sum(SSIM) / dI = conv(a1) + 2 I conv(a11) + G conv(a12)   (the Gaussian window is symmetric, so the
+//             adjoint of the zero-padded convolution is the same convolution) + the L1 sign term.
+// G (the ground-truth image) receives no gradient, as in the reference.
+#include "dgm_common.hpp"
+
+namespace dgm {
+
+static constexpr int LT = 16, LH = 5, LR = LT + 2 * LH;  // tile, halo, haloed tile edge (26)
+static constexpr int LP = LR + 1;                        // LDS row pitch
+
+__device__ __forceinline__ void gauss11(float* w) {  // R/utils/loss_utils.py:32-34
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        w[k] = expf(-(float)((k - 5) * (k - 5)) / (2.0f * 1.5f * 1.5f));
+        s += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] /= s;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256)
+loss_fwd_kernel(const float* __restrict__ I, const float* __restrict__ G, int H, int W, float* __restrict__ a1,
+                float* __restrict__ a11, float* __restrict__ a12, float* __restrict__ partial) {
+    __shared__ float sI[LR * LP], sG[LR * LP];
+    __shared__ float hq[5][LR * LT];
+    __shared__ float red[4];
+    float w[11];
+    gauss11(w);
+    const int ch = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    const float* Ic = I + ch * plane;
+    const float* Gc = G + ch * plane;
+    const int x0 = blockIdx.x * LT - LH, y0 = blockIdx.y * LT - LH;
+    for (int i = threadIdx.x; i < LR * LR; i += 256) {
+        const int y = i / LR, x = i - y * LR;
+        const int gy = y0 + y, gx = x0 + x;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        sI[y * LP + x] = in ? Ic[(size_t)gy * W + gx] : 0.f;
+        sG[y * LP + x] = in ? Gc[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LR * LT; i += 256) {  // horizontal pass
+        const int y = i / LT, x = i - y * LT;
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float a = sI[y * LP + x + k], b = sG[y * LP + x + k];
+            m1 += w[k] * a;
+            m2 += w[k] * b;
+            e11 += w[k] * (a * a);
+            e22 += w[k] * (b * b);
+            e12 += w[k] * (a * b);
+        }
+        hq[0][i] = m1;
+        hq[1][i] = m2;
+        hq[2][i] = e11;
+        hq[3][i] = e22;
+        hq[4][i] = e12;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float mu1 = 0.f, mu2 = 0.f, E11 = 0.f, E22 = 0.f, E12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const int o = (ty + k) * LT + tx;
+        mu1 += w[k] * hq[0][o];
+        mu2 += w[k] * hq[1][o];
+        E11 += w[k] * hq[2][o];
+        E22 += w[k] * hq[3][o];
+        E12 += w[k] * hq[4][o];
+    }
+    const int px = blockIdx.x * LT + tx, py = blockIdx.y * LT + ty;
+    float ssim = 0.f, l1 = 0.f;
+    if (px < W && py < H) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float s1 = E11 - mu1 * mu1, s2 = E22 - mu2 * mu2, s12 = E12 - mu1 * mu2;
+        const float A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2;
+        const float C = mu1 * mu1 + mu2 * mu2 + C1, D = s1 + s2 + C2;
+        const float iCD = 1.f / (C * D);
+        ssim = A * B * iCD;
+        // partials of the map value w.r.t. (E11, E12, mu1) with sigma1^2 = E11 - mu1^2, sigma12 = E12 - mu1 mu2
+        const float d11 = -ssim / D;
+        const float d12 = 2.f * A * iCD;
+        const float d1 = 2.f * mu2 * B * iCD - ssim * 2.f * mu1 / C + d11 * (-2.f * mu1) + d12 * (-mu2);
+        const size_t o = ch * plane + (size_t)py * W + px;
+        a1[o] = d1;
+        a11[o] = d11;
+        a12[o] = d12;
+        l1 = fabsf(sI[(ty + LH) * LP + tx + LH] - sG[(ty + LH) * LP + tx + LH]);
+    }
+    const float ssum = block_sum_256(ssim, red);
+    const float lsum = block_sum_256(l1, red);
+    if (threadIdx.x == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * b] = ssum;
+        partial[2 * b + 1] = lsum;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+loss_reduce_kernel(int nblocks, const float* __restrict__ partial, float inv_n, float lambda, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f, l = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        s += partial[2 * i];
+        l += partial[2 * i + 1];
+    }
+    const float S = block_sum_256(s, red);
+    const float Lsum = block_sum_256(l, red);
+    if (threadIdx.x == 0) {
+        out[0] = (1.f - lambda) * (Lsum * inv_n) + lambda * (1.f - S * inv_n);
+        out[1] = Lsum * inv_n;  // L1 term
+        out[2] = S * inv_n;     // mean SSIM
+    }
+}
+
+__global__ void __launch_bounds__(256)
+loss_bwd_kernel(const float* __restrict__ I, const float* __restrict__ G, const float* __restrict__ a1,
+                const float* __restrict__ a11, const float* __restrict__ a12, int H, int W, float inv_n, float lambda,
+                const float* __restrict__ gout, float* __restrict__ dI) {
+    __shared__ float sA[3][LR * LP];
+    __shared__ float hq[3][LR * LT];
+    float w[11];
+    gauss11(w);
+    const int ch = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    const int x0 = blockIdx.x * LT - LH, y0 = blockIdx.y * LT - LH;
+    for (int i = threadIdx.x; i < LR * LR; i += 256) {
+        const int y = i / LR, x = i - y * LR;
+        const int gy = y0 + y, gx = x0 + x;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o = ch * plane + (size_t)gy * W + gx;
+        sA[0][y * LP + x] = in ? a1[o] : 0.f;
+        sA[1][y * LP + x] = in ? a11[o] : 0.f;
+        sA[2][y * LP + x] = in ? a12[o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LR * LT; i += 256) {
+        const int y = i / LT, x = i - y * LT;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            c0 += w[k] * sA[0][y * LP + x + k];
+            c1 += w[k] * sA[1][y * LP + x + k];
+            c2 += w[k] * sA[2][y * LP + x + k];
+        }
+        hq[0][i] = c0;
+        hq[1][i] = c1;
+        hq[2][i] = c2;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int px = blockIdx.x * LT + tx, py = blockIdx.y * LT + ty;
+    if (px >= W || py >= H) return;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const int o = (ty + k) * LT + tx;
+        c0 += w[k] * hq[0][o];
+        c1 += w[k] * hq[1][o];
+        c2 += w[k] * hq[2][o];
+    }
+    const size_t o = ch * plane + (size_t)py * W + px;
+    const float iv = I[o], gv = G[o];
+    const float d = iv - gv;
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    const float dssim = c0 + 2.f * iv * c1 + gv * c2;
+    dI[o] = gout[0] * ((1.f - lambda) * inv_n * sgn - lambda * inv_n * dssim);
+}
+
+}  // namespace dgm
+
+using namespace dgm;
+namespace dgm {
+void set_last_error(const char* msg);
+}
+
+extern "C" {
+
+size_t dgm_image_loss_workspace_bytes(int channels, int H, int W) {
+    const size_t n = (size_t)channels * H * W;
+    const size_t nb = (size_t)channels * ((H + LT - 1) / LT) * ((W + LT - 1) / LT);
+    return align_up(n * 4, 256) * 3 + align_up(nb * 2 * 4, 256) + 512;
+}
+
+// image, gt: (channels, H, W) fp32.  out: 3 floats (loss, L1 term, mean SSIM).  workspace is kept for backward.
+int dgm_image_loss_forward(const float* image, const float* gt, int channels, int H, int W, float lambda_dssim,
+                           char* workspace, float* out, void* stream) {
+    if (!image || !gt || !workspace || !out || channels <= 0 || H <= 0 || W <= 0) {
+        set_last_error("image_loss_forward: bad argument");
+        return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)channels * H * W;
+    char* p = align_ptr(workspace);
+    float* a1 = (float*)p;
+    float* a11 = (float*)(p + align_up(n * 4, 256));
+    float* a12 = (float*)(p + 2 * align_up(n * 4, 256));
+    float* partial = (float*)(p + 3 * align_up(n * 4, 256));
+    dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, channels);
+    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, st, image, gt, H, W, a1, a11, a12, partial);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (int)(grid.x * grid.y * grid.z), partial,
+                       1.0f / (float)n, lambda_dssim, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error(hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+
+// grad_out: device scalar (dL/dloss).  d_image: (channels, H, W), fully written.
+int dgm_image_loss_backward(const float* image, const float* gt, int channels, int H, int W, float lambda_dssim,
+                            const char* workspace, const float* grad_out, float* d_image, void* stream) {
+    if (!image || !gt || !workspace || !grad_out || !d_image) {
+        set_last_error("image_loss_backward: NULL pointer");
+        return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)channels * H * W;
+    const char* p = align_ptr((char*)workspace);
+    const float* a1 = (const float*)p;
+    const float* a11 = (const float*)(p + align_up(n * 4, 256));
+    const float* a12 = (const float*)(p + 2 * align_up(n * 4, 256));
+    dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, channels);
+    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, st, image, gt, a1, a11, a12, H, W, 1.0f / (float)n, lambda_dssim,
+                       grad_out, d_image);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error(hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -60,7 +60,7 @@ def frame_schedule(n_frames, step, rank, world, seed=0):
 class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
-                 process_group=None):
+                 process_group=None, fused_loss=True):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
         self.cameras = cameras
         self.opt = opt or S.OptimizationParams()
@@ -70,6 +70,7 @@ class Trainer:
         self.rank, self.world, self.seed = rank, world, seed
         self.render_fn = render_fn or S.render
         self.group = process_group
+        self.fused_loss = fused_loss
         self.step_count = 0
         dev = gaussians.get_xyz.device
         fused = (dev.type == "cuda") if fused_adam is None else fused_adam
@@ -106,8 +107,12 @@ class Trainer:
             cycle = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rotation) + S.l1_loss(-back[2], d_scaling)) / 3.0
             losses["cycle_loss"] = cycle
         gt = cam.original_image
-        Ll1 = S.l1_loss(image, gt)
-        losses["img_loss"] = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - S.ssim(image, gt))
+        if image.is_cuda and self.fused_loss:  # same value, two HIP kernels instead of 5 convs + autograd
+            from .loss import image_loss
+            losses["img_loss"] = image_loss(image, gt, opt.lambda_dssim)
+        else:
+            Ll1 = S.l1_loss(image, gt)
+            losses["img_loss"] = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - S.ssim(image, gt))
         return losses, pkg
 
     def step(self, iteration):

@@ -186,6 +186,19 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
 int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace,
                      float* const* dW, float* const* db, float* dWh, float* dbh, float* dtemb, void* stream);
 
+/* ---- fused image loss -------------------------------------------------------------------------------- */
+
+/* loss = (1 - lambda) * mean|image - gt| + lambda * (1 - mean SSIM(image, gt)), the Gaussian-branch image loss of
+ * dgmesh/train.py:307-311 (l1_loss + ssim of dgmesh/utils/loss_utils.py:18-19, 32-76; 11x11 window, sigma 1.5,
+ * zero padding).  image, gt: (channels, H, W) fp32 device; out: 3 floats {loss, L1 term, mean SSIM};
+ * the workspace filled by forward is consumed by backward.  gt receives no gradient. */
+size_t dgm_image_loss_workspace_bytes(int channels, int H, int W);
+int dgm_image_loss_forward(const float* image, const float* gt, int channels, int H, int W, float lambda_dssim,
+                           char* workspace, float* out, void* stream);
+/* grad_out: device scalar dL/dloss; d_image (channels, H, W) is fully written. */
+int dgm_image_loss_backward(const float* image, const float* gt, int channels, int H, int W, float lambda_dssim,
+                            const char* workspace, const float* grad_out, float* d_image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
