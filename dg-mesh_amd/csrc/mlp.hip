@@ -21,6 +21,8 @@
 //    gradients ride along as column sums of the same G tiles;
 //  * t is the same for every row in training, so dL/dt_emb = db . W[:, t-columns] (no per-row GEMM); the general
 //    per-row case has its own small kernel.
+#include <stdlib.h>
+
 #include "dgm_common.hpp"
 
 namespace dgm {
@@ -82,35 +84,35 @@ __global__ void mlp_embed_kernel(int N, const float* __restrict__ x, const float
 // EPI 0: C = relu(acc + bias), and the ReLU mask is saved as bits: mask[row][col / 32] bit (col % 32)
 // EPI 1: C = acc where the saved mask bit of the layer below is set, else 0  (backward data: the product is
 //        directly the gradient w.r.t. the pre-activation of the layer below)
-// 64 x 256 output tile per 256-thread workgroup (4 waves side by side, each 64 x 64 = 2 x 2 MFMA tiles): small
-// tiles keep the 100k-row problem balanced over 256 CUs (1563 tiles), 4 workgroups fit a CU.
-template <int EPI>
+// 64 x 128 output tile per 256-thread workgroup (blockIdx.y = column half; 4 waves side by side, each 64 x 32 =
+// two MFMA tiles, 32 accumulator VGPRs).  Small tiles keep the 100k-row problem balanced over 256 CUs (3126 tiles)
+// and the low register count lets 5 workgroups share a CU, which is what hides the global->LDS staging latency.
+static constexpr int GN = 128;
+template <int EPI, int ABL = 0>  // ABL: ablation switch for profiling only (1: no refills, 2: no MFMA)
 __global__ void __launch_bounds__(256)
 mlp_gemm_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2, int K2,
                 const float* __restrict__ Bt, const float* __restrict__ bias, unsigned* __restrict__ mask,
                 float* __restrict__ C) {
     __shared__ float As[2][GK * GAP];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK * MLP_W];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * GN];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const int m0 = blockIdx.x * GM;
+    const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
     const int nk = (K1 + K2) / GK;
     const int a_row = tid >> 2, a_c4 = tid & 3;  // A tile: 64 rows x 4 float4
-    const int b_k0 = tid >> 6, b_j4 = tid & 63;  // B tile: rows b_k0 + {0,4,8,12}, 64 float4 per row
+    const int b_k0 = tid >> 5, b_j4 = tid & 31;  // B tile: rows b_k0 and b_k0 + 8, 32 float4 per row
     const bool a_ok = (m0 + a_row) < M;
     // register staging of the next K stage (plain scalars + macros: an array or a by-reference lambda capture here
     // is demoted to scratch memory by the compiler)
-    float4 ra, rb0, rb1, rb2, rb3;
+    float4 ra, rb0, rb1;
 #define MLP_LOAD_STAGE(kt_)                                                                                          \
     {                                                                                                                \
         const int k_ = (kt_) * GK;                                                                                   \
         const float* src_ = (k_ < K1) ? (A1 + (size_t)(m0 + a_row) * lda1 + k_)                                      \
                                       : (A2 + (size_t)(m0 + a_row) * lda2 + (k_ - K1));                              \
         ra = a_ok ? *reinterpret_cast<const float4*>(src_ + a_c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);             \
-        const float* bsrc_ = Bt + (size_t)(k_ + b_k0) * MLP_W + b_j4 * 4;                                            \
+        const float* bsrc_ = Bt + (size_t)(k_ + b_k0) * MLP_W + n0 + b_j4 * 4;                                       \
         rb0 = *reinterpret_cast<const float4*>(bsrc_);                                                               \
-        rb1 = *reinterpret_cast<const float4*>(bsrc_ + 4 * MLP_W);                                                   \
-        rb2 = *reinterpret_cast<const float4*>(bsrc_ + 8 * MLP_W);                                                   \
-        rb3 = *reinterpret_cast<const float4*>(bsrc_ + 12 * MLP_W);                                                  \
+        rb1 = *reinterpret_cast<const float4*>(bsrc_ + 8 * MLP_W);                                                   \
     }
 #define MLP_STORE_STAGE(buf_)                                                                                        \
     {                                                                                                                \
@@ -119,65 +121,59 @@ mlp_gemm_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const flo
         a_[GAP] = ra.y;                                                                                              \
         a_[2 * GAP] = ra.z;                                                                                          \
         a_[3 * GAP] = ra.w;                                                                                          \
-        float* b_ = Bs[buf_] + b_k0 * MLP_W + b_j4 * 4;                                                              \
+        float* b_ = Bs[buf_] + b_k0 * GN + b_j4 * 4;                                                                 \
         *reinterpret_cast<float4*>(b_) = rb0;                                                                        \
-        *reinterpret_cast<float4*>(b_ + 4 * MLP_W) = rb1;                                                            \
-        *reinterpret_cast<float4*>(b_ + 8 * MLP_W) = rb2;                                                            \
-        *reinterpret_cast<float4*>(b_ + 12 * MLP_W) = rb3;                                                           \
+        *reinterpret_cast<float4*>(b_ + 8 * GN) = rb1;                                                               \
     }
-    f32x16 acc[2][2];
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; r++) acc0[r] = 0.f, acc1[r] = 0.f;
 
     MLP_LOAD_STAGE(0)
     MLP_STORE_STAGE(0)
     __syncthreads();
-    const int a_off = lane & 31, b_off = wn * 64 + (lane & 31), kh = lane >> 5;
+    const int a_off = lane & 31, b_off = wn * 32 + (lane & 31), kh = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) MLP_LOAD_STAGE(kt + 1)
+        if (ABL != 1 && kt + 1 < nk) MLP_LOAD_STAGE(kt + 1)
         const float* as = As[buf];
         const float* bs = Bs[buf];
 #pragma unroll
         for (int kk = 0; kk < GK / 2; kk++) {
             const int k = 2 * kk + kh;
             const float a0 = as[k * GAP + a_off], a1 = as[k * GAP + a_off + 32];
-            const float b0 = bs[k * MLP_W + b_off], b1 = bs[k * MLP_W + b_off + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const float b0 = bs[k * GN + b_off];
+            if (ABL != 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
+            } else {
+                asm volatile("" ::"v"(a0), "v"(a1), "v"(b0));
+            }
         }
-        if (kt + 1 < nk) MLP_STORE_STAGE(buf ^ 1)
+        if (ABL != 1 && kt + 1 < nk) MLP_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
     // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
+    const int col = n0 + wn * 32 + (lane & 31);
+    const int mword = (n0 >> 5) + wn;  // 32-column group of this wave
+    const float bv = (EPI == 0) ? bias[col] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int mt = 0; mt < 2; mt++) {
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            const int col = wn * 64 + nt * 32 + (lane & 31);
-            const int mword = wn * 2 + nt;  // 32-column group of this tile
-            const float bv = (EPI == 0) ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float v = acc[mt][nt][r];
-                if (EPI == 0) {
-                    v = fmaxf(v + bv, 0.f);
-                    const unsigned long long bal = __ballot(v > 0.f);  // low half: row, high half: row + 4
-                    if ((lane & 31) == 0 && row < M) mask[(size_t)row * 8 + mword] = (unsigned)(bal >> (kh * 32));
-                } else {
-                    const unsigned bits = row < M ? mask[(size_t)row * 8 + mword] : 0u;
-                    v = ((bits >> (lane & 31)) & 1u) ? v : 0.f;
-                }
-                if (row < M) C[(size_t)row * MLP_W + col] = v;
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = mt == 0 ? acc0[r] : acc1[r];
+            if (EPI == 0) {
+                v = fmaxf(v + bv, 0.f);
+                const unsigned long long bal = __ballot(v > 0.f);  // low half: row, high half: row + 4
+                if ((lane & 31) == 0 && row < M) mask[(size_t)row * 8 + mword] = (unsigned)(bal >> (kh * 32));
+            } else {
+                const unsigned bits = row < M ? mask[(size_t)row * 8 + mword] : 0u;
+                v = ((bits >> (lane & 31)) & 1u) ? v : 0.f;
             }
+            if (row < M) C[(size_t)row * MLP_W + col] = v;
         }
+    }
 }
 
 #undef MLP_LOAD_STAGE
@@ -596,8 +592,16 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         } else {
             A1 = w.Y[l - 1], lda1 = MLP_W, K1 = MLP_W;
         }
-        hipLaunchKernelGGL(mlp_gemm_kernel<0>, dim3(grid), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2, w.Wt[l], p->b[l],
-                           w.mask[l], w.Y[l]);
+        static const int abl = getenv("DGM_MLP_ABL") ? atoi(getenv("DGM_MLP_ABL")) : 0;  // profiling aid
+        if (abl == 1)
+            hipLaunchKernelGGL((mlp_gemm_kernel<0, 1>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
+                               w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
+        else if (abl == 2)
+            hipLaunchKernelGGL((mlp_gemm_kernel<0, 2>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
+                               w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
+        else
+            hipLaunchKernelGGL((mlp_gemm_kernel<0, 0>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
+                               w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
     }
     hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, p->n_out, w.Y[7], p->Wh, 1,
                        MLP_W, p->bh, out, p->n_out, 0);
@@ -649,7 +653,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                                    p->t_dim - c0 < 16 ? p->t_dim - c0 : 16, G, p->W[l] + MLP_XE + c0, layer_in(p, l), 1,
                                    (const float*)nullptr, dtemb + c0, p->t_dim, l == 0 ? 1 : 0);
         if (l >= 1) {
-            hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid), dim3(256), 0, st, N, G, MLP_W, MLP_W, (const float*)nullptr, 0,
+            hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W, (const float*)nullptr, 0,
                                0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
             float* t = G;
             G = Gn;

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Builds the REFERENCE's own rasterizer (and simple-knn) kernels for gfx950 as a GPU-side checker:
+#   /root/reference/dgmesh/submodules/{diff-gaussian-rasterization/cuda_rasterizer,simple-knn}/*  (read where they lie)
+#   --hipify-perl + 5 mechanical text fixes, in a temporary directory-->  hipcc --offload-arch=gfx950
+#   --> oracle/_ref/libref_raster.so       (-ffp-contract=off: the canonical arithmetic of DESIGN.md section 3)
+#       oracle/_ref/libref_raster_fma.so   (hipcc default contraction: what a plain port of the reference would do)
+# Only the binaries are kept (oracle/_ref/ is git-ignored but travels to the GPU box); no reference source is
+# copied into the repository.  Skips silently when /root/reference is absent (e.g. on the GPU box).
+set -e
+REF=/root/reference/dgmesh/submodules
+HERE="$(cd "$(dirname "$0")" && pwd)"
+[ -d "$REF/diff-gaussian-rasterization/cuda_rasterizer" ] || { echo "build_ref: /root/reference not present, skipping"; exit 0; }
+TMP="$(mktemp -d /tmp/dgm_refbuild.XXXXXX)"
+trap 'rm -rf "$TMP"' EXIT
+DGR="$REF/diff-gaussian-rasterization"
+for f in forward.cu backward.cu rasterizer_impl.cu auxiliary.h forward.h backward.h rasterizer.h rasterizer_impl.h config.h; do
+  /opt/rocm/bin/hipify-perl "$DGR/cuda_rasterizer/$f" > "$TMP/$f" 2>/dev/null
+done
+for f in simple_knn.cu simple_knn.h; do /opt/rocm/bin/hipify-perl "$REF/simple-knn/$f" > "$TMP/$f" 2>/dev/null; done
+cd "$TMP"
+# mechanical fixes: empty include left by hipify, CUDA-only headers, __trap, spaced launch chevrons
+sed -i -e '/#include ""/d' -e '/cooperative_groups\/reduce.h/d' -e '/cub\/device\/device_radix_sort.cuh/d' \
+       -e '/device_launch_parameters.h/d' -e 's/__trap()/abort()/' -e 's/<< </<<</g' -e 's/>> >/>>>/g' \
+       -e 's/#define __CUDACC__//' *.cu *.h
+mkdir -p "$HERE/_ref"
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -include cfloat -I$TMP -I$DGR/third_party/glm -DGLM_FORCE_QUIET"
+KNN=""
+if /opt/rocm/bin/hipcc $COMMON -c simple_knn.cu -o knn_probe.o 2>knn.err; then KNN="-DREF_WITH_KNN simple_knn.cu"; else echo "build_ref: simple-knn does not build here (see below), rasterizer only"; head -5 knn.err; fi
+/opt/rocm/bin/hipcc $COMMON -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $KNN forward.cu backward.cu rasterizer_impl.cu "$HERE/ref_shim.cpp" -o "$HERE/_ref/libref_raster.so"
+/opt/rocm/bin/hipcc $COMMON forward.cu backward.cu rasterizer_impl.cu "$HERE/ref_shim.cpp" -o "$HERE/_ref/libref_raster_fma.so"
+echo "build_ref: wrote $(ls "$HERE/_ref")"
