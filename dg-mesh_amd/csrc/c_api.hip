@@ -3,6 +3,7 @@
 // with the reference's error points (DGR/rasterize_points.cu:57-59, rasterizer_impl.cu:242-245), optional
 // hipEvent stage timing.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -43,6 +44,9 @@ void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const uns
 void launch_render_bwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* bg, const float* rec, const float* final_T, const unsigned* n_contrib,
                        const float* dL_dpix, float* slab, unsigned* nproc);
+void launch_render_bwd2(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
+                        int gridx, const float* bg, const float* rec, const float* final_T, const unsigned* n_contrib,
+                        const float* dL_dpix, float* slab, unsigned* nproc);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
@@ -402,8 +406,13 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
 
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
-    launch_render_bwd(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib, dL_dpix,
-                      slab, nproc);
+    static const bool bwd_v1 = getenv("DGM_RENDER_BWD_V1") != nullptr;  // A/B aid: first-generation kernel
+    if (bwd_v1)
+        launch_render_bwd(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib,
+                          dL_dpix, slab, nproc);
+    else
+        launch_render_bwd2(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib,
+                           dL_dpix, slab, nproc);
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);
 

@@ -25,39 +25,9 @@
 #include <stdlib.h>
 
 #include "dgm_common.hpp"
+#include "render_common.hpp"
 
 namespace dgm {
-
-// Make a wave-uniform 64-bit value provably uniform (SGPR pair) for the scalar bit loops.  NB: the builtin
-// returns a signed int -- widen through `unsigned`, or the low half is sign-extended into the high half.
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (unsigned long long)lo | ((unsigned long long)hi << 32);
-}
-
-// Which of the tile's four 8x8 quadrants can receive alpha >= 1/255 from this splat?
-// alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o);  the ellipse {q <= tau} has the
-// axis-aligned half extents sqrt(tau * Sxx), sqrt(tau * Syy) with S = conic^-1.  Inflated by 0.1 % + 0.01 px
-// and written as "not provably outside" so that rounding or NaN can only keep a splat, never drop one.
-__device__ __forceinline__ unsigned quadrant_mask(float x, float y, float a, float b, float c, float o, float tx0,
-                                                  float ty0) {
-    const float o255 = o * 255.0f;
-    if (o255 < 1.0f) return 0u;  // alpha = min(.99, o*G) <= o < 1/255 for every pixel (G <= 1 where power <= 0)
-    const float tau = 2.0f * __logf(o255) * 1.001f + 0.01f;
-    const float det = a * c - b * b;
-    const float inv = 1.0f / det;
-    const float ex = sqrtf(tau * c * inv) * 1.001f + 0.01f;
-    const float ey = sqrtf(tau * a * inv) * 1.001f + 0.01f;
-    unsigned m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
-        const bool outside = (x + ex < qx0) || (x - ex > qx0 + 7.0f) || (y + ey < qy0) || (y - ey > qy0 + 7.0f);
-        if (!outside) m |= 1u << q;
-    }
-    return m;
-}
 
 template <bool CULL, int MODE = 0>
 __global__ void __launch_bounds__(256)
@@ -146,34 +116,6 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         out_color[plane + pid] = C1 + T * bg[1];
         out_color[2 * plane + pid] = C2 + T * bg[2];
     }
-}
-
-// In-place wave64 inclusive-scan-style reduction of nine values with DPP adds: after the block lane 63 of
-// every register holds the wave total.  Nine independent chains are interleaved, so the >= 2 wait states a
-// DPP read needs after a VALU write of the same VGPR are always covered by the eight other instructions.
-__device__ __forceinline__ void wave_reduce9(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
-                                             float& v6, float& v7, float& v8) {
-#define DGM_DPP_STEP(ctrl)                    \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"  \
-    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"  \
-    "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"  \
-    "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"  \
-    "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"  \
-    "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"  \
-    "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"  \
-    "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"  \
-    "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"
-    asm volatile(
-        "s_nop 1\n\t"
-        DGM_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        DGM_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-        "s_nop 1"
-        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
-#undef DGM_DPP_STEP
 }
 
 __global__ void __launch_bounds__(256)
