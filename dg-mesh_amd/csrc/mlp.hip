@@ -24,10 +24,9 @@
 #include <stdlib.h>
 
 #include "dgm_common.hpp"
+#include "mlp_bf16x6.hpp"
 
 namespace dgm {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int MLP_W = 256;     // trunk width (the reference hard-codes W=256)
 static constexpr int MLP_EMB = 96;    // padded width of [PE(x) | t_emb]: 63 + 30 (blender) or 63 + 21, zero padded
@@ -263,8 +262,9 @@ mlp_dw_kernel(int M, const float* __restrict__ X1, int ldx1, int K1, const float
 }
 
 // dW[j][dst(k)] = sum_chunks partial[c][k][j] (PyTorch (out, in) layout, padding rows dropped); db[j] likewise
-__global__ void mlp_reduce_dw_kernel(int chunks, int Kp, int in_features, int emb_dim, const float* __restrict__ partial,
-                                     const float* __restrict__ partial_db, float* __restrict__ dW, float* __restrict__ db) {
+__global__ void mlp_reduce_dw_kernel(int chunks, int db_chunks, int Kp, int in_features, int emb_dim,
+                                     const float* __restrict__ partial, const float* __restrict__ partial_db,
+                                     float* __restrict__ dW, float* __restrict__ db) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < Kp * MLP_W) {
         const int k = idx / MLP_W, j = idx % MLP_W;
@@ -295,9 +295,16 @@ __global__ void mlp_reduce_dw_kernel(int chunks, int Kp, int in_features, int em
         }
     }
     if (idx < MLP_W && db != nullptr) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; c++) s += partial_db[(size_t)c * MLP_W + idx];
-        db[idx] = s;
+        float sp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sp[u] = 0.f;
+        int c = 0;
+        for (; c + 8 <= db_chunks; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) sp[u] += partial_db[(size_t)(c + u) * MLP_W + idx];
+        }
+        for (; c < db_chunks; c++) sp[0] += partial_db[(size_t)c * MLP_W + idx];
+        db[idx] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
     }
 }
 
@@ -504,10 +511,34 @@ int mlp_fail(const char* msg) {
     return 1;
 }
 struct Ws {
-    float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb;
+    float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb, *part2;
+    uint4 *Wt6[8], *Wd6[8], *Wh6f, *Wh6b;  // bf16x6 weight planes
     unsigned* mask[8];
     size_t bytes;
 };
+// bf16x6 dW decomposition: about 512 workgroups (two per CU) whatever the layer's K
+struct DwPlan {
+    int rows, chunks, slabs;
+};
+DwPlan dw6_plan(int N, int Kp) {
+    DwPlan d;
+    d.slabs = (Kp + DW6_SLAB - 1) / DW6_SLAB;
+    const int target = 512 / d.slabs;
+    int rows = (N + target - 1) / target;
+    rows = (rows + 15) & ~15;
+    if (rows < 16) rows = 16;
+    d.rows = rows;
+    d.chunks = (N + rows - 1) / rows;
+    return d;
+}
+constexpr int DW_GROUPS = 8;  // first-level groups of the two-level dW partial reduction
+// 0: bf16x6 (fp32 operands split exactly into 3 bf16, 6 partial products on the bf16 matrix cores; default)
+// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f32|bf16x6.
+int g_gemm_mode = [] {
+    const char* e = getenv("DGM_MLP_GEMM");
+    return (e != nullptr && e[0] == 'f') ? 1 : 0;
+}();
+bool use_f32_mfma() { return g_gemm_mode == 1; }
 Ws carve(char* base, int N) {
     Ws w;
     char* p = align_ptr(base);
@@ -525,8 +556,19 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.Wd[l] = take((size_t)MLP_W * MLP_W * 4);
     w.Ga = take(n * MLP_W * 4);
     w.Gb = take(n * MLP_W * 4);
-    w.partial = take((size_t)chunks * (MLP_EMB + MLP_W) * MLP_W * 4);
-    w.partial_db = take((size_t)chunks * MLP_W * 4);
+    size_t pfl = (size_t)chunks * (MLP_EMB + MLP_W), pdb = (size_t)chunks;
+    for (int Kp : {MLP_EMB, MLP_W, MLP_EMB + MLP_W}) {
+        const DwPlan d = dw6_plan(N > 0 ? N : 1, Kp);
+        if ((size_t)d.chunks * Kp > pfl) pfl = (size_t)d.chunks * Kp;
+        if ((size_t)d.chunks * 2 > pdb) pdb = (size_t)d.chunks * 2;
+    }
+    w.partial = take(pfl * MLP_W * 4);
+    w.partial_db = take(pdb * MLP_W * 4);
+    w.part2 = take((size_t)DW_GROUPS * (MLP_EMB + MLP_W) * MLP_W * 4);
+    for (int l = 0; l < 8; l++) w.Wt6[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 6);
+    for (int l = 0; l < 8; l++) w.Wd6[l] = (uint4*)take((size_t)MLP_W * MLP_W * 6);
+    w.Wh6f = (uint4*)take((size_t)MLP_W * 32 * 6);
+    w.Wh6b = (uint4*)take((size_t)16 * MLP_W * 6);
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     w.partial_h = take((size_t)hchunks * 16 * MLP_W * 4);
     w.partial_hb = take((size_t)hchunks * 16 * 4);
@@ -558,6 +600,12 @@ int check_params(const dgm_mlp_params* p) {
 
 extern "C" {
 
+int dgm_mlp_set_gemm(int mode) {
+    const int prev = g_gemm_mode;
+    if (mode == 0 || mode == 1) g_gemm_mode = mode;
+    return prev;
+}
+
 size_t dgm_mlp_workspace_bytes(int N) {
     Ws w = carve(nullptr, N > 0 ? N : 0);
     return w.bytes;
@@ -570,11 +618,27 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     if (!x || !temb || !workspace || !out) return mlp_fail("mlp_forward: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
+    const bool f32 = use_f32_mfma();
     for (int l = 0; l < 8; l++) {
         const int Kp = layer_kp(p, l);
-        const int n = (Kp > MLP_W ? Kp : MLP_W) * MLP_W;
-        hipLaunchKernelGGL(mlp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, layer_in(p, l), Kp, p->emb_dim,
-                           l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
+        if (f32) {
+            const int n = (Kp > MLP_W ? Kp : MLP_W) * MLP_W;
+            hipLaunchKernelGGL(mlp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, layer_in(p, l), Kp, p->emb_dim,
+                               l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
+        } else {
+            hipLaunchKernelGGL(mlp_prep6_kernel, dim3((Kp / 8 * MLP_W + 255) / 256), dim3(256), 0, st, 0, Kp, MLP_W,
+                               layer_in(p, l), p->emb_dim, 0, 0, MLP_W, p->W[l], w.Wt6[l]);
+            if (l >= 1)
+                hipLaunchKernelGGL(mlp_prep6_kernel, dim3((MLP_W / 8 * MLP_W + 255) / 256), dim3(256), 0, st, 1, MLP_W, MLP_W,
+                                   layer_in(p, l), p->emb_dim, l == p->skip_layer ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l],
+                                   w.Wd6[l]);
+        }
+    }
+    if (!f32) {
+        hipLaunchKernelGGL(mlp_prep6_kernel, dim3((MLP_W / 8 * 32 + 255) / 256), dim3(256), 0, st, 0, MLP_W, 32, MLP_W, 0, 0,
+                           0, p->n_out, p->Wh, w.Wh6f);
+        hipLaunchKernelGGL(mlp_prep6_kernel, dim3((16 / 8 * MLP_W + 255) / 256), dim3(256), 0, st, 1, 16, MLP_W, MLP_W, 0, 0,
+                           p->n_out, MLP_W, p->Wh, w.Wh6b);
     }
     {
         const size_t tot = (size_t)N * MLP_EMB;
@@ -582,6 +646,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
                            p->t_dim, w.emb);
     }
     const int grid = (N + GM - 1) / GM;
+    const int grid6 = (N + 127) / 128;
     for (int l = 0; l < 8; l++) {
         const float *A1, *A2 = nullptr;
         int lda1, K1, lda2 = 0, K2 = 0;
@@ -593,6 +658,18 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             A1 = w.Y[l - 1], lda1 = MLP_W, K1 = MLP_W;
         }
         static const int abl = getenv("DGM_MLP_ABL") ? atoi(getenv("DGM_MLP_ABL")) : 0;  // profiling aid
+        if (!f32) {
+#define G6_FWD(ABL_)                                                                                                         \
+    hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false, ABL_>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, \
+                       K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W)
+            if (abl == 1) G6_FWD(1);
+            else if (abl == 2) G6_FWD(2);
+            else if (abl == 3) G6_FWD(3);
+            else if (abl == 4) G6_FWD(4);
+            else G6_FWD(0);
+#undef G6_FWD
+            continue;
+        }
         if (abl == 1)
             hipLaunchKernelGGL((mlp_gemm_kernel<0, 1>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
                                w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
@@ -603,8 +680,12 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             hipLaunchKernelGGL((mlp_gemm_kernel<0, 0>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
                                w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
     }
-    hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, p->n_out, w.Y[7], p->Wh, 1,
-                       MLP_W, p->bh, out, p->n_out, 0);
+    if (f32)
+        hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, p->n_out, w.Y[7], p->Wh, 1,
+                           MLP_W, p->bh, out, p->n_out, 0);
+    else  // heads: out = Y7 * Wh^T + bh as a 32-column GEMM (HBM-bound: one pass over Y7)
+        hipLaunchKernelGGL((mlp_gemm6_kernel<2, 4, 1, 1, 1, false>), dim3(grid6), dim3(256), 0, st, N, w.Y[7], MLP_W, MLP_W,
+                           (const float*)nullptr, 0, 0, 0, w.Wh6f, p->bh, (unsigned*)nullptr, out, p->n_out, p->n_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
     return 0;
@@ -619,9 +700,15 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     Ws w = carve(workspace, N);
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
     const int grid = (N + GM - 1) / GM;
+    const bool f32 = use_f32_mfma();
+    const int grid6 = (N + 127) / 128;
     // heads
-    hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3((unsigned)(((size_t)N * 64 + 255) / 256)), dim3(256), 0, st, N, p->n_out,
-                       dOut, p->Wh, w.Y[7], w.Ga);
+    if (f32)
+        hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3((unsigned)(((size_t)N * 64 + 255) / 256)), dim3(256), 0, st, N, p->n_out,
+                           dOut, p->Wh, w.Y[7], w.Ga);
+    else  // G7 = (dOut * Wh) masked by layer 7's ReLU bits: a K=16 GEMM
+        hipLaunchKernelGGL((mlp_gemm6_kernel<1, 2, 2, 2, 4, true>), dim3(grid6), dim3(256), 0, st, N, dOut, p->n_out, 16,
+                           (const float*)nullptr, 0, 0, p->n_out, w.Wh6b, (const float*)nullptr, w.mask[7], w.Ga, MLP_W, MLP_W);
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     hipLaunchKernelGGL(mlp_heads_dw_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, w.Y[7], w.partial_h,
                        w.partial_hb);
@@ -642,19 +729,35 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             X1 = w.Y[l - 1], ldx1 = MLP_W, K1 = MLP_W;
         }
         const int Kp = K1 + K2;
-        const int slabs = (Kp + DW_SLAB - 1) / DW_SLAB;
-        hipLaunchKernelGGL(mlp_dw_kernel, dim3(slabs, chunks), dim3(512), 0, st, N, X1, ldx1, K1, X2, ldx2, K2, G, w.partial,
-                           w.partial_db);
-        hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, chunks, Kp, layer_in(p, l),
-                           p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
+        if (f32) {
+            const int slabs = (Kp + DW_SLAB - 1) / DW_SLAB;
+            hipLaunchKernelGGL(mlp_dw_kernel, dim3(slabs, chunks), dim3(512), 0, st, N, X1, ldx1, K1, X2, ldx2, K2, G, w.partial,
+                               w.partial_db);
+            hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, chunks, chunks, Kp,
+                               layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
+        } else {
+            const DwPlan d = dw6_plan(N, Kp);
+            hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2, K2, G,
+                               w.partial, w.partial_db);
+            const int per_group = (d.chunks + DW_GROUPS - 1) / DW_GROUPS;
+            const int groups = (d.chunks + per_group - 1) / per_group;
+            hipLaunchKernelGGL(mlp_reduce_dw_groups_kernel, dim3((Kp * MLP_W + 255) / 256, groups), dim3(256), 0, st, d.chunks,
+                               per_group, Kp * MLP_W, w.partial, w.part2);
+            hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, groups, 2 * d.chunks, Kp,
+                               layer_in(p, l), p->emb_dim, w.part2, w.partial_db, dW[l], db[l]);
+        }
         if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]
             for (int c0 = 0; c0 < p->t_dim; c0 += 16)     // the small kernel handles 16 output columns per pass
                 hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N,
                                    p->t_dim - c0 < 16 ? p->t_dim - c0 : 16, G, p->W[l] + MLP_XE + c0, layer_in(p, l), 1,
                                    (const float*)nullptr, dtemb + c0, p->t_dim, l == 0 ? 1 : 0);
         if (l >= 1) {
-            hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W, (const float*)nullptr, 0,
-                               0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
+            if (f32)
+                hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W,
+                                   (const float*)nullptr, 0, 0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
+            else
+                hipLaunchKernelGGL((mlp_gemm6_kernel<1, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, G, MLP_W, MLP_W,
+                                   (const float*)nullptr, 0, 0, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn, MLP_W, MLP_W);
             float* t = G;
             G = Gn;
             Gn = t;
