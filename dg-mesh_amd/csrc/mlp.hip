@@ -531,6 +531,16 @@ DwPlan dw6_plan(int N, int Kp) {
     d.chunks = (N + rows - 1) / rows;
     return d;
 }
+int num_cus() {
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            n <= 0)
+            n = 256;
+        return n;
+    }();
+    return v;
+}
 constexpr int DW_GROUPS = 8;  // first-level groups of the two-level dW partial reduction
 // 0: bf16x6 (fp32 operands split exactly into 3 bf16, 6 partial products on the bf16 matrix cores; default)
 // 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f32|bf16x6.
@@ -666,7 +676,16 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             else if (abl == 2) G6_FWD(2);
             else if (abl == 3) G6_FWD(3);
             else if (abl == 4) G6_FWD(4);
-            else G6_FWD(0);
+            else if (abl == 9 || K1 + K2 == MLP_EMB + MLP_W) G6_FWD(0);  // skip layer: its 22 x 12 weight registers do not fit
+            else {
+                const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
+                if (K1 + K2 == MLP_W)
+                    hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
+                                       w.Wt6[l], p->b[l], w.mask[l], w.Y[l], (unsigned long long*)nullptr);
+                else
+                    hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 6, 2, 4>), dim3(gx), dim3(256), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
+                                       w.Wt6[l], p->b[l], w.mask[l], w.Y[l], (unsigned long long*)nullptr);
+            }
 #undef G6_FWD
             continue;
         }
@@ -755,9 +774,12 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             if (f32)
                 hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W,
                                    (const float*)nullptr, 0, 0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
-            else
-                hipLaunchKernelGGL((mlp_gemm6_kernel<1, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, G, MLP_W, MLP_W,
-                                   (const float*)nullptr, 0, 0, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn, MLP_W, MLP_W);
+            else {
+                const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
+                hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
+                                   (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn,
+                                   (unsigned long long*)nullptr);
+            }
             float* t = G;
             G = Gn;
             Gn = t;

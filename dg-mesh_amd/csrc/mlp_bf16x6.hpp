@@ -277,6 +277,201 @@ mlp_gemm6_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const fl
     }
 }
 
+// ---- the trunk-layer GEMM, weights stationary in REGISTERS ------------------------------------------------------------
+// C[M x 256] = [A1 | A2] * B  (EPI 0 / EPI 1 as above).  The whole B operand of a wave -- all K of its NT*32 output
+// columns, three bf16 planes -- lives in registers for the lifetime of the kernel (K = 256, NT = 2: 384 of the 512
+// registers a wave owns at one wave per SIMD); the matrix-core operands are read straight from there.  What streams is
+// the activation side only, in tiles of 32 rows:
+//   * persistent grid, one 4-wave workgroup per CU; wave w owns columns [w*NT*32, (w+1)*NT*32) (+ blockIdx.y * 128
+//     when NT == 1, the K = 352 skip layer, whose planes would not fit otherwise);
+//   * tile t+2 is fetched with plain coalesced float4 loads (8 rows x 128 B per wave instruction) into registers while
+//     tile t is multiplied; at the top of the next step it is split into the three bf16 planes and written to LDS as
+//     [k step][plane][k half][row] 16-byte granules (double buffered), so an A fragment is one ds_read_b128 and a wave
+//     reads 1 KiB contiguous -- no bank conflicts on either side;
+//   * per tile and wave: KS * 3 fragment reads feed KS * 6 * NT MFMAs; one barrier per tile; nothing but the
+//     activations ever crosses LDS, and no weight byte is re-read.
+// HBM traffic is the algorithmic minimum (A once, C once); rows are balanced over the CUs at 32-row granularity.
+template <int EPI, int KS, int NT, int NW, int ABL = 0, bool TIMING = false>  // NW waves, each NT*32 columns: NW * NT * 32 = 256 (or 128 with gridDim.y = 2)
+__global__ void __launch_bounds__(NW * 64)
+mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2,
+                  const uint4* __restrict__ Bp, const float* __restrict__ bias, unsigned* __restrict__ mask,
+                  float* __restrict__ C, unsigned long long* __restrict__ dbg = nullptr) {
+    constexpr int K = KS * 16;
+    constexpr int PU = KS * 6 * 32;     // granules per plane tile
+    constexpr int NR = 4 * (K / 32) / NW;  // producer blocks (8 rows x 32 floats) per wave and tile
+    static_assert(NR * NW == 4 * (K / 32), "producer blocks must divide over the waves");
+    __shared__ uint4 Ps[2 * PU];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int col0 = blockIdx.y * (NW * NT * 32) + wv * (NT * 32);
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+
+    bf16x8 bh[KS][NT], bm[KS][NT], bl[KS][NT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const uint4* b = Bp + ((size_t)ks * 6 + g) * 256 + col0 + nt * 32 + li;
+            bh[ks][nt] = as_bf16x8(b[0]), bm[ks][nt] = as_bf16x8(b[512]), bl[ks][nt] = as_bf16x8(b[1024]);
+        }
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bv[nt] = (EPI == 0) ? bias[col0 + nt * 32 + li] : 0.f;
+
+    // producer role: block i of this wave = rows (b & 3) * 8 + (lane & 7), floats (b >> 2) * 32 + (lane >> 3) * 4 .. +3
+    float4 R[NR];
+    const int p_r = lane & 7, p_k = (lane >> 3) * 4;
+#define R6_LOAD(tile_)                                                                                                 \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NR; i_++) {                                                            \
+            const int b_ = wv * NR + i_;                                                                               \
+            int grow_ = (tile_) * 32 + (b_ & 3) * 8 + p_r;                                                             \
+            grow_ = grow_ < M ? grow_ : M - 1;                                                                         \
+            const int k_ = (b_ >> 2) * 32;                                                                             \
+            const float* s_ = (k_ < K1) ? (A1 + (size_t)grow_ * lda1 + k_ + p_k) : (A2 + (size_t)grow_ * lda2 + (k_ - K1) + p_k); \
+            R[i_] = *reinterpret_cast<const float4*>(s_);                                                              \
+        }                                                                                                              \
+    }
+#define R6_SPLIT(pb_)                                                                                                  \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NR; i_++) {                                                            \
+            const int b_ = wv * NR + i_;                                                                               \
+            const int row_ = (b_ & 3) * 8 + p_r;                                                                       \
+            const int k_ = (b_ >> 2) * 32 + p_k;                                                                       \
+            unsigned h0_, m0_, l0_, h1_, m1_, l1_;                                                                     \
+            split2(R[i_].x, R[i_].y, h0_, m0_, l0_);                                                                   \
+            split2(R[i_].z, R[i_].w, h1_, m1_, l1_);                                                                   \
+            uint2* d_ = reinterpret_cast<uint2*>(&Ps[(pb_) * PU + ((k_ >> 4) * 6 + ((k_ >> 3) & 1)) * 32 + row_]) + ((k_ >> 2) & 1); \
+            d_[0] = make_uint2(h0_, h1_);                                                                              \
+            d_[2 * 64] = make_uint2(m0_, m1_);                                                                         \
+            d_[4 * 64] = make_uint2(l0_, l1_);                                                                         \
+        }                                                                                                              \
+    }
+#define R6_MFMA(pb_)                                                                                                   \
+    {                                                                                                                  \
+        const uint4* ps = &Ps[(pb_) * PU + g * 32 + li];                                                               \
+        /* A fragments are single-buffered (no registers to spare): each plane is re-read right after its last use, */ \
+        /* and the products are ordered h, h, h, m, m, l so that every read has MFMAs of the same step to hide behind */ \
+        bf16x8 ah = as_bf16x8(ps[0]), am = as_bf16x8(ps[64]), al = as_bf16x8(ps[128]);                                 \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks++) {                                                            \
+            const int nx = (ks + 1 < KS ? ks + 1 : ks) * 192;                                                          \
+            if (ABL == 2) asm volatile("" ::"v"(ah), "v"(am), "v"(al));                                                \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) if (ABL != 2) {                                          \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks][nt], acc[nt], 0, 0, 0);                   \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks][nt], acc[nt], 0, 0, 0);                   \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks][nt], acc[nt], 0, 0, 0);                   \
+            }                                                                                                          \
+            ah = as_bf16x8(ps[nx]);                                                                                    \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) if (ABL != 2) {                                          \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks][nt], acc[nt], 0, 0, 0);                   \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks][nt], acc[nt], 0, 0, 0);                   \
+            }                                                                                                          \
+            am = as_bf16x8(ps[nx + 64]);                                                                               \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) if (ABL != 2)                                            \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks][nt], acc[nt], 0, 0, 0);                   \
+            al = as_bf16x8(ps[nx + 128]);                                                                              \
+        }                                                                                                              \
+        R6_T(2)                                                                                                        \
+    }
+#define R6_EPILOGUE(tile_)                                                                                             \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int rb = 0; rb < 16; rb += 8) {                                                         \
+            unsigned mws[8][NT];                                                                                       \
+            if (EPI == 1) { /* the mask words of eight rows first (clamped rows: no branches), so the loads overlap */  \
+                _Pragma("unroll") for (int r = rb; r < rb + 8; r++) {                                                  \
+                    int rc = (tile_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;                                            \
+                    rc = rc < M ? rc : M - 1;                                                                          \
+                    if (NT == 2) {                                                                                     \
+                        const uint2 q = *reinterpret_cast<const uint2*>(mask + (size_t)rc * 8 + (col0 >> 5));          \
+                        mws[r - rb][0] = q.x, mws[r - rb][NT - 1] = q.y;                                               \
+                    } else {                                                                                           \
+                        mws[r - rb][0] = mask[(size_t)rc * 8 + (col0 >> 5)];                                           \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+            _Pragma("unroll") for (int r = rb; r < rb + 8; r++) {                                                      \
+                const int row = (tile_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;                                         \
+                const bool ok = (ABL == 4) ? (row < 0) : (row < M);                                                    \
+                unsigned mw[NT];                                                                                       \
+                _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                                    \
+                    float v = acc[nt][r];                                                                              \
+                    if (EPI == 0) {                                                                                    \
+                        v = fmaxf(v + bv[nt], 0.f);                                                                    \
+                        mw[nt] = (unsigned)(__ballot(v > 0.f) >> (g * 32));                                            \
+                    } else {                                                                                           \
+                        v = ((mws[r - rb][nt] >> li) & 1u) ? v : 0.f;                                                  \
+                    }                                                                                                  \
+                    if (ok) C[(size_t)row * 256 + col0 + nt * 32 + li] = v;                                            \
+                    acc[nt][r] = 0.f;                                                                                  \
+                }                                                                                                      \
+                if (EPI == 0 && li == 0 && ok) {                                                                       \
+                    if (NT == 2) *reinterpret_cast<uint2*>(mask + (size_t)row * 8 + (col0 >> 5)) = make_uint2(mw[0], mw[NT - 1]); \
+                    else mask[(size_t)row * 8 + (col0 >> 5)] = mw[0];                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        R6_T(3)                                                                                                        \
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;  // split, load, mfma, epilogue, barrier
+#define R6_T(i_)                                                                                                       \
+    if (TIMING) {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                                   \
+        tm[i_] += t1_ - t0;                                                                                            \
+        t0 = t1_;                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+
+    if (my_tiles > 0) {
+        R6_LOAD(blockIdx.x)
+        R6_SPLIT(0)
+        if (my_tiles > 1) R6_LOAD(blockIdx.x + G)
+    }
+    __syncthreads();
+    if (TIMING) t0 = __builtin_amdgcn_s_memtime();
+    // Waves w and w + 4 share a SIMD (NW == 8): the low wave runs [split, load | multiply, store], the high wave
+    // [multiply, store | split, load], so that the two are out of phase between the per-tile barriers.
+    for (int j = 0; j < my_tiles; j++) {
+        const int tile = blockIdx.x + j * G;
+        if (NW == 4 || wv < 4) {
+            if (j + 1 < my_tiles) R6_SPLIT((j + 1) & 1)      // R holds tile j+1 (fetched during the previous step)
+            R6_T(0)
+            if (ABL != 5 && j + 2 < my_tiles) R6_LOAD(tile + 2 * G)
+            __builtin_amdgcn_sched_barrier(0);
+            R6_T(1)
+            R6_MFMA(j & 1)
+            R6_EPILOGUE(tile)
+        } else {
+            R6_MFMA(j & 1)
+            R6_EPILOGUE(tile)
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < my_tiles) R6_SPLIT((j + 1) & 1)
+            R6_T(0)
+            if (ABL != 5 && j + 2 < my_tiles) R6_LOAD(tile + 2 * G)
+            R6_T(1)
+        }
+        __syncthreads();
+        R6_T(4)
+    }
+    if (TIMING && dbg != nullptr && blockIdx.x == 0 && (wv == 0 || wv == 4) && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) dbg[(wv >> 2) * 8 + i] = tm[i];
+        dbg[(wv >> 2) * 8 + 6] = (unsigned long long)my_tiles;
+    }
+#undef R6_T
+#undef R6_LOAD
+#undef R6_SPLIT
+#undef R6_MFMA
+#undef R6_EPILOGUE
+}
+
 // ---- weight gradient: partial[chunk][k][j] = sum_{rows of chunk} X[row][k] * G[row][j] ------------------------------
 // The contraction runs over ROWS, so both MFMA operands need "8 consecutive rows of one column" per lane: a stage of
 // 16 rows is split and transposed on its way into LDS.  A staging thread owns an 8-row x 4-column block (eight
