@@ -150,8 +150,9 @@ def main():
         dist.barrier()
     L.lib().dgm_set_profiling(2)
     torch.cuda.synchronize()
+    RZ = importlib.import_module("dg-mesh_amd.rasterizer")
+    RZ.FORWARD_CALL_SECONDS = 0.0
     t0 = time.perf_counter()
-    R_seen = []
     for i in range(args.steps):
         _, pkg = tr.step(it0 + args.warmup + i)
     torch.cuda.synchronize()
@@ -181,11 +182,14 @@ def main():
             "config": {"workload": "D-NeRF jumpingjacks-like cfg2: 800x800, P=100000 Gaussians, deformation MLP on "
                                    "(deform + deform_back, is_blender), 1 frame per rank per step",
                        "P": P, "W": W, "H": H, "num_rendered": n_inst, "visible": R, "mlp_impl": mlp_impl,
-                       "parallelism": f"dp{world} (frame-parallel, flat-bucket all-reduce {tr.bucket.nbytes() / 1e6:.1f} MB)"},
-            "roofline": {"kernel": "render_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "parallelism": f"dp{world} (frame-parallel, flat-bucket all-reduce {tr.grad_bytes() / 1e6:.1f} MB)"},
+            "roofline": {"kernel": "render_bwd2_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms, "launches": bwd_n},
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
+            # host side: time blocked in the rasterizer forward (its R read-back is the step's only sync) vs busy
+            "host_ms_per_step": {"blocked_on_gpu": round(1e3 * RZ.FORWARD_CALL_SECONDS / args.steps, 3),
+                                 "busy": round(1e3 * (elapsed - RZ.FORWARD_CALL_SECONDS) / args.steps, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

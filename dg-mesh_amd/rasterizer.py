@@ -10,6 +10,7 @@ PyTorch is plumbing here: it owns device memory, the stream and autograd bookkee
 in the HIP library; tensors are handed over as raw device pointers through ctypes.
 """
 import ctypes
+import time
 from typing import NamedTuple
 
 import torch
@@ -19,6 +20,7 @@ from . import _lib
 
 NUM_CHANNELS = 3  # DGR/cuda_rasterizer/config.h:15
 LAST_NUM_RENDERED = 0  # num_rendered of the most recent forward (read by bench.py for the roofline bytes)
+FORWARD_CALL_SECONDS = 0.0  # wall time spent inside dgm_rasterize_forward, i.e. mostly waiting on the R read-back
 
 
 def _ptr(t):
@@ -76,6 +78,7 @@ class _CModule:
         M = sh.size(1) if sh is not None and sh.numel() != 0 else 0
         rendered = ctypes.c_int(0)
         cbs = (_resizer(geom), _resizer(binning), _resizer(img))
+        t_call = time.perf_counter()
         with torch.cuda.device(dev):
             _lib.check(L.dgm_rasterize_forward(
                 cbs[0], None, cbs[1], None, cbs[2], None, P, int(degree), M, _ptr(background), W, H, _ptr(means3D),
@@ -83,8 +86,9 @@ class _CModule:
                 _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), _ptr(out_color), _ptr(radii), int(bool(debug)), _stream(),
                 ctypes.byref(rendered)))
-        global LAST_NUM_RENDERED
+        global LAST_NUM_RENDERED, FORWARD_CALL_SECONDS
         LAST_NUM_RENDERED = rendered.value
+        FORWARD_CALL_SECONDS += time.perf_counter() - t_call  # contains the step's only host<->device sync (R read-back)
         return rendered.value, out_color, radii, geom, binning, img
 
     @staticmethod

@@ -11,9 +11,12 @@ Data parallelism (absent in the reference; BASELINE.json north_star): one proces
 ranks, every rank holds a full replica of the Gaussians and MLPs.
   * all ranks derive the same shuffled camera order from a shared seed; rank r takes entries r, r+W, ... so one
     step consumes W frames (effective batch W);
-  * gradients live in ONE flat fp32 bucket (every .grad is a view into it), so the exchange is a single
-    all-reduce(SUM) per step over RCCL/xGMI -- 35 MB at P=100k: latency-bound, one collective beats many;
-  * every rank then applies the identical Adam update, so replicas stay bit-identical without broadcasting.
+  * gradients are exchanged as ONE flat fp32 bucket, a single all-reduce(SUM) per step over RCCL/xGMI -- 35 MB at
+    P=100k: latency-bound, one collective beats many.  On the GPU the step's fresh gradients are packed into the
+    bucket by one multi-tensor copy ("pack" mode; no per-tensor accumulate kernels, no zero-fill), on the CPU test
+    path every .grad is a view into the bucket ("views" mode, which also supports accumulating several frames);
+  * every rank then applies the identical Adam update, so replicas stay bit-identical without broadcasting.  On the
+    GPU that is one kernel for all three optimizers (optim.MultiAdam).
   W ranks x 1 frame is therefore equivalent to 1 rank accumulating the same W frames before stepping.
 """
 import random
@@ -27,16 +30,33 @@ from . import scene as S
 class FlatGradBucket:
     """All gradients of `params` as views into one contiguous buffer (DDP's gradient_as_bucket_view idea)."""
 
-    def __init__(self, params):
+    def __init__(self, params, attach=True):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self.views = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
+            if attach:
+                p.grad = self.views[-1]
             off += n
+
+    def pack(self):
+        """Copy the parameters' current .grad tensors into the bucket (one multi-tensor kernel); absent gradients
+        count as zero.  Returns {id(param): view}."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        return {id(p): v for p, v in zip(self.params, self.views)}
 
     def zero(self):
         self.flat.zero_()
@@ -77,18 +97,25 @@ class Trainer:
         gaussians.training_setup(self.opt)
         deform.train_setting(self.opt)
         deform_back.train_setting(self.opt)
-        if fused:  # same update rule, one multi-tensor kernel per optimizer instead of several per tensor
-            for o in (gaussians, deform, deform_back):
-                for group in o.optimizer.param_groups:
-                    group["fused"], group["foreach"] = True, False
         self.optimizers = [gaussians.optimizer, deform.optimizer, deform_back.optimizer]
+        self.multi_adam = None
+        if fused:  # same update rule, ONE kernel for every tensor of the three optimizers
+            from .optim import MultiAdam
+            self.multi_adam = MultiAdam(self.optimizers)
         # parameters that receive gradients in the Gaussian branch (the normal parameter is only used by the
         # mesh branch; leaving its .grad None mirrors zero_grad(set_to_none=True))
         params = [gaussians._xyz, gaussians._features_dc, gaussians._features_rest, gaussians._opacity,
                   gaussians._scaling, gaussians._rotation]
         params += list(deform.net.parameters()) + list(deform_back.net.parameters())
-        self.bucket = FlatGradBucket(params)
+        self.params = [p for p in params if p.requires_grad]
+        # "pack": gradients are fresh tensors every step (no accumulate kernels); "views": .grad lives in the bucket
+        self.pack = self.multi_adam is not None
+        self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or world > 1) else None
         self.time_interval = 1.0 / max(len(cameras), 1)
+
+    def grad_bytes(self):
+        """Size of the all-reduce payload (all gradients, fp32)."""
+        return sum(p.numel() for p in self.params) * 4
 
     def loss_terms(self, cam, iteration):
         g, opt = self.g, self.opt
@@ -123,13 +150,23 @@ class Trainer:
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         cam = self.cameras[frame_schedule(len(self.cameras), self.step_count, self.rank, self.world, self.seed)]
-        self.bucket.zero()
+        if self.pack:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.bucket.zero()
         losses, pkg = self.loss_terms(cam, iteration)
         loss = sum(losses.values())
         loss.backward()
+        grads = None
         if self.world > 1:
+            if self.pack:
+                grads = self.bucket.pack()
             self.bucket.all_reduce(self.group)
-        for o in self.optimizers:
-            o.step()
+        if self.multi_adam is not None:
+            self.multi_adam.step(grads)
+        else:
+            for o in self.optimizers:
+                o.step()
         self.step_count += 1
         return loss.detach(), pkg

@@ -206,6 +206,17 @@ int dgm_image_loss_forward(const float* image, const float* gt, int channels, in
 int dgm_image_loss_backward(const float* image, const float* gt, int channels, int H, int W, float lambda_dssim,
                             const char* workspace, const float* grad_out, float* d_image, void* stream);
 
+/* ---- optimizer ---------------------------------------------------------------------------------------- */
+
+/* torch.optim.Adam (amsgrad=False, weight_decay=0) over n_tensors tensors in ONE kernel launch: the Adam steps that
+ * close a train iteration (dgmesh/train.py:518-524; groups of gaussian_model_dpsr_dynamic_anchor.py:186-212 and
+ * deform_model.py:33-44).  All arrays are HOST arrays of length n_tensors; params / grads / exp_avg / exp_avg_sq hold
+ * fp32 device pointers, lr[i] the tensor's learning rate, step[i] >= 1 its step count AFTER this update (bias
+ * correction 1 - beta^step).  Tensors with numel 0 are skipped. */
+int dgm_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const long long* numel, const float* lr, const int* step, float beta1,
+                  float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

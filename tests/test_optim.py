@@ -1,0 +1,79 @@
+"""MultiAdam (dgm_adam_step): the three torch.optim.Adam(eps=1e-15) steps of a train iteration as one kernel.
+GPU: identical trajectory to torch.optim.Adam over several steps with per-group learning rates that change every step
+(the reference rewrites param_groups[*]["lr"] each iteration) -- tolerance 1e-6 relative (same formula, fp32).
+CPU: the flat-bucket packing used by the data-parallel path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+
+def test_bucket_pack_cpu():
+    T = pkg("trainer")
+    a, b, c = (torch.nn.Parameter(torch.zeros(3, 2)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2)))
+    bk = T.FlatGradBucket([a, b, c], attach=False)
+    assert a.grad is None
+    (a.sum() * 2 + (b * torch.arange(5.0)).sum()).backward()     # c receives no gradient
+    bk.flat.fill_(7.0)
+    views = bk.pack()
+    assert bk.flat.tolist() == [2.0] * 6 + [0.0, 1.0, 2.0, 3.0, 4.0] + [0.0, 0.0]
+    assert views[id(b)].data_ptr() == bk.flat.data_ptr() + 6 * 4 and views[id(b)].shape == b.shape
+
+
+@pytest.mark.gpu
+def test_multi_adam_matches_torch_adam():
+    O = pkg("optim")
+    dev = "cuda"
+    rng = np.random.RandomState(0)
+    shapes = [(100000, 3), (100000, 15, 3), (100000, 1), (256, 352), (256,), (3, 256), (7,), (1,), (4099,)]
+    ref = [torch.nn.Parameter(torch.tensor(rng.randn(*s).astype(np.float32), device=dev)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+
+    def make(ps):
+        o1 = torch.optim.Adam([{"params": [ps[0]], "lr": 1.6e-4, "name": "xyz"}, {"params": [ps[1]], "lr": 1.25e-4},
+                               {"params": [ps[2]], "lr": 0.05}], lr=0.0, eps=1e-15)
+        o2 = torch.optim.Adam([{"params": ps[3:7], "lr": 8e-4}], eps=1e-15)
+        o3 = torch.optim.Adam([{"params": ps[7:], "lr": 1e-3}], eps=1e-15, betas=(0.8, 0.99))
+        return [o1, o2, o3]
+
+    o_ref, o_mine = make(ref), make(mine)
+    ma = O.MultiAdam(o_mine)
+    for it in range(6):
+        scale = 10.0 ** (-it)                                   # gradients spanning many magnitudes
+        for k, (p, q) in enumerate(zip(ref, mine)):
+            g = torch.tensor(rng.randn(*p.shape).astype(np.float32), device=dev) * scale
+            if it == 2 and k == 4:
+                p.grad, q.grad = None, None                     # a tensor that skips a step keeps its own step count
+            else:
+                p.grad, q.grad = g, g.clone()
+        for oa, ob in zip(o_ref, o_mine):                       # lr schedule: rewritten every iteration
+            for ga, gb in zip(oa.param_groups, ob.param_groups):
+                ga["lr"] = gb["lr"] = ga["lr"] * 0.9
+        for o in o_ref:
+            o.step()
+        ma.step()
+        for k, (p, q) in enumerate(zip(ref, mine)):
+            err = (p - q).abs().max().item() / (p.abs().max().item() + 1e-30)
+            assert err < 1e-6, f"step {it} tensor {k}: {err:.2e}"
+    # gradients passed explicitly (views of a reduced bucket) behave the same as .grad
+    g = {id(q): torch.ones_like(q) for q in mine}
+    for p in ref:
+        p.grad = torch.ones_like(p)
+    for q in mine:
+        q.grad = None
+    for o in o_ref:
+        o.step()
+    ma.step(g)
+    for p, q in zip(ref, mine):
+        assert (p - q).abs().max().item() / (p.abs().max().item() + 1e-30) < 1e-6
+
+
+@pytest.mark.gpu
+def test_multi_adam_rejects_unsupported():
+    O = pkg("optim")
+    p = torch.nn.Parameter(torch.zeros(4, device="cuda"))
+    with pytest.raises(ValueError):
+        O.MultiAdam([torch.optim.Adam([p], amsgrad=True)])
+    with pytest.raises(ValueError):
+        O.MultiAdam([torch.optim.Adam([p], weight_decay=0.1)])
