@@ -511,26 +511,11 @@ int mlp_fail(const char* msg) {
     return 1;
 }
 struct Ws {
-    float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb, *part2;
+    float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb, *part2, *part2_db;
     uint4 *Wt6[8], *Wd6[8], *Wh6f, *Wh6b;  // bf16x6 weight planes
     unsigned* mask[8];
     size_t bytes;
 };
-// bf16x6 dW decomposition: about 512 workgroups (two per CU) whatever the layer's K
-struct DwPlan {
-    int rows, chunks, slabs;
-};
-DwPlan dw6_plan(int N, int Kp) {
-    DwPlan d;
-    d.slabs = (Kp + DW6_SLAB - 1) / DW6_SLAB;
-    const int target = 512 / d.slabs;
-    int rows = (N + target - 1) / target;
-    rows = (rows + 15) & ~15;
-    if (rows < 16) rows = 16;
-    d.rows = rows;
-    d.chunks = (N + rows - 1) / rows;
-    return d;
-}
 int num_cus() {
     static const int v = [] {
         int dev = 0, n = 0;
@@ -540,6 +525,22 @@ int num_cus() {
         return n;
     }();
     return v;
+}
+// bf16x6 dW decomposition: about 512 workgroups (two per CU) whatever the layer's K
+struct DwPlan {
+    int rows, chunks, slabs;
+};
+DwPlan dw6_plan(int N, int Kp) {
+    DwPlan d;
+    d.slabs = (Kp + DW6_SLAB - 1) / DW6_SLAB;
+    if (Kp == MLP_W) d.slabs = 1;  // mlp_dw6b_kernel: one 8-wave workgroup per chunk covers all 256 columns
+    const int target = (Kp == MLP_W) ? num_cus() : 512 / d.slabs;
+    int rows = (N + target - 1) / target;
+    rows = (rows + 15) & ~15;
+    if (rows < 16) rows = 16;
+    d.rows = rows;
+    d.chunks = (N + rows - 1) / rows;
+    return d;
 }
 constexpr int DW_GROUPS = 8;  // first-level groups of the two-level dW partial reduction
 // 0: bf16x6 (fp32 operands split exactly into 3 bf16, 6 partial products on the bf16 matrix cores; default)
@@ -575,6 +576,7 @@ Ws carve(char* base, int N) {
     w.partial = take(pfl * MLP_W * 4);
     w.partial_db = take(pdb * MLP_W * 4);
     w.part2 = take((size_t)DW_GROUPS * (MLP_EMB + MLP_W) * MLP_W * 4);
+    w.part2_db = take((size_t)DW_GROUPS * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.Wt6[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 6);
     for (int l = 0; l < 8; l++) w.Wd6[l] = (uint4*)take((size_t)MLP_W * MLP_W * 6);
     w.Wh6f = (uint4*)take((size_t)MLP_W * 32 * 6);
@@ -629,26 +631,30 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
     const bool f32 = use_f32_mfma();
-    for (int l = 0; l < 8; l++) {
-        const int Kp = layer_kp(p, l);
-        if (f32) {
+    if (f32) {
+        for (int l = 0; l < 8; l++) {
+            const int Kp = layer_kp(p, l);
             const int n = (Kp > MLP_W ? Kp : MLP_W) * MLP_W;
             hipLaunchKernelGGL(mlp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, layer_in(p, l), Kp, p->emb_dim,
                                l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
-        } else {
-            hipLaunchKernelGGL(mlp_prep6_kernel, dim3((Kp / 8 * MLP_W + 255) / 256), dim3(256), 0, st, 0, Kp, MLP_W,
-                               layer_in(p, l), p->emb_dim, 0, 0, MLP_W, p->W[l], w.Wt6[l]);
-            if (l >= 1)
-                hipLaunchKernelGGL(mlp_prep6_kernel, dim3((MLP_W / 8 * MLP_W + 255) / 256), dim3(256), 0, st, 1, MLP_W, MLP_W,
-                                   layer_in(p, l), p->emb_dim, l == p->skip_layer ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l],
-                                   w.Wd6[l]);
         }
-    }
-    if (!f32) {
-        hipLaunchKernelGGL(mlp_prep6_kernel, dim3((MLP_W / 8 * 32 + 255) / 256), dim3(256), 0, st, 0, MLP_W, 32, MLP_W, 0, 0,
-                           0, p->n_out, p->Wh, w.Wh6f);
-        hipLaunchKernelGGL(mlp_prep6_kernel, dim3((16 / 8 * MLP_W + 255) / 256), dim3(256), 0, st, 1, 16, MLP_W, MLP_W, 0, 0,
-                           p->n_out, MLP_W, p->Wh, w.Wh6b);
+    } else {  // all 17 weight re-layouts (8 forward, 7 backward-data, 2 head matrices) in one launch
+        Prep6Batch pb;
+        int nj = 0, max_threads = 0;
+        auto add = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp,
+                       uint4* Bp) {
+            Prep6Job& j = pb.job[nj++];
+            j.mode = mode, j.Kp = Kp, j.ncols = ncols, j.in_features = in_features, j.emb_dim = p->emb_dim, j.hoff = hoff;
+            j.k_valid = k_valid, j.col_valid = col_valid, j.W = Wp, j.Bp = Bp;
+            if (Kp / 8 * ncols > max_threads) max_threads = Kp / 8 * ncols;
+        };
+        for (int l = 0; l < 8; l++) {
+            add(0, layer_kp(p, l), MLP_W, layer_in(p, l), 0, 0, MLP_W, p->W[l], w.Wt6[l]);
+            if (l >= 1) add(1, MLP_W, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l], w.Wd6[l]);
+        }
+        add(0, MLP_W, 32, MLP_W, 0, 0, p->n_out, p->Wh, w.Wh6f);
+        add(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh6b);
+        hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
     }
     {
         const size_t tot = (size_t)N * MLP_EMB;
@@ -756,14 +762,18 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                                layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
         } else {
             const DwPlan d = dw6_plan(N, Kp);
-            hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2, K2, G,
-                               w.partial, w.partial_db);
+            if (Kp == MLP_W)
+                hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial,
+                                   w.partial_db);
+            else
+                hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
+                                   K2, G, w.partial, w.partial_db);
             const int per_group = (d.chunks + DW_GROUPS - 1) / DW_GROUPS;
             const int groups = (d.chunks + per_group - 1) / per_group;
             hipLaunchKernelGGL(mlp_reduce_dw_groups_kernel, dim3((Kp * MLP_W + 255) / 256, groups), dim3(256), 0, st, d.chunks,
-                               per_group, Kp * MLP_W, w.partial, w.part2);
-            hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, groups, 2 * d.chunks, Kp,
-                               layer_in(p, l), p->emb_dim, w.part2, w.partial_db, dW[l], db[l]);
+                               per_group, Kp * MLP_W, w.partial, w.part2, 2, w.partial_db, w.part2_db);
+            hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, groups, groups, Kp,
+                               layer_in(p, l), p->emb_dim, w.part2, w.part2_db, dW[l], db[l]);
         }
         if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]
             for (int c0 = 0; c0 < p->t_dim; c0 += 16)     // the small kernel handles 16 output columns per pass

@@ -63,33 +63,54 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 v) { return __builtin_bi
 //   mode 0 (forward, B = W^T through the trunk's K mapping): B[k][col] = W[col][src(k)]   (col < col_valid)
 //       Kp == 96 : src(k) = k for k < emb_dim (else zero row);  Kp == 352: [emb | h] -> k, k - 96 + emb_dim;  else k
 //   mode 1 (backward data, B = W[:, hoff:hoff+ncols]):      B[k][col] = W[k][hoff + col]  (k < k_valid)
-__global__ void mlp_prep6_kernel(int mode, int Kp, int ncols, int in_features, int emb_dim, int hoff, int k_valid,
-                                 int col_valid, const float* __restrict__ W, uint4* __restrict__ Bp) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (Kp >> 3) * ncols) return;
-    const int kg = idx / ncols, col = idx % ncols;
+struct Prep6Job {
+    int mode, Kp, ncols, in_features, emb_dim, hoff, k_valid, col_valid;
+    const float* W;
+    uint4* Bp;
+};
+static constexpr int PREP6_MAX_JOBS = 20;
+struct Prep6Batch {
+    Prep6Job job[PREP6_MAX_JOBS];
+};
+
+__device__ __forceinline__ void prep6_one(const Prep6Job& j, int idx) {
+    if (idx >= (j.Kp >> 3) * j.ncols) return;
+    const int kg = idx / j.ncols, col = idx % j.ncols;
     float e[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int k = kg * 8 + i;
         float v = 0.f;
-        if (mode == 0) {
+        if (j.mode == 0) {
             int src = k;
-            if (Kp == 96) src = k < emb_dim ? k : -1;
-            else if (Kp == 352) src = k < 96 ? (k < emb_dim ? k : -1) : k - 96 + emb_dim;
-            if (src >= 0 && col < col_valid) v = W[(size_t)col * in_features + src];
+            if (j.Kp == 96) src = k < j.emb_dim ? k : -1;
+            else if (j.Kp == 352) src = k < 96 ? (k < j.emb_dim ? k : -1) : k - 96 + j.emb_dim;
+            if (src >= 0 && col < j.col_valid) v = j.W[(size_t)col * j.in_features + src];
         } else {
-            if (k < k_valid) v = W[(size_t)k * in_features + hoff + col];
+            if (k < j.k_valid) v = j.W[(size_t)k * j.in_features + j.hoff + col];
         }
         e[i] = v;
     }
     uint4 H, Mi, L;
     split8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], H, Mi, L);
     const int stage = kg >> 1, g = kg & 1;
-    uint4* dst = Bp + ((size_t)stage * 6 + g) * ncols + col;
+    uint4* dst = j.Bp + ((size_t)stage * 6 + g) * j.ncols + col;
     dst[0] = H;
-    dst[2 * ncols] = Mi;
-    dst[4 * ncols] = L;
+    dst[2 * j.ncols] = Mi;
+    dst[4 * j.ncols] = L;
+}
+
+// every weight matrix of a network in one launch: blockIdx.y = job (the jobs travel in the kernel argument block)
+__global__ void __launch_bounds__(256) mlp_prep6_batch_kernel(const Prep6Batch b) {
+    prep6_one(b.job[blockIdx.y], blockIdx.x * 256 + threadIdx.x);
+}
+
+__global__ void mlp_prep6_kernel(int mode, int Kp, int ncols, int in_features, int emb_dim, int hoff, int k_valid,
+                                 int col_valid, const float* __restrict__ W, uint4* __restrict__ Bp) {
+    Prep6Job j;
+    j.mode = mode, j.Kp = Kp, j.ncols = ncols, j.in_features = in_features, j.emb_dim = emb_dim, j.hoff = hoff;
+    j.k_valid = k_valid, j.col_valid = col_valid, j.W = W, j.Bp = Bp;
+    prep6_one(j, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---- C[M x ncols] = [A1 | A2] * B -----------------------------------------------------------------------------------
@@ -594,13 +615,131 @@ mlp_dw6_kernel(int M, int rows_per_chunk, const float* __restrict__ X1, int ldx1
         *reinterpret_cast<float4*>(partial_db + ((size_t)chunk * 2 + rg) * 256 + c4 * 4) = colsum;
 }
 
-// first reduction level of the dW partials: part2[grp][k][j] = sum of the chunks of group grp (fixed order)
+// Weight gradient of the K = 256 layers, one 8-wave workgroup per CU covering ALL 256 K columns of a chunk of rows
+// (waves 4 x 2, wave tile 64 x 128): G is split and transposed once instead of once per 128-column slab, the staging
+// work per MFMA halves, and every SIMD hosts exactly one staging wave (threads 0..255) and one pure MFMA wave.
+__global__ void __launch_bounds__(512)
+mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx, const float* __restrict__ G,
+                float* __restrict__ partial, float* __restrict__ partial_db) {
+    __shared__ uint4 Xs[2][DW6_GU];
+    __shared__ uint4 Gs[2][DW6_GU];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1, g = lane >> 5, li = lane & 31;
+    const int chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const int nst = (r1 - r0 + 15) >> 4;
+    // staging role: threads 0..127 -> X blocks (2 row halves x 64 column quads), 128..255 -> G blocks
+    const bool stager = tid < 256, isG = tid >= 128;
+    const int rg = (tid >> 6) & 1, c4 = tid & 63;
+    const float* sp = isG ? (G + c4 * 4) : (X + c4 * 4);
+    const int sld = isG ? 256 : ldx;
+    uint4* sdst0 = (isG ? &Gs[0][0] : &Xs[0][0]) + rg * 256 + c4 * 4;
+    float4 v[8];
+    float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define DWB_LOAD(st_)                                                                                 \
+    if (stager) {                                                                                     \
+        const int rb_ = r0 + (st_) * 16 + rg * 8;                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                            \
+            v[i_] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+            if (rb_ + i_ < r1) v[i_] = *reinterpret_cast<const float4*>(sp + (size_t)(rb_ + i_) * sld); \
+        }                                                                                             \
+    }
+#define DWB_STORE(buf_)                                                                               \
+    if (stager) {                                                                                     \
+        uint4* d_ = sdst0 + (buf_) * DW6_GU;                                                          \
+        uint4 H_, M_, L_;                                                                             \
+        split8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, H_, M_, L_);           \
+        d_[0] = H_, d_[512] = M_, d_[1024] = L_;                                                      \
+        split8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, H_, M_, L_);           \
+        d_[1] = H_, d_[513] = M_, d_[1025] = L_;                                                      \
+        split8(v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z, H_, M_, L_);           \
+        d_[2] = H_, d_[514] = M_, d_[1026] = L_;                                                      \
+        split8(v[0].w, v[1].w, v[2].w, v[3].w, v[4].w, v[5].w, v[6].w, v[7].w, H_, M_, L_);           \
+        d_[3] = H_, d_[515] = M_, d_[1027] = L_;                                                      \
+        if (isG) {                                                                                    \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                        \
+                colsum.x += v[i_].x, colsum.y += v[i_].y, colsum.z += v[i_].z, colsum.w += v[i_].w;   \
+            }                                                                                         \
+        }                                                                                             \
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+
+    DWB_LOAD(0)
+    DWB_STORE(0)
+    __syncthreads();
+    for (int st = 0; st < nst; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nst) DWB_LOAD(st + 1)
+        const uint4* xs = Xs[buf];
+        const uint4* gs = Gs[buf];
+        bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const int ai = g * 256 + wm * 64 + mt * 32 + li;
+            ah[mt] = as_bf16x8(xs[ai]), am[mt] = as_bf16x8(xs[512 + ai]), al[mt] = as_bf16x8(xs[1024 + ai]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int bi = g * 256 + wn * 128 + nt * 32 + li;
+            const bf16x8 bh = as_bf16x8(gs[bi]), bm = as_bf16x8(gs[512 + bi]), bl = as_bf16x8(gs[1024 + bi]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                DGM_MFMA6(acc[mt][nt], ah[mt], am[mt], al[mt], bh, bm, bl)
+            }
+        }
+        if (st + 1 < nst) DWB_STORE(buf ^ 1)
+        __syncthreads();
+    }
+#undef DWB_LOAD
+#undef DWB_STORE
+
+    float* out = partial + (size_t)chunk * 256 * 256;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int col = wn * 128 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                out[(size_t)k * 256 + col] = acc[mt][nt][r];
+            }
+        }
+    if (stager && isG && partial_db != nullptr)
+        *reinterpret_cast<float4*>(partial_db + ((size_t)chunk * 2 + rg) * 256 + c4 * 4) = colsum;
+}
+
+// first reduction level of the dW partials: part2[grp][k][j] = sum of the chunks of group grp (fixed order); the
+// bias-gradient rows (db_rows per chunk, 256 wide) of the group are summed by the blocks with blockIdx.x == 0.
 __global__ void __launch_bounds__(256)
-mlp_reduce_dw_groups_kernel(int chunks, int per_group, int n, const float* __restrict__ partial, float* __restrict__ part2) {
+mlp_reduce_dw_groups_kernel(int chunks, int per_group, int n, const float* __restrict__ partial, float* __restrict__ part2,
+                            int db_rows, const float* __restrict__ partial_db, float* __restrict__ part2_db) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int grp = blockIdx.y;
-    if (idx >= n) return;
     const int c0 = grp * per_group, c1 = min(chunks, c0 + per_group);
+    if (blockIdx.x == 0 && partial_db != nullptr) {
+        float sp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sp[u] = 0.f;
+        const float* src = partial_db + threadIdx.x;
+        int r = c0 * db_rows;
+        const int r1 = c1 * db_rows;
+        for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) sp[u] += src[(size_t)(r + u) * 256];
+        }
+        for (; r < r1; r++) sp[0] += src[(size_t)r * 256];
+        part2_db[grp * 256 + threadIdx.x] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
+    }
+    if (idx >= n) return;
     float sp[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) sp[u] = 0.f;

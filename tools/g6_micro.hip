@@ -77,6 +77,14 @@ int main(int argc, char** argv) {
     });
     timeit("memcpy A -> C (102 MB)", [&] { CK(hipMemcpyAsync(C, A, (size_t)M * 1024, hipMemcpyDeviceToDevice, 0)); });
     unsigned long long hd[16];
+    CK(hipMemset(A, 0, (size_t)M * K * 4));
+    timeit("gemm6r 8w, A = zeros (DVFS check)", [&] {
+        hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(t32 < ncu ? t32 : ncu), dim3(512), 0, 0, M, t32, A, K, K, (const float*)nullptr, 0, Bp, bias, mask, C, (unsigned long long*)nullptr);
+    });
+    CK(hipMemset(Bp, 0, (size_t)K * 256 * 6));
+    timeit("gemm6r 8w, A = B = zeros", [&] {
+        hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(t32 < ncu ? t32 : ncu), dim3(512), 0, 0, M, t32, A, K, K, (const float*)nullptr, 0, Bp, bias, mask, C, (unsigned long long*)nullptr);
+    });
     CK(hipMemset(dbg, 0, 256));
     hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8, 0, true>), dim3(t32 < ncu ? t32 : ncu), dim3(512), 0, 0, M, t32, A, K, K, (const float*)nullptr, 0, Bp, bias, mask, C, dbg);
     CK(hipDeviceSynchronize());
