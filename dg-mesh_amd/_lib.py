@@ -57,6 +57,8 @@ SYMBOLS = {
     "dgm_image_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "dgm_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp]),
     "dgm_mlp_set_gemm": (_i, [_i]),
+    "dgm_timenet_forward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dgm_timenet_backward": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgm_mlp_workspace_bytes": (_c.c_size_t, [_i]),
     "dgm_mlp_forward": (_i, [_c.POINTER(MlpParams), _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_mlp_backward": (_i, [_c.POINTER(MlpParams), _i, _vp, _i, _vp, _vp * 8, _vp * 8, _vp, _vp, _vp, _vp]),

@@ -495,6 +495,75 @@ mlp_dtemb_bcast_kernel(int T, const float* __restrict__ db0, const float* __rest
     if (j == 0) dtemb[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- time branch for ONE row: t_emb = timenet(PE(t)) (R/utils/time_utils.py:52-55, 178-204 with is_blender) ------------
+// t is identical for every Gaussian of a training iteration (R/train.py:158), so the branch is a 13 -> 256 -> 30
+// network on a single row: one workgroup, instead of ~45 one-element PyTorch kernels forward and ~50 backward.
+// save = [pe (2 n_freq + 1) | h (hidden)]
+__global__ void __launch_bounds__(256)
+mlp_timenet_fwd_kernel(const float* __restrict__ t, int n_freq, const float* __restrict__ W1, const float* __restrict__ b1,
+                       int hidden, const float* __restrict__ W2, const float* __restrict__ b2, int n_out,
+                       float* __restrict__ save, float* __restrict__ out) {
+    __shared__ float pe[64];
+    __shared__ float h[1024];
+    const int n_pe = 2 * n_freq + 1;
+    const int tid = threadIdx.x;
+    if (tid < n_pe) {
+        const float tv = t[0];
+        float v = tv;
+        if (tid > 0) {
+            const int q = (tid - 1) >> 1;
+            const float arg = tv * (float)(1 << q);  // freq_bands = 2^linspace(0, n_freq - 1, n_freq)
+            v = ((tid - 1) & 1) ? cosf(arg) : sinf(arg);
+        }
+        pe[tid] = v;
+        save[tid] = v;
+    }
+    __syncthreads();
+    for (int j = tid; j < hidden; j += 256) {
+        float a = b1[j];
+        for (int i = 0; i < n_pe; i++) a += W1[j * n_pe + i] * pe[i];
+        a = fmaxf(a, 0.f);
+        h[j] = a;
+        save[n_pe + j] = a;
+    }
+    __syncthreads();
+    // one wave per output: 64 lanes stride over the hidden units, butterfly sum
+    for (int o = tid >> 6; o < n_out; o += 4) {
+        float a = 0.f;
+        for (int j = tid & 63; j < hidden; j += 64) a += W2[o * hidden + j] * h[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+        if ((tid & 63) == 0) out[o] = a + b2[o];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+mlp_timenet_bwd_kernel(const float* __restrict__ d_out, int n_freq, const float* __restrict__ W2, int hidden, int n_out,
+                       const float* __restrict__ save, float* __restrict__ dW1, float* __restrict__ db1,
+                       float* __restrict__ dW2, float* __restrict__ db2) {
+    __shared__ float dO[64];
+    const int n_pe = 2 * n_freq + 1;
+    const int tid = threadIdx.x;
+    if (tid < n_out) {
+        dO[tid] = d_out[tid];
+        db2[tid] = d_out[tid];
+    }
+    __syncthreads();
+    const float* pe = save;
+    const float* h = save + n_pe;
+    for (int j = tid; j < hidden; j += 256) {
+        const float hj = h[j];
+        float dh = 0.f;
+        for (int o = 0; o < n_out; o++) {
+            dh += dO[o] * W2[o * hidden + j];
+            dW2[o * hidden + j] = dO[o] * hj;
+        }
+        dh = hj > 0.f ? dh : 0.f;
+        db1[j] = dh;
+        for (int i = 0; i < n_pe; i++) dW1[j * n_pe + i] = dh * pe[i];
+    }
+}
+
 }  // namespace dgm
 
 // =================================================================================================================
@@ -798,6 +867,30 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     if (!per_row_t && dtemb != nullptr)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
                            db[p->skip_layer], p->W[p->skip_layer], layer_in(p, p->skip_layer), dtemb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
+    return 0;
+}
+
+int dgm_timenet_forward(const float* t, int n_freq, const float* W1, const float* b1, int hidden, const float* W2,
+                        const float* b2, int n_out, float* save, float* out, void* stream) {
+    if (!t || !W1 || !b1 || !W2 || !b2 || !save || !out) return mlp_fail("timenet_forward: NULL pointer");
+    if (n_freq < 0 || 2 * n_freq + 1 > 64 || hidden < 1 || hidden > 1024 || n_out < 1 || n_out > 64)
+        return mlp_fail("timenet_forward: unsupported size (2 n_freq + 1 <= 64, hidden <= 1024, n_out <= 64)");
+    hipLaunchKernelGGL(mlp_timenet_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, n_freq, W1, b1, hidden, W2, b2,
+                       n_out, save, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
+    return 0;
+}
+
+int dgm_timenet_backward(const float* d_out, int n_freq, const float* W2, int hidden, int n_out, const float* save,
+                         float* dW1, float* db1, float* dW2, float* db2, void* stream) {
+    if (!d_out || !W2 || !save || !dW1 || !db1 || !dW2 || !db2) return mlp_fail("timenet_backward: NULL pointer");
+    if (n_freq < 0 || 2 * n_freq + 1 > 64 || hidden < 1 || hidden > 1024 || n_out < 1 || n_out > 64)
+        return mlp_fail("timenet_backward: unsupported size");
+    hipLaunchKernelGGL(mlp_timenet_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_out, n_freq, W2, hidden, n_out,
+                       save, dW1, db1, dW2, db2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
     return 0;

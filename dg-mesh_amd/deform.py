@@ -94,6 +94,9 @@ class _TrunkNet(nn.Module):
         """(t_emb, broadcast): t identical on every row (expanded view, R/train.py:158) -> evaluate the time branch
         on ONE row and broadcast it."""
         if t.dim() == 2 and t.shape[0] > 1 and t.stride(0) == 0:
+            if self.trunk_impl == "hip" and self.is_blender and t.is_cuda and t.shape[1] == 1:
+                from . import mlp_hip
+                return mlp_hip.time_row(self, t[:1]), True  # one small kernel instead of ~45 one-element ones
             return self.time_embedding(t[:1]), True
         return self.time_embedding(t), False
 

@@ -60,6 +60,49 @@ class _MLPFunction(torch.autograd.Function):
         return (None, dtemb if need_t else None, None, dWh, dbh, *dW, *db)
 
 
+class _TimeNetFunction(torch.autograd.Function):
+    """t (one device float) -> timenet(PE(t)) as a (1, n_out) row; gradients for the four timenet tensors only."""
+
+    @staticmethod
+    def forward(ctx, t, n_freq, W1, b1, W2, b2):
+        L = _lib.lib()
+        W1, b1, W2, b2 = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
+        t = t.reshape(-1)[:1].contiguous().float()
+        hidden, n_out = W1.shape[0], W2.shape[0]
+        if W1.shape[1] != 2 * n_freq + 1 or W2.shape[1] != hidden:
+            raise RuntimeError("timenet: weight shapes do not match PE(t) / hidden width")
+        save = torch.empty(2 * n_freq + 1 + hidden, dtype=torch.float32, device=t.device)
+        out = torch.empty((1, n_out), dtype=torch.float32, device=t.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        vp = lambda x: ctypes.c_void_p(x.data_ptr())
+        with torch.cuda.device(t.device):
+            _lib.check(L.dgm_timenet_forward(vp(t), n_freq, vp(W1), vp(b1), hidden, vp(W2), vp(b2), n_out, vp(save), vp(out), st))
+        ctx.save_for_backward(save, W1, W2)
+        ctx.n_freq = n_freq
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        L = _lib.lib()
+        save, W1, W2 = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        hidden, n_out = W1.shape[0], W2.shape[0]
+        dW1, db1 = torch.empty_like(W1), torch.empty(hidden, dtype=torch.float32, device=W1.device)
+        dW2, db2 = torch.empty_like(W2), torch.empty(n_out, dtype=torch.float32, device=W1.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        vp = lambda x: ctypes.c_void_p(x.data_ptr())
+        with torch.cuda.device(W1.device):
+            _lib.check(L.dgm_timenet_backward(vp(d_out), ctx.n_freq, vp(W2), hidden, n_out, vp(save), vp(dW1), vp(db1), vp(dW2),
+                                              vp(db2), st))
+        return None, None, dW1, db1, dW2, db2
+
+
+def time_row(net, t_row):
+    """timenet(PE(t)) of the is_blender networks for the single time value in t_row ((1, 1) device tensor)."""
+    lin1, lin2 = net.timenet[0], net.timenet[2]
+    return _TimeNetFunction.apply(t_row, net.t_multires, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+
+
 def network_forward(net, heads, x, t_emb, bcast):
     if not x.is_cuda:
         raise RuntimeError("trunk_impl='hip' needs CUDA/HIP tensors (dg-mesh_amd has no CPU path for its kernels)")

@@ -193,6 +193,16 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
 int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace,
                      float* const* dW, float* const* db, float* dWh, float* dbh, float* dtemb, void* stream);
 
+/* The time branch of the is_blender networks for ONE row (t is identical for every Gaussian of an iteration,
+ * dgmesh/train.py:158): out (n_out) = W2 relu(W1 PE(t) + b1) + b2 with PE(t) = [t, sin(2^k t), cos(2^k t), k < n_freq]
+ * (dgmesh/utils/time_utils.py:24-55, 150-153: timenet = Linear(13, 256), ReLU, Linear(256, 30), n_freq = 6).
+ * t: one device float; W1 (hidden, 2 n_freq + 1), W2 (n_out, hidden) row-major as nn.Linear stores them;
+ * save: 2 n_freq + 1 + hidden floats kept for backward.  backward writes dW1, db1, dW2, db2 (t gets no gradient). */
+int dgm_timenet_forward(const float* t, int n_freq, const float* W1, const float* b1, int hidden, const float* W2,
+                        const float* b2, int n_out, float* save, float* out, void* stream);
+int dgm_timenet_backward(const float* d_out, int n_freq, const float* W2, int hidden, int n_out, const float* save,
+                         float* dW1, float* db1, float* dW2, float* db2, void* stream);
+
 /* ---- fused image loss -------------------------------------------------------------------------------- */
 
 /* loss = (1 - lambda) * mean|image - gt| + lambda * (1 - mean SSIM(image, gt)), the Gaussian-branch image loss of
