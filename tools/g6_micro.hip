@@ -72,6 +72,12 @@ int main(int argc, char** argv) {
     timeit("  8w: no stores", [&] {
         hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8, 4>), dim3(t32 < ncu ? t32 : ncu), dim3(512), 0, 0, M, t32, A, K, K, (const float*)nullptr, 0, Bp, bias, mask, C);
     });
+    timeit("  8w: no C stores", [&] {
+        hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8, 6>), dim3(t32 < ncu ? t32 : ncu), dim3(512), 0, 0, M, t32, A, K, K, (const float*)nullptr, 0, Bp, bias, mask, C, (unsigned long long*)nullptr);
+    });
+    timeit("  8w: no mask stores", [&] {
+        hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8, 7>), dim3(t32 < ncu ? t32 : ncu), dim3(512), 0, 0, M, t32, A, K, K, (const float*)nullptr, 0, Bp, bias, mask, C, (unsigned long long*)nullptr);
+    });
     timeit("  8w: no loads", [&] {
         hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8, 5>), dim3(t32 < ncu ? t32 : ncu), dim3(512), 0, 0, M, t32, A, K, K, (const float*)nullptr, 0, Bp, bias, mask, C);
     });
