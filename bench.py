@@ -174,6 +174,14 @@ def main():
         bwd_ms, bwd_n = stages.get("render_bwd", (0.0, 0))
         alg_bytes = 40.0 * n_inst + 20.0 * W * H + 36.0 * P  # render bwd per frame
         achieved = (alg_bytes / (bwd_ms * 1e-3) / 1e9) if bwd_ms > 0 else 0.0
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_render_bwd2.json), same workload
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_render_bwd2.json")) as fh:
+                pmc = json.load(fh)
+            if pmc.get("workload") == WORKLOAD:
+                traffic = float(pmc["fetch_bytes"]) + float(pmc["write_bytes"])
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "train-step iters/sec (800x800, ~100k Gaussians)", "value": args.steps * world / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,7 +192,7 @@ def main():
                        "P": P, "W": W, "H": H, "num_rendered": n_inst, "visible": R, "mlp_impl": mlp_impl,
                        "parallelism": f"dp{world} (frame-parallel, flat-bucket all-reduce {tr.grad_bytes() / 1e6:.1f} MB)"},
             "roofline": {"kernel": "render_bwd2_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms, "launches": bwd_n},
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
             # host side: time blocked in the rasterizer forward (its R read-back is the step's only sync) vs busy
