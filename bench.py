@@ -32,6 +32,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_FP32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32: 64 cycles/SIMD)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
 WORKLOAD = "cfg2"
 
 
@@ -174,6 +176,9 @@ def main():
         bwd_ms, bwd_n = stages.get("render_bwd", (0.0, 0))
         alg_bytes = 40.0 * n_inst + 20.0 * W * H + 36.0 * P  # render bwd per frame
         achieved = (alg_bytes / (bwd_ms * 1e-3) / 1e9) if bwd_ms > 0 else 0.0
+        gemm_ms, gemm_n = stages.get("mlp_layer_fwd", (0.0, 0))
+        gemm_flops = 2.0 * P * 256 * 256  # 2 * 65536 MAC-flops per row and layer
+        gemm_tf = (gemm_flops / (gemm_ms * 1e-3) / 1e12) if gemm_ms > 0 else 0.0
         traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_render_bwd2.json), same workload
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_render_bwd2.json")) as fh:
@@ -191,9 +196,21 @@ def main():
                                    "(deform + deform_back, is_blender), 1 frame per rank per step",
                        "P": P, "W": W, "H": H, "num_rendered": n_inst, "visible": R, "mlp_impl": mlp_impl,
                        "parallelism": f"dp{world} (frame-parallel, flat-bucket all-reduce {tr.grad_bytes() / 1e6:.1f} MB)"},
-            "roofline": {"kernel": "render_bwd2_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms, "launches": bwd_n},
+            # dominant kernel of the step: the 256 -> 256 trunk-layer GEMM (12 forward + 14 backward-data launches per
+            # step, 1/3 of the GPU time).  Bound: matrix cores; priced against the DENSE fp32 MFMA peak because the
+            # path computes fp32 GEMMs -- its bf16x6 arithmetic (6 bf16 MFMAs per fp32 K step) is also given against
+            # the dense bf16 peak.
+            "roofline": {"kernel": "mlp_gemm6r_kernel<0,16,1,8> (one 256->256 layer forward, N rows)", "bound": "mfma",
+                         "achieved": gemm_tf, "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": gemm_tf / MFMA_FP32_PEAK_TF, "traffic": None,
+                         "algorithmic_flops": gemm_flops, "avg_ms": gemm_ms, "launches": gemm_n,
+                         "bf16_mfma_flops": 6.0 * gemm_flops,
+                         "frac_of_bf16_peak": 6.0 * gemm_tf / MFMA_BF16_PEAK_TF},
+            # the rasterizer's dominant kernel, graded against HBM by BASELINE.json's north_star
+            "roofline_render_bwd": {"kernel": "render_bwd2_kernel", "bound": "hbm", "achieved": achieved,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                    "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms,
+                                    "launches": bwd_n},
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
             # host side: time blocked in the rasterizer forward (its R read-back is the step's only sync) vs busy
             "host_ms_per_step": {"blocked_on_gpu": round(1e3 * RZ.FORWARD_CALL_SECONDS / args.steps, 3),

@@ -105,7 +105,7 @@ def check(status):
         raise RuntimeError(lib().dgm_last_error().decode() or "libdgmesh_hip error")
 
 
-STAGE_COUNT = 8
+STAGE_COUNT = 11
 
 
 def stage_ms():

@@ -153,6 +153,33 @@ struct StageTimer {
     ~StageTimer() { finish(); }
 };
 
+}  // namespace
+
+namespace dgm {
+// deferred-mode stage brackets for translation units without a StageTimer (mlp.hip); no-ops unless mode == 2
+void prof_begin(int s, hipStream_t st) {
+    if (g_profile != 2) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_deferred_n[s] >= kMaxDeferred) return;
+    const int i = g_deferred_n[s];
+    if (i >= g_deferred_created[s]) {
+        (void)hipEventCreate(&g_deferred[s][i].a);
+        (void)hipEventCreate(&g_deferred[s][i].b);
+        g_deferred_created[s] = i + 1;
+    }
+    (void)hipEventRecord(g_deferred[s][i].a, st);
+}
+void prof_end(int s, hipStream_t st) {
+    if (g_profile != 2) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_deferred_n[s] >= kMaxDeferred || g_deferred_n[s] >= g_deferred_created[s]) return;
+    (void)hipEventRecord(g_deferred[s][g_deferred_n[s]].b, st);
+    g_deferred_n[s]++;
+}
+}  // namespace dgm
+
+namespace {
+
 int check_launch(const char* what, bool debug, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
@@ -210,8 +237,9 @@ int dgm_get_stage_ms(float* ms, int capacity) {
     return n;
 }
 const char* dgm_stage_name(int s) {
-    static const char* names[DGM_STAGE_COUNT] = {"preprocess_fwd", "bin_count",  "bin_scan",   "bin_scatter",
-                                                 "tile_sort",      "render_fwd", "render_bwd", "preprocess_bwd"};
+    static const char* names[DGM_STAGE_COUNT] = {"preprocess_fwd", "bin_count",      "bin_scan",      "bin_scatter",
+                                                 "tile_sort",      "render_fwd",     "render_bwd",    "preprocess_bwd",
+                                                 "mlp_layer_fwd",  "mlp_layer_bwd",  "mlp_layer_dw"};
     return (s >= 0 && s < DGM_STAGE_COUNT) ? names[s] : "?";
 }
 

@@ -573,6 +573,8 @@ using namespace dgm;
 
 namespace dgm {
 void set_last_error(const char* msg);  // c_api.hip
+void prof_begin(int stage, hipStream_t st);
+void prof_end(int stage, hipStream_t st);
 }
 namespace {
 int mlp_fail(const char* msg) {
@@ -754,10 +756,12 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             else if (abl == 9 || K1 + K2 == MLP_EMB + MLP_W) G6_FWD(0);  // skip layer: its 22 x 12 weight registers do not fit
             else {
                 const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
-                if (K1 + K2 == MLP_W)
+                if (K1 + K2 == MLP_W) {
+                    dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
                     hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
                                        w.Wt6[l], p->b[l], w.mask[l], w.Y[l], (unsigned long long*)nullptr);
-                else
+                    dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
+                } else
                     hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 6, 2, 4>), dim3(gx), dim3(256), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
                                        w.Wt6[l], p->b[l], w.mask[l], w.Y[l], (unsigned long long*)nullptr);
             }
@@ -831,10 +835,12 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                                layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
         } else {
             const DwPlan d = dw6_plan(N, Kp);
-            if (Kp == MLP_W)
+            if (Kp == MLP_W) {
+                dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
                 hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial,
                                    w.partial_db);
-            else
+                dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
+            } else
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
                                    K2, G, w.partial, w.partial_db);
             const int per_group = (d.chunks + DW_GROUPS - 1) / DW_GROUPS;
@@ -855,9 +861,11 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                                    (const float*)nullptr, 0, 0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
             else {
                 const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
+                dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
                 hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
                                    (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn,
                                    (unsigned long long*)nullptr);
+                dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
             }
             float* t = G;
             G = Gn;
