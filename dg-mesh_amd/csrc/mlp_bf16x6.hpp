@@ -682,12 +682,21 @@ mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
 
+    // The staging waves (0..3) split and store stage st+1 BEFORE their MFMAs of stage st: each shares its SIMD with a
+    // pure MFMA wave (4..7), so the VALU/LDS work of one overlaps the matrix work of the other instead of both waves
+    // multiplying first and the partner idling at the barrier while the stager splits.  Data for stage st+1 was
+    // requested a whole stage earlier (registers v[] are refilled for st+2 right after the store).
     DWB_LOAD(0)
     DWB_STORE(0)
+    if (nst > 1) DWB_LOAD(1)
     __syncthreads();
     for (int st = 0; st < nst; st++) {
         const int buf = st & 1;
-        if (st + 1 < nst) DWB_LOAD(st + 1)
+        if (st + 1 < nst) {
+            DWB_STORE(buf ^ 1)
+            if (st + 2 < nst) DWB_LOAD(st + 2)
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const uint4* xs = Xs[buf];
         const uint4* gs = Gs[buf];
         bf16x8 ah[2], am[2], al[2];
@@ -705,7 +714,6 @@ mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
                 DGM_MFMA6(acc[mt][nt], ah[mt], am[mt], al[mt], bh, bm, bl)
             }
         }
-        if (st + 1 < nst) DWB_STORE(buf ^ 1)
         __syncthreads();
     }
 #undef DWB_LOAD
