@@ -55,6 +55,11 @@ SYMBOLS = {
     "dgm_image_loss_workspace_bytes": (_c.c_size_t, [_i, _i, _i]),
     "dgm_image_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "dgm_image_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "dgm_gaussian_apply_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dgm_gaussian_apply_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dgm_cycle_loss_workspace_bytes": (_c.c_size_t, [_i]),
+    "dgm_cycle_loss_forward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dgm_cycle_loss_backward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dgm_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp]),
     "dgm_mlp_set_gemm": (_i, [_i]),
     "dgm_timenet_forward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

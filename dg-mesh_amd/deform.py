@@ -234,6 +234,14 @@ class _ModelWrapper:
     def step(self, xyz, time_emb):
         return self.net(xyz, time_emb)
 
+    def step_raw(self, xyz, time_emb):
+        """The network's raw (N, n_out) head output [d_xyz | d_rotation | d_scaling | ...] without slicing it (the fused
+        glue kernels of glue.py take it whole); None when the network has no such layout (is_6dof, other classes)."""
+        net = self.net
+        if isinstance(net, DeformNetwork) and not net.is_6dof:
+            return net.heads_out(xyz, time_emb)
+        return None
+
     def train_setting(self, training_args):
         lr0 = training_args.position_lr_init * self.spatial_lr_scale
         self.optimizer = torch.optim.Adam([{"params": list(self.net.parameters()), "lr": lr0, "name": self.model_name}],

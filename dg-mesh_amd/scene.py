@@ -185,9 +185,11 @@ class OptimizationParams:
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, is_6dof=False, scaling_modifier=1.0,
-           override_color=None):
+           override_color=None, delta=None):
     """R/gaussian_renderer/__init__.py:32-119.  viewpoint_camera needs FoVx, FoVy, image_height, image_width,
-    world_view_transform, full_proj_transform, camera_center (torch tensors on the GPU)."""
+    world_view_transform, full_proj_transform, camera_center (torch tensors on the GPU).
+    delta: optionally the deformation network's raw (P, >= 10) output [d_xyz | d_rotation | d_scaling | ...] instead of
+    the three slices; activations + deformation then run as one fused kernel (glue.gaussian_apply)."""
     screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
                                           device=pc.get_xyz.device) + 0
     try:
@@ -202,7 +204,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, i
         viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
         sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-    if is_6dof:
+    fused = delta is not None and not is_6dof
+    if fused:
+        from .glue import gaussian_apply
+        means3D, scales, rotations, opacity = gaussian_apply(pc._xyz, pc._scaling, pc._rotation, pc._opacity, delta)
+    elif is_6dof:
         if torch.is_tensor(d_xyz) is False:
             means3D = pc.get_xyz
         else:
@@ -212,9 +218,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, i
     else:
         means3D = pc.get_xyz + d_xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
-    scales = pc.get_scaling + d_scaling
-    rotations = pc.get_rotation + d_rotation
+    if not fused:
+        opacity = pc.get_opacity
+        scales = pc.get_scaling + d_scaling
+        rotations = pc.get_rotation + d_rotation
     shs = None
     colors_precomp = override_color
     if colors_precomp is None:
@@ -222,7 +229,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, i
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
                                        opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "radii": radii}
+            "radii": radii, "means3D": means3D}
 
 
 def l1_loss(network_output, gt):

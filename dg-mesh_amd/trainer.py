@@ -80,7 +80,7 @@ def frame_schedule(n_frames, step, rank, world, seed=0):
 class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
-                 process_group=None, fused_loss=True):
+                 process_group=None, fused_loss=True, fused_glue=None):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
         self.cameras = cameras
         self.opt = opt or S.OptimizationParams()
@@ -92,6 +92,9 @@ class Trainer:
         self.group = process_group
         self.fused_loss = fused_loss
         self.step_count = 0
+        # fused per-Gaussian glue (activations + deformation, cycle loss): GPU, stock render(), plain (non-6dof) networks
+        self.fused_glue = bool(fused_glue) if fused_glue is not None else (
+            gaussians.get_xyz.is_cuda and render_fn is None and not is_6dof)
         dev = gaussians.get_xyz.device
         fused = (dev.type == "cuda") if fused_adam is None else fused_adam
         gaussians.training_setup(self.opt)
@@ -119,20 +122,30 @@ class Trainer:
 
     def loss_terms(self, cam, iteration):
         g, opt = self.g, self.opt
+        delta = None
         if iteration < opt.warm_up:
             d_xyz, d_rotation, d_scaling = 0.0, 0.0, 0.0
         else:
             N = g.get_xyz.shape[0]
             time_input = cam.fid.unsqueeze(0).expand(N, -1)
-            d_xyz, d_rotation, d_scaling = self.deform.step(g.get_xyz.detach(), time_input)[:3]
-        pkg = self.render_fn(cam, g, self.pipe, self.bg, d_xyz, d_rotation, d_scaling, self.is_6dof)
-        image = pkg["render"]
+            if self.fused_glue:  # raw (N, 13) head output straight into the fused glue kernels (glue.py)
+                delta = self.deform.step_raw(g.get_xyz.detach(), time_input)
+            if delta is None:
+                d_xyz, d_rotation, d_scaling = self.deform.step(g.get_xyz.detach(), time_input)[:3]
         losses = {}
-        if iteration >= opt.warm_up:
-            deformed_xyz = g.get_xyz + d_xyz
-            back = self.deform_back.step(deformed_xyz.detach(), time_input)
-            cycle = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rotation) + S.l1_loss(-back[2], d_scaling)) / 3.0
-            losses["cycle_loss"] = cycle
+        if delta is not None:
+            pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta)
+            back = self.deform_back.step_raw(pkg["means3D"].detach(), time_input)
+            from .glue import cycle_loss
+            losses["cycle_loss"] = cycle_loss(delta, back)
+        else:
+            pkg = self.render_fn(cam, g, self.pipe, self.bg, d_xyz, d_rotation, d_scaling, self.is_6dof)
+            if iteration >= opt.warm_up:
+                deformed_xyz = g.get_xyz + d_xyz
+                back = self.deform_back.step(deformed_xyz.detach(), time_input)
+                cycle = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rotation) + S.l1_loss(-back[2], d_scaling)) / 3.0
+                losses["cycle_loss"] = cycle
+        image = pkg["render"]
         gt = cam.original_image
         if image.is_cuda and self.fused_loss:  # same value, two HIP kernels instead of 5 convs + autograd
             from .loss import image_loss

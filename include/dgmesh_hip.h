@@ -219,6 +219,29 @@ int dgm_image_loss_forward(const float* image, const float* gt, int channels, in
 int dgm_image_loss_backward(const float* image, const float* gt, int channels, int H, int W, float lambda_dssim,
                             const char* workspace, const float* grad_out, float* d_image, void* stream);
 
+/* ---- per-Gaussian glue of the train step ------------------------------------------------------------------ */
+
+/* Activations + deformation in front of the rasterizer (dgmesh/gaussian_renderer/__init__.py:77-95 with the accessors
+ * of dgmesh/scene/gaussian_model_dpsr_dynamic_anchor.py:92-128):  means3D = xyz + d_xyz, scales = exp(scaling) +
+ * d_scaling, rotations = normalize(rotation) + d_rotation, opacities = sigmoid(opacity).  delta: raw (P, ld) head
+ * output of the deformation network, columns [d_xyz 0:3 | d_rotation 3:7 | d_scaling 7:10 | ...], ld >= 10.
+ * backward: given the rasterizer's gradients writes the parameter gradients and d_delta (P, ld; columns >= 10 zero). */
+int dgm_gaussian_apply_forward(int P, const float* xyz, const float* scaling, const float* rotation, const float* opacity,
+                               const float* delta, int ld, float* means3D, float* scales, float* rotations,
+                               float* opacities, void* stream);
+int dgm_gaussian_apply_backward(int P, const float* scaling, const float* rotation, const float* opacity,
+                                const float* g_means3D, const float* g_scales, const float* g_rotations,
+                                const float* g_opacities, float* d_xyz, float* d_scaling, float* d_rotation,
+                                float* d_opacity, float* d_delta, int ld, void* stream);
+
+/* Cycle-consistency loss of dgmesh/train.py:221-238 on the raw (N, ld) outputs a (deform) and b (deform_back):
+ * out[0] = (mean|b_xyz + a_xyz| + mean|b_rot + a_rot| + mean|b_scale + a_scale|) / 3, out[1..3] the three terms.
+ * Fixed-order two-level reduction.  backward: grad_out = device scalar; d_a, d_b (N, ld) fully written. */
+size_t dgm_cycle_loss_workspace_bytes(int N);
+int dgm_cycle_loss_forward(int N, const float* a, const float* b, int ld, char* workspace, float* out, void* stream);
+int dgm_cycle_loss_backward(int N, const float* a, const float* b, int ld, const float* grad_out, float* d_a, float* d_b,
+                            void* stream);
+
 /* ---- optimizer ---------------------------------------------------------------------------------------- */
 
 /* torch.optim.Adam (amsgrad=False, weight_decay=0) over n_tensors tensors in ONE kernel launch: the Adam steps that

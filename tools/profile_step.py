@@ -16,5 +16,5 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for i in range(3):
         tr.step(it0 + 5 + i)
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=45, max_shapes_column_width=60))
-print(prof.key_averages().table(sort_by="count", row_limit=30, max_name_column_width=50))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=220, max_name_column_width=45, max_shapes_column_width=60))
+print(prof.key_averages().table(sort_by="count", row_limit=80, max_name_column_width=50))
