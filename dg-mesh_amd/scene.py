@@ -67,6 +67,12 @@ class GaussianModel:
     def get_opacity(self):
         return self.opacity_activation(self._opacity)
 
+    def get_covariance(self, scaling_modifier=1):
+        """(P, 6) upper triangle [xx, xy, xz, yy, yz, zz] of R S S^T R^T with S = diag(scaling_modifier * get_scaling) and
+        R from the (re-normalised) raw quaternion (gaussian_model_dpsr_dynamic_anchor.py:148-149 through
+        general_utils.py:130-170)."""
+        return covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
+
     @property
     def get_normal(self):
         return self._normal
@@ -184,6 +190,51 @@ class OptimizationParams:
     lambda_dssim = 0.2
 
 
+def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    """Sigma = (R S)(R S)^T as its six upper-triangle entries; rotation is normalised here (w, x, y, z)."""
+    q = rotation / rotation.norm(dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+    L = R * (scaling_modifier * scaling).unsqueeze(1)          # R @ diag(s): scales the columns
+    cov = L @ L.transpose(1, 2)
+    return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=-1)
+
+
+_SH_C0 = 0.28209479177387814
+_SH_C1 = 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435)
+
+
+def sh_basis(deg, dirs):
+    """(..., (deg+1)^2) real spherical-harmonics basis at unit directions, in the coefficient order and sign convention of
+    the rasterizer's computeColorFromSH (forward.cu:20-71) and of R/utils/sh_utils.py:57-112."""
+    if not 0 <= deg <= 3:
+        raise ValueError("sh_basis: degrees 0..3 (the Gaussian model never exceeds max_sh_degree = 3)")
+    x, y, z = dirs[..., 0], dirs[..., 1], dirs[..., 2]
+    b = [torch.full_like(x, _SH_C0)]
+    if deg > 0:
+        b += [-_SH_C1 * y, _SH_C1 * z, -_SH_C1 * x]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        b += [_SH_C2[0] * xy, _SH_C2[1] * yz, _SH_C2[2] * (2.0 * zz - xx - yy), _SH_C2[3] * xz, _SH_C2[4] * (xx - yy)]
+    if deg > 2:
+        b += [_SH_C3[0] * y * (3 * xx - yy), _SH_C3[1] * xy * z, _SH_C3[2] * y * (4 * zz - xx - yy),
+              _SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy), _SH_C3[4] * x * (4 * zz - xx - yy), _SH_C3[5] * z * (xx - yy),
+              _SH_C3[6] * x * (xx - 3 * yy)]
+    return torch.stack(b, dim=-1)
+
+
+def eval_sh(deg, sh, dirs):
+    """sh (..., C, >= (deg+1)^2), dirs (..., 3) unit vectors -> (..., C): the Python SH path of the reference's render()
+    (pipe.convert_SHs_python, R/gaussian_renderer/__init__.py:95-100)."""
+    n = (deg + 1) ** 2
+    return (sh[..., :n] * sh_basis(deg, dirs).unsqueeze(-2)).sum(-1)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, is_6dof=False, scaling_modifier=1.0,
            override_color=None, delta=None):
     """R/gaussian_renderer/__init__.py:32-119.  viewpoint_camera needs FoVx, FoVy, image_height, image_width,
@@ -218,16 +269,24 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, i
     else:
         means3D = pc.get_xyz + d_xyz
     means2D = screenspace_points
+    cov3D_precomp = None
     if not fused:
         opacity = pc.get_opacity
         scales = pc.get_scaling + d_scaling
         rotations = pc.get_rotation + d_rotation
+    if getattr(pipe, "compute_cov3D_python", False):  # as in the reference: canonical covariance, deltas not applied
+        cov3D_precomp, scales, rotations = pc.get_covariance(scaling_modifier), None, None
     shs = None
     colors_precomp = override_color
     if colors_precomp is None:
-        shs = pc.get_features
+        if getattr(pipe, "convert_SHs_python", False):  # as in the reference: view directions from the CANONICAL xyz
+            shs_view = pc.get_features.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.reshape(1, 3)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "means3D": means3D}
 
