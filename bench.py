@@ -90,6 +90,11 @@ def cpu_baseline(P, W, H, max_threads=32):
     gt = torch.tensor(syn.gt_image(W, H, 0))
     torch.manual_seed(0)
     nets = [D.DeformNetworkNormal(is_blender=True, trunk_impl="torch") for _ in range(2)]
+    with torch.no_grad():  # same small-deformation heads as the GPU workload (build_scene), so R is comparable
+        for m in nets:
+            for head in (m.gaussian_warp, m.gaussian_rotation, m.gaussian_scaling, m.gaussian_normal):
+                head.weight.mul_(0.01)
+                head.bias.mul_(0.01)
     params = [p for n in nets for p in n.parameters()]
     opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15)
     xyz = torch.tensor(g["xyz"])
