@@ -85,7 +85,8 @@ def cpu_baseline(P, W, H, max_threads=32):
     cores = min(os.cpu_count() or 1, max_threads)
     orc.set_threads(cores)
     torch.set_num_threads(cores)
-    g = syn.make_gaussians(P, seed=0, dist2=np.full(P, 4e-4, np.float32))
+    xyz0 = ((np.random.RandomState(0).rand(P, 3) * 2 - 1) * 1.3).astype(np.float32)  # the points build_scene() draws
+    g = syn.make_gaussians(P, seed=0, dist2=orc.knn(xyz0))  # same initialisation as create_from_pcd (simple-knn scales)
     cam = syn.config_camera(WORKLOAD, frame=0)
     gt = torch.tensor(syn.gt_image(W, H, 0))
     torch.manual_seed(0)
