@@ -626,8 +626,9 @@ mlp_dw6_kernel(int M, int rows_per_chunk, const float* __restrict__ X1, int ldx1
 }
 
 // Weight gradient of the K = 256 layers, one 8-wave workgroup per CU covering ALL 256 K columns of a chunk of rows
-// (waves 4 x 2, wave tile 64 x 128): G is split and transposed once instead of once per 128-column slab, the staging
-// work per MFMA halves, and every SIMD hosts exactly one staging wave (threads 0..255) and one pure MFMA wave.
+// (waves 4 x 2, wave tile 64 x 128): G is split and transposed once instead of once per 128-column slab.  EVERY
+// thread stages: threads 0..255 the X block of a 16-row stage, 256..511 the G block, each an 8-row x 2-column piece
+// (eight float2 loads, six 16-byte LDS writes), so the split work is spread evenly over the eight waves.
 __global__ void __launch_bounds__(512)
 mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx, const float* __restrict__ G,
                 float* __restrict__ partial, float* __restrict__ partial_db) {
@@ -638,39 +639,33 @@ mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
     const int chunk = blockIdx.x;
     const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     const int nst = (r1 - r0 + 15) >> 4;
-    // staging role: threads 0..127 -> X blocks (2 row halves x 64 column quads), 128..255 -> G blocks
-    const bool stager = tid < 256, isG = tid >= 128;
-    const int rg = (tid >> 6) & 1, c4 = tid & 63;
-    const float* sp = isG ? (G + c4 * 4) : (X + c4 * 4);
+    // staging role: (row half rg, column pair c2) of X (threads 0..255) or G (256..511)
+    const bool isG = tid >= 256;
+    const int rg = (tid >> 7) & 1, c2 = tid & 127;
+    const float* sp = isG ? (G + c2 * 2) : (X + c2 * 2);
     const int sld = isG ? 256 : ldx;
-    uint4* sdst0 = (isG ? &Gs[0][0] : &Xs[0][0]) + rg * 256 + c4 * 4;
-    float4 v[8];
-    float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4* sdst0 = (isG ? &Gs[0][0] : &Xs[0][0]) + rg * 256 + c2 * 2;
+    float2 v[8];
+    float2 colsum = make_float2(0.f, 0.f);
 
 #define DWB_LOAD(st_)                                                                                 \
-    if (stager) {                                                                                     \
+    {                                                                                                 \
         const int rb_ = r0 + (st_) * 16 + rg * 8;                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                            \
-            v[i_] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
-            if (rb_ + i_ < r1) v[i_] = *reinterpret_cast<const float4*>(sp + (size_t)(rb_ + i_) * sld); \
+            v[i_] = make_float2(0.f, 0.f);                                                            \
+            if (rb_ + i_ < r1) v[i_] = *reinterpret_cast<const float2*>(sp + (size_t)(rb_ + i_) * sld); \
         }                                                                                             \
     }
 #define DWB_STORE(buf_)                                                                               \
-    if (stager) {                                                                                     \
+    {                                                                                                 \
         uint4* d_ = sdst0 + (buf_) * DW6_GU;                                                          \
         uint4 H_, M_, L_;                                                                             \
         split8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, H_, M_, L_);           \
         d_[0] = H_, d_[512] = M_, d_[1024] = L_;                                                      \
         split8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, H_, M_, L_);           \
         d_[1] = H_, d_[513] = M_, d_[1025] = L_;                                                      \
-        split8(v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z, H_, M_, L_);           \
-        d_[2] = H_, d_[514] = M_, d_[1026] = L_;                                                      \
-        split8(v[0].w, v[1].w, v[2].w, v[3].w, v[4].w, v[5].w, v[6].w, v[7].w, H_, M_, L_);           \
-        d_[3] = H_, d_[515] = M_, d_[1027] = L_;                                                      \
         if (isG) {                                                                                    \
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                        \
-                colsum.x += v[i_].x, colsum.y += v[i_].y, colsum.z += v[i_].z, colsum.w += v[i_].w;   \
-            }                                                                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) colsum.x += v[i_].x, colsum.y += v[i_].y; \
         }                                                                                             \
     }
 
@@ -682,10 +677,8 @@ mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
 
-    // The staging waves (0..3) split and store stage st+1 BEFORE their MFMAs of stage st: each shares its SIMD with a
-    // pure MFMA wave (4..7), so the VALU/LDS work of one overlaps the matrix work of the other instead of both waves
-    // multiplying first and the partner idling at the barrier while the stager splits.  Data for stage st+1 was
-    // requested a whole stage earlier (registers v[] are refilled for st+2 right after the store).
+    // stage st+1 is split and stored at the top of step st (its data was requested a whole step earlier), then the
+    // registers are refilled for st+2
     DWB_LOAD(0)
     DWB_STORE(0)
     if (nst > 1) DWB_LOAD(1)
@@ -731,8 +724,8 @@ mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
                 out[(size_t)k * 256 + col] = acc[mt][nt][r];
             }
         }
-    if (stager && isG && partial_db != nullptr)
-        *reinterpret_cast<float4*>(partial_db + ((size_t)chunk * 2 + rg) * 256 + c4 * 4) = colsum;
+    if (isG && partial_db != nullptr)
+        *reinterpret_cast<float2*>(partial_db + ((size_t)chunk * 2 + rg) * 256 + c2 * 2) = colsum;
 }
 
 // first reduction level of the dW partials: part2[grp][k][j] = sum of the chunks of group grp (fixed order); the
