@@ -426,7 +426,8 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
                     float v = acc[nt][r];                                                                              \
                     if (EPI == 0) {                                                                                    \
                         v = fmaxf(v + bv[nt], 0.f);                                                                    \
-                        mw[nt] = (unsigned)(__ballot(v > 0.f) >> (g * 32));                                            \
+                        const unsigned long long bal_ = __ballot(v > 0.f);                                             \
+                        mw[nt] = g ? (unsigned)(bal_ >> 32) : (unsigned)bal_;  /* select, not a 64-bit VALU shift */   \
                     } else {                                                                                           \
                         v = ((mws[r - rb][nt] >> li) & 1u) ? v : 0.f;                                                  \
                     }                                                                                                  \
