@@ -1,24 +1,23 @@
-// Deformation / appearance MLP trunk for gfx950 on the fp32 matrix cores.
+// Deformation / appearance MLP trunk for gfx950.
 //
 // Replaces the nn.Linear + F.relu chain of DeformNetwork* / AppearanceNetwork (R/utils/time_utils.py:104-129,
 // 178-204, 252-266, 310-323): positional encoding of x, 8 x 256 ReLU layers with the skip re-injection of
-// [PE(x), t_emb] before layer 5, linear heads -- forward and backward (dX, dW, db, dt_emb).
+// [PE(x), t_emb] before layer 5, linear heads -- forward and backward (dX, dW, db, dt_emb) -- plus the single-row
+// time branch timenet(PE(t)).
 //
-// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: bitwise a k-ordered fmaf chain), so results
-// match an fp32 reference to rounding; no reduced precision anywhere.
-//
-// MI355X design:
-//  * one GEMM kernel shape for every 256-wide layer: 128 x 256 output tile per 512-thread workgroup, 8 waves
-//    as 2 (rows) x 4 (cols), each wave 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs); K is consumed in
-//    16-deep stages that are register-staged global -> LDS with one barrier per stage (loads of stage s+1 are
-//    in flight while stage s is multiplied); A is stored k-major in LDS with row stride 130 (130 = 2 mod 8 makes
-//    both the transposing ds_write_b32 and the fragment ds_read_b32 conflict free), B rows are 256 floats;
+// Two arithmetics for the 256-wide GEMMs, selected by dgm_mlp_set_gemm() / DGM_MLP_GEMM:
+//  * bf16x6 (default, mlp_bf16x6.hpp): fp32 operands split exactly into three bf16 numbers, six partial products per
+//    fp32 product on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- an fp32 GEMM to rounding at 2.7x the MFMA
+//    rate of the fp32 instruction;
+//  * f32 (this file): v_mfma_f32_32x32x2_f32; 64 x 128 output tile per 256-thread workgroup, K consumed in 16-deep
+//    register-staged global -> LDS stages (A k-major with row pitch 66 = 2 mod 8: conflict-free transposing stores and
+//    fragment reads), dW as row-chunk x 128-column-slab partial tiles.
+// Common to both:
 //  * the skip layer reads its input as TWO K-segments ([emb | h4]) -- the concatenation is never materialised;
-//  * bias + ReLU are the forward epilogue; the backward-data epilogue multiplies by the ReLU mask of the layer
-//    BELOW, so each backward GEMM directly emits the next layer's pre-masked gradient;
-//  * weight gradients reduce over the 100k rows: row chunks of 512 x 128-wide K slabs per workgroup write
-//    partial [Kp x 256] tiles that a second kernel sums in fixed order (deterministic, no atomics); bias
-//    gradients ride along as column sums of the same G tiles;
+//  * bias + ReLU are the forward epilogue, which also saves the ReLU mask as bits; the backward-data epilogue applies
+//    the mask of the layer BELOW, so each backward GEMM directly emits the next layer's pre-masked gradient;
+//  * weight gradients reduce over the rows in fixed order (partials + ordered reduction: deterministic, no atomics);
+//    bias gradients ride along as column sums of the same G tiles;
 //  * t is the same for every row in training, so dL/dt_emb = db . W[:, t-columns] (no per-row GEMM); the general
 //    per-row case has its own small kernel.
 #include <stdlib.h>
