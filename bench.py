@@ -149,11 +149,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    # test aid for one-GPU boxes: DGM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and exchanges over gloo, which
+    # exercises the whole multi-rank code path (the measured configuration is one rank per GPU over RCCL)
+    share_gpu = os.environ.get("DGM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     L = importlib.import_module("dg-mesh_amd._lib")
     mlp_impl = args.mlp
     if mlp_impl == "auto":
