@@ -170,7 +170,7 @@ def main():
     tr, (P, W, H) = build_scene(dev, rank, world, mlp_impl)
     it0 = tr.opt.warm_up + 2000  # "deformation MLP on" phase (warm_up <= it < dpsr_iter)
 
-    for i in range(3):  # allocator / code-object priming (untimed, not part of the W warm-up steps requested below)
+    for i in range(10):  # allocator / code-object / clock priming (untimed, not part of the W warm-up steps requested below)
         tr.step(it0)
     for i in range(args.warmup):
         tr.step(it0 + i)
