@@ -41,9 +41,6 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* r
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
                        unsigned* n_contrib);
-void launch_render_bwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
-                       int gridx, const float* bg, const float* rec, const float* final_T, const unsigned* n_contrib,
-                       const float* dL_dpix, float* slab, unsigned* nproc);
 void launch_render_bwd2(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float* final_T, const unsigned* n_contrib,
                         const float* dL_dpix, float* slab, unsigned* nproc);
@@ -434,13 +431,8 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
 
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
-    static const bool bwd_v1 = getenv("DGM_RENDER_BWD_V1") != nullptr;  // A/B aid: first-generation kernel
-    if (bwd_v1)
-        launch_render_bwd(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib,
-                          dL_dpix, slab, nproc);
-    else
-        launch_render_bwd2(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib,
-                           dL_dpix, slab, nproc);
+    launch_render_bwd2(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib,
+                       dL_dpix, slab, nproc);
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);
 

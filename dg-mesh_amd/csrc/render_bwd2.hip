@@ -1,8 +1,7 @@
 // render_bwd, second generation: TWO pixels per lane.
 //
-// Same contract as render_bwd_kernel in render.hip (replays BACKWARD::render / renderCUDA<3>,
-// DGR/cuda_rasterizer/backward.cu:401-557, and writes one 48-byte gradient row per (tile, splat) instance into the
-// slab), different mapping of the 16x16 tile onto the machine:
+// Replays BACKWARD::render / renderCUDA<3> (DGR/cuda_rasterizer/backward.cu:401-557) and writes one 48-byte gradient
+// row per (tile, splat) instance into the slab; mapping of the 16x16 tile onto the machine:
 //   * 128-thread workgroup = 2 waves; wave w owns the 16 x 8 half tile of rows [8w, 8w+8); lane l owns the two pixels
 //     (col = l & 15, row = 8w + (l >> 4)) and (col, row + 4): same column, so dx and a*dx*dx are shared;
 //   * the per-pixel arithmetic is written on 2-vectors and compiles to v_pk_{mul,add,fma}_f32 -- the packed fp32 ops

@@ -35,35 +35,6 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float a, flo
     return m;
 }
 
-// In-place wave64 inclusive-scan-style reduction of nine values with DPP adds: after the block lane 63 of
-// every register holds the wave total.  Nine independent chains are interleaved, so the >= 2 wait states a
-// DPP read needs after a VALU write of the same VGPR are always covered by the eight other instructions.
-__device__ __forceinline__ void wave_reduce9(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
-                                             float& v6, float& v7, float& v8) {
-#define DGM_DPP_STEP(ctrl)                    \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"  \
-    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"  \
-    "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"  \
-    "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"  \
-    "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"  \
-    "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"  \
-    "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"  \
-    "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"  \
-    "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"
-    asm volatile(
-        "s_nop 1\n\t"
-        DGM_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        DGM_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        DGM_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-        "s_nop 1"
-        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
-#undef DGM_DPP_STEP
-}
-
-
 // Transposed butterfly reduction of EIGHT values over the 64 lanes of a wave: on return every lane l holds the wave
 // total of value number (l & 7).  Each xor-exchange stage keeps, per pair of values, the one selected by the lane's
 // bit and ships the other to the partner lane, so the number of live values halves per stage:
