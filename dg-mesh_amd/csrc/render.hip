@@ -1,27 +1,21 @@
-// Tile alpha-compositing for gfx950: forward blend and its backward replay.
+// Tile alpha-compositing for gfx950: the forward blend (the backward replay lives in render_bwd2.hip).
 //
-// Replaces FORWARD::render / renderCUDA<3> (DGR/cuda_rasterizer/forward.cu:263-374) and BACKWARD::render /
-// renderCUDA<3> (DGR/cuda_rasterizer/backward.cu:401-557).  Same tile size (16x16), same per-pixel
-// arithmetic (power, alpha = min(.99, o*exp(power)), 1/255 and 1e-4 thresholds, n_contrib / final_T
-// semantics), so `out_color`, `final_T`, `n_contrib` and all gradients agree with the reference to
-// rounding (tests: 1e-4; integer n_contrib exact away from the thresholds).
+// Replaces FORWARD::render / renderCUDA<3> (DGR/cuda_rasterizer/forward.cu:263-374).  Same tile size (16x16), same
+// per-pixel arithmetic (power, alpha = min(.99, o*exp(power)), 1/255 and 1e-4 thresholds, n_contrib / final_T
+// semantics), so `out_color`, `final_T`, `n_contrib` agree with the reference to rounding (tests: 1e-4; integer
+// n_contrib exact away from the thresholds).
 //
 // MI355X design:
 //  * one 256-thread workgroup per tile = 4 wave64, and each WAVE owns an 8x8 pixel quadrant (not 4 rows of
-//    16): the 64 lanes of a wave are spatially compact, which makes wave-uniform decisions effective;
+//    16): the 64 lanes of a wave are spatially compact, which makes wave-uniform decisions (early exit, culling)
+//    effective;
 //  * splats are staged 256 at a time into LDS from ONE 48-byte record per Gaussian (3 x 16 B gathers);
 //  * while staging, each thread computes the exact screen-space bounding box of "alpha >= 1/255" for its
 //    splat (half-extent sqrt(2 ln(255 o) * Sigma_xx|yy)) and tests it against the four quadrants; four
 //    wave ballots turn that into one 64-bit mask per (staging wave, quadrant).  The blend loop of a wave is a
 //    SCALAR loop over the set bits of its masks (s_ff1 / s_andn2), so pairs that the reference would discard
 //    with `alpha < 1/255` after evaluating exp() are never issued.  The test is conservative (inflated box;
-//    NaN => keep), hence results are unchanged;
-//  * backward: no global atomics.  The 9 partial gradients of a (pixel, splat) pair are summed across the
-//    wave with DPP row_shr / row_bcast adds (no LDS traffic), the 4 waves combine through ds_add_f32 into a
-//    per-batch LDS accumulator, and each (tile, splat) instance writes ONE 48-byte row into a slab indexed by
-//    its slot in the tile list (coalesced).  A later per-Gaussian kernel gathers its rows through the
-//    inverse map, which also makes the gradient summation order deterministic (the reference's is not);
-//  * backward replays only the first max(n_contrib) instances of the tile instead of the whole list.
+//    NaN => keep), hence results are unchanged.
 #include <stdlib.h>
 
 #include "dgm_common.hpp"
