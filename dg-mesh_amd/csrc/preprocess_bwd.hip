@@ -78,27 +78,45 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
             unsigned xmin, ymin, w;
             unpack_rect(__float_as_uint(r2.y), xmin, ymin, w);
             const unsigned n = tiles_touched[idx], o = offs[idx];
+            // Instances are visited in tile order (fixed summation order), four at a time so that the three dependent
+            // loads of each (slot -> tile bookkeeping -> 48-byte row) overlap across instances instead of serialising.
             unsigned x = 0, y = 0;
-            for (unsigned k = 0; k < n; k++) {
-                const unsigned slot = inv[o + k];
-                const unsigned tile = (ymin + y) * (unsigned)gridx + xmin + x;
-                if (++x == w) {
-                    x = 0;
-                    y++;
+            for (unsigned k0 = 0; k0 < n; k0 += 4) {
+                unsigned slot[4], tile[4];
+                bool use[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool in = k0 + j < n;
+                    slot[j] = in ? inv[o + k0 + j] : 0u;
+                    tile[j] = in ? (ymin + y) * (unsigned)gridx + xmin + x : 0u;
+                    use[j] = in;
+                    if (in && ++x == w) {
+                        x = 0;
+                        y++;
+                    }
                 }
-                if (slot - ranges[tile].x < nproc[tile]) {
-                    const float4* row = reinterpret_cast<const float4*>(slab + (size_t)slot * DGM_SLAB_STRIDE);
-                    const float4 a = row[0], b = row[1];
-                    const float c = row[2].x;
-                    acc[0] += a.x;
-                    acc[1] += a.y;
-                    acc[2] += a.z;
-                    acc[3] += a.w;
-                    acc[4] += b.x;
-                    acc[5] += b.y;
-                    acc[6] += b.z;
-                    acc[7] += b.w;
-                    acc[8] += c;
+#pragma unroll
+                for (int j = 0; j < 4; j++) use[j] = use[j] && (slot[j] - ranges[tile[j]].x < nproc[tile[j]]);
+                float4 ra[4], rb[4];
+                float rc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float4* row = reinterpret_cast<const float4*>(slab + (size_t)(use[j] ? slot[j] : slot[0]) * DGM_SLAB_STRIDE);
+                    ra[j] = row[0], rb[j] = row[1], rc[j] = row[2].x;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (use[j]) {
+                        acc[0] += ra[j].x;
+                        acc[1] += ra[j].y;
+                        acc[2] += ra[j].z;
+                        acc[3] += ra[j].w;
+                        acc[4] += rb[j].x;
+                        acc[5] += rb[j].y;
+                        acc[6] += rb[j].z;
+                        acc[7] += rb[j].w;
+                        acc[8] += rc[j];
+                    }
                 }
             }
         }
