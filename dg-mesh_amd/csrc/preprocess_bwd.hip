@@ -78,14 +78,14 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
             unsigned xmin, ymin, w;
             unpack_rect(__float_as_uint(r2.y), xmin, ymin, w);
             const unsigned n = tiles_touched[idx], o = offs[idx];
-            // Instances are visited in tile order (fixed summation order), four at a time so that the three dependent
-            // loads of each (slot -> tile bookkeeping -> 48-byte row) overlap across instances instead of serialising.
+            // Instances are visited in tile order (fixed summation order), eight at a time so that the three dependent
+            // loads of each (slot -> tile bookkeeping -> 48-byte row) overlap across instances instead of serialising (eight in flight).
             unsigned x = 0, y = 0;
-            for (unsigned k0 = 0; k0 < n; k0 += 4) {
-                unsigned slot[4], tile[4];
-                bool use[4];
+            for (unsigned k0 = 0; k0 < n; k0 += 8) {
+                unsigned slot[8], tile[8];
+                bool use[8];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < 8; j++) {
                     const bool in = k0 + j < n;
                     slot[j] = in ? inv[o + k0 + j] : 0u;
                     tile[j] = in ? (ymin + y) * (unsigned)gridx + xmin + x : 0u;
@@ -96,16 +96,16 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) use[j] = use[j] && (slot[j] - ranges[tile[j]].x < nproc[tile[j]]);
-                float4 ra[4], rb[4];
-                float rc[4];
+                for (int j = 0; j < 8; j++) use[j] = use[j] && (slot[j] - ranges[tile[j]].x < nproc[tile[j]]);
+                float4 ra[8], rb[8];
+                float rc[8];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < 8; j++) {
                     const float4* row = reinterpret_cast<const float4*>(slab + (size_t)(use[j] ? slot[j] : slot[0]) * DGM_SLAB_STRIDE);
                     ra[j] = row[0], rb[j] = row[1], rc[j] = row[2].x;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < 8; j++) {
                     if (use[j]) {
                         acc[0] += ra[j].x;
                         acc[1] += ra[j].y;
