@@ -33,7 +33,7 @@ static constexpr int MLP_XE = 63;     // PE(x) width: 3 + 3*2*10
 static constexpr int GM = 64, GK = 16, GAP = 66;  // GEMM tile rows, K stage, padded LDS row stride of A (= 2 mod 8)
 static constexpr int DW_ROWS = 512;   // rows per dW chunk
 static constexpr int DW_SLAB = 128;   // K columns per dW workgroup
-static constexpr int HD_ROWS = 128;   // rows per head-gradient chunk
+static constexpr int HD_ROWS = 256;   // rows per head-gradient chunk
 
 // ---- weight preparation -----------------------------------------------------------------------------------------
 // Wt (forward B operand): [Kp x 256] with Wt[k][j] = W[j][src(k)], zero rows for padding.
@@ -378,7 +378,7 @@ mlp_heads_bwd_kernel(int N, int NC, const float* __restrict__ dOut, const float*
 }
 
 // partial_Wh[chunk][o][c] = sum_rows dOut[r][o] * Y7[r][c] ; partial_bh[chunk][o] = sum_rows dOut[r][o]
-// (rows are consumed four at a time so that four Y7 loads are in flight per thread)
+// (rows are consumed eight at a time so that eight Y7 loads are in flight per thread)
 __global__ void __launch_bounds__(256)
 mlp_heads_dw_kernel(int N, int NC, const float* __restrict__ dOut, const float* __restrict__ Y7,
                     float* __restrict__ partial_W, float* __restrict__ partial_b) {
@@ -396,12 +396,12 @@ mlp_heads_dw_kernel(int N, int NC, const float* __restrict__ dOut, const float* 
             sd[i] = (rr < nr && o < NC) ? dOut[(size_t)(rb + rr) * NC + o] : 0.f;
         }
         __syncthreads();
-        for (int rr = 0; rr < nr; rr += 4) {
-            float y[4];
+        for (int rr = 0; rr < nr; rr += 8) {
+            float y[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) y[u] = (rr + u < nr) ? Y7[(size_t)(rb + rr + u) * MLP_W + c] : 0.f;
+            for (int u = 0; u < 8; u++) y[u] = (rr + u < nr) ? Y7[(size_t)(rb + rr + u) * MLP_W + c] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 const float4* d4 = reinterpret_cast<const float4*>(sd + (rr + u) * 16);
                 const float4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
                 acc[0] += d0.x * y[u];
