@@ -214,6 +214,14 @@ def main():
                 traffic = float(pmc["fetch_bytes"]) + float(pmc["write_bytes"])
         except (OSError, ValueError, KeyError):
             traffic = None
+        gemm_traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_gemm6r.json")) as fh:
+                pmc = json.load(fh)
+            if pmc.get("workload") == WORKLOAD:
+                gemm_traffic = float(pmc["fetch_bytes"]) + float(pmc["write_bytes"])
+        except (OSError, ValueError, KeyError):
+            gemm_traffic = None
         out = {
             "metric": "train-step iters/sec (800x800, ~100k Gaussians)", "value": args.steps * world / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,7 +237,7 @@ def main():
             # the dense bf16 peak.
             "roofline": {"kernel": "mlp_gemm6r_kernel<0,16,1,8> (one 256->256 layer forward, N rows)", "bound": "mfma",
                          "achieved": gemm_tf, "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": gemm_tf / MFMA_FP32_PEAK_TF, "traffic": None,
+                         "frac": gemm_tf / MFMA_FP32_PEAK_TF, "traffic": gemm_traffic,
                          "algorithmic_flops": gemm_flops, "avg_ms": gemm_ms, "launches": gemm_n,
                          "bf16_mfma_flops": 6.0 * gemm_flops,
                          "frac_of_bf16_peak": 6.0 * gemm_tf / MFMA_BF16_PEAK_TF},
