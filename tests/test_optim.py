@@ -77,3 +77,16 @@ def test_multi_adam_rejects_unsupported():
         O.MultiAdam([torch.optim.Adam([p], amsgrad=True)])
     with pytest.raises(ValueError):
         O.MultiAdam([torch.optim.Adam([p], weight_decay=0.1)])
+
+
+def test_multi_adam_refuses_cpu_tensors():
+    """No CPU fallback: the one-launch Adam only accepts device tensors (and plain-Adam hyper parameters)."""
+    O = pkg("optim")
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    ma = O.MultiAdam([torch.optim.Adam([p], lr=1e-3, eps=1e-15)])
+    with pytest.raises(ValueError):
+        ma.step()
+    assert torch.equal(p.detach(), torch.zeros(4))
+    with pytest.raises(ValueError):
+        O.MultiAdam([torch.optim.Adam([p], amsgrad=True)])
