@@ -84,3 +84,13 @@ def test_train_step_same_with_and_without_fused_glue():
         assert abs(res[0][0][k] - res[1][0][k]) < 1e-5 * abs(res[0][0][k]), k
     for k, (a, b) in enumerate(zip(res[0][1], res[1][1])):
         assert _rel(b, a) < 1e-4, (k, _rel(b, a))
+
+
+def test_glue_refuses_cpu_tensors():
+    """No CPU fallback for the fused glue either (the trainer only selects it for device tensors)."""
+    G = pkg("glue")
+    z = lambda *s: torch.zeros(*s)
+    with pytest.raises(RuntimeError):
+        G.gaussian_apply(z(5, 3), z(5, 3), z(5, 4), z(5, 1), z(5, 13))
+    with pytest.raises(RuntimeError):
+        G.cycle_loss(z(5, 13), z(5, 13))
