@@ -161,6 +161,19 @@ class GaussianModel:
                                                               keepdim=True)
         self.denom[update_filter] += 1
 
+    @torch.no_grad()
+    def track_densification_stats(self, viewspace_point_tensor, visibility_filter, radii):
+        """The per-iteration bookkeeping of R/train.py:489-496 (max_radii2D of the visible Gaussians, then
+        add_densification_stats) written with masks instead of boolean indexing: identical values, but no
+        nonzero() and hence no host synchronisation inside the step."""
+        vis = visibility_filter
+        r = radii.to(self.max_radii2D.dtype)
+        self.max_radii2D = torch.where(vis, torch.maximum(self.max_radii2D, r), self.max_radii2D)
+        g = None if viewspace_point_tensor is None else viewspace_point_tensor.grad
+        if g is not None:
+            self.xyz_gradient_accum += torch.norm(g[:, :2], dim=-1, keepdim=True) * vis.unsqueeze(-1)
+            self.denom += vis.unsqueeze(-1).to(self.denom.dtype)
+
 
 class PipelineParams:
     """R/arguments/__init__.py:95-100."""
@@ -188,6 +201,10 @@ class OptimizationParams:
     rotation_lr = 0.001
     percent_dense = 0.01
     lambda_dssim = 0.2
+    densify_from_iter = 500
+    densify_until_iter = 15_000
+    densification_interval = 100
+    opacity_reset_interval = 3000
 
 
 def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):

@@ -80,7 +80,7 @@ def frame_schedule(n_frames, step, rank, world, seed=0):
 class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
-                 process_group=None, fused_loss=True, fused_glue=None):
+                 process_group=None, fused_loss=True, fused_glue=None, track_stats=True):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
         self.cameras = cameras
         self.opt = opt or S.OptimizationParams()
@@ -91,6 +91,7 @@ class Trainer:
         self.render_fn = render_fn or S.render
         self.group = process_group
         self.fused_loss = fused_loss
+        self.track_stats = track_stats
         self.step_count = 0
         # fused per-Gaussian glue (activations + deformation, cycle loss): GPU, stock render(), plain (non-6dof) networks
         self.fused_glue = bool(fused_glue) if fused_glue is not None else (
@@ -115,6 +116,14 @@ class Trainer:
         self.pack = self.multi_adam is not None
         self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or world > 1) else None
         self.time_interval = 1.0 / max(len(cameras), 1)
+
+    def sync_densification_stats(self):
+        """Before a densify/prune decision every rank must see the statistics of ALL frames:
+        gradient accumulators and visit counts add up, the screen-space radius bound is a maximum."""
+        if self.world > 1:
+            dist.all_reduce(self.g.xyz_gradient_accum, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.g.denom, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.g.max_radii2D, op=dist.ReduceOp.MAX, group=self.group)
 
     def grad_bytes(self):
         """Size of the all-reduce payload (all gradients, fp32)."""
@@ -171,6 +180,8 @@ class Trainer:
         losses, pkg = self.loss_terms(cam, iteration)
         loss = sum(losses.values())
         loss.backward()
+        if self.track_stats and iteration < self.opt.densify_until_iter:  # R/train.py:488-496
+            g.track_densification_stats(pkg.get("viewspace_points"), pkg["visibility_filter"], pkg["radii"])
         grads = None
         if self.world > 1:
             if self.pack:

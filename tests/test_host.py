@@ -134,3 +134,26 @@ def test_synthetic_camera_conventions(syn):
     a = syn.activate(g)
     np.testing.assert_allclose(a["opacities"], 0.1, rtol=1e-5)
     np.testing.assert_allclose(np.linalg.norm(a["rotations"], axis=1), 1, rtol=1e-5)
+
+
+def test_densification_stats_mask_form_equals_indexing():
+    """GaussianModel.track_densification_stats (mask arithmetic, no nonzero()) == the reference's boolean-index form
+    (train.py:489-496 + add_densification_stats)."""
+    import torch
+    S = pkg("scene")
+    P = 50
+    g1, g2 = S.GaussianModel(sh_degree=3, device="cpu"), S.GaussianModel(sh_degree=3, device="cpu")
+    rng = np.random.RandomState(0)
+    for g in (g1, g2):
+        g.load_raw(rng.randn(P, 3), rng.randn(P, 1, 3), rng.randn(P, 15, 3), rng.randn(P, 3), rng.randn(P, 4), rng.randn(P, 1))
+        g.training_setup(S.OptimizationParams())
+    for step in range(3):
+        vp = torch.zeros(P, 3, requires_grad=True)
+        vp.grad = torch.tensor(rng.randn(P, 3).astype(np.float32))
+        radii = torch.tensor(rng.randint(0, 40, P).astype(np.int32))
+        vis = radii > 0
+        g1.max_radii2D[vis] = torch.max(g1.max_radii2D[vis], radii[vis].to(g1.max_radii2D.dtype))
+        g1.add_densification_stats(vp, vis)
+        g2.track_densification_stats(vp, vis, radii)
+    assert torch.equal(g1.max_radii2D, g2.max_radii2D)
+    assert torch.allclose(g1.xyz_gradient_accum, g2.xyz_gradient_accum) and torch.equal(g1.denom, g2.denom)
