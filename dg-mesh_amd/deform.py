@@ -215,6 +215,21 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
     return helper
 
 
+def get_linear_noise_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """R/utils/general_utils.py:78-111: like get_expon_lr_func but LINEAR interpolation between lr_init and lr_final
+    (the annealing factor of the time-input noise, R/train.py:119-121)."""
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay_rate = 1.0
+        t = np.clip(step / max_steps, 0, 1)
+        return delay_rate * (lr_init * (1 - t) + lr_final * t)
+    return helper
+
+
 class _ModelWrapper:
     """DeformModel* / AppearanceModel: .step(), Adam(eps=1e-15) setup, lr schedule, save/load
     (R/scene/deform_model.py:8-138, R/scene/appearance_model.py:8-46)."""

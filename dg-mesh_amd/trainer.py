@@ -116,6 +116,8 @@ class Trainer:
         self.pack = self.multi_adam is not None
         self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or world > 1) else None
         self.time_interval = 1.0 / max(len(cameras), 1)
+        from .deform import get_linear_noise_func
+        self.smooth_term = get_linear_noise_func(lr_init=0.1, lr_final=1e-15, lr_delay_mult=0.01, max_steps=20000)
 
     def sync_densification_stats(self):
         """Before a densify/prune decision every rank must see the statistics of ALL frames:
@@ -129,6 +131,15 @@ class Trainer:
         """Size of the all-reduce payload (all gradients, fp32)."""
         return sum(p.numel() for p in self.params) * 4
 
+    def time_input(self, cam, N, iteration):
+        """fid (+ annealed noise for real scenes, R/train.py:158-166 and 208-216) for all N rows.  The noise is one
+        sample per call, shared by every row, so it is added to the single time value BEFORE expanding: same values as
+        the reference's expand-then-add, but the tensor stays a stride-0 view (the MLPs' one-row time branch)."""
+        t = cam.fid.reshape(1, 1)
+        if not self.is_blender:
+            t = t + torch.randn(1, 1, device=t.device) * self.time_interval * self.smooth_term(iteration)
+        return t.expand(N, -1)
+
     def loss_terms(self, cam, iteration):
         g, opt = self.g, self.opt
         delta = None
@@ -136,7 +147,7 @@ class Trainer:
             d_xyz, d_rotation, d_scaling = 0.0, 0.0, 0.0
         else:
             N = g.get_xyz.shape[0]
-            time_input = cam.fid.unsqueeze(0).expand(N, -1)
+            time_input = self.time_input(cam, N, iteration)
             if self.fused_glue:  # raw (N, 13) head output straight into the fused glue kernels (glue.py)
                 delta = self.deform.step_raw(g.get_xyz.detach(), time_input)
             if delta is None:
@@ -144,14 +155,14 @@ class Trainer:
         losses = {}
         if delta is not None:
             pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta)
-            back = self.deform_back.step_raw(pkg["means3D"].detach(), time_input)
+            back = self.deform_back.step_raw(pkg["means3D"].detach(), self.time_input(cam, N, iteration))
             from .glue import cycle_loss
             losses["cycle_loss"] = cycle_loss(delta, back)
         else:
             pkg = self.render_fn(cam, g, self.pipe, self.bg, d_xyz, d_rotation, d_scaling, self.is_6dof)
             if iteration >= opt.warm_up:
                 deformed_xyz = g.get_xyz + d_xyz
-                back = self.deform_back.step(deformed_xyz.detach(), time_input)
+                back = self.deform_back.step(deformed_xyz.detach(), self.time_input(cam, N, iteration))
                 cycle = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rotation) + S.l1_loss(-back[2], d_scaling)) / 3.0
                 losses["cycle_loss"] = cycle
         image = pkg["render"]

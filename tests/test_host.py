@@ -157,3 +157,27 @@ def test_densification_stats_mask_form_equals_indexing():
         g2.track_densification_stats(vp, vis, radii)
     assert torch.equal(g1.max_radii2D, g2.max_radii2D)
     assert torch.allclose(g1.xyz_gradient_accum, g2.xyz_gradient_accum) and torch.equal(g1.denom, g2.denom)
+
+
+def test_time_noise_schedule_and_shape():
+    """get_linear_noise_func: linear (not log) interpolation with the delayed warm-up factor, as the reference's
+    smooth_term (train.py:119-121); Trainer.time_input keeps a stride-0 view and only adds noise for real scenes."""
+    import torch
+    D, T = pkg("deform"), pkg("trainer")
+    f = D.get_linear_noise_func(lr_init=0.1, lr_final=1e-15, lr_delay_mult=0.01, max_steps=20000)
+    assert abs(f(0) - 0.1) < 1e-12 and abs(f(10000) - 0.05) < 1e-9 and f(20000) < 1e-12 and f(10 ** 9) < 1e-12
+    g = D.get_linear_noise_func(1.0, 0.0, lr_delay_steps=100, lr_delay_mult=0.5, max_steps=1000)
+    assert abs(g(0) - 0.5) < 1e-12 and abs(g(100) - 0.9) < 1e-9
+
+    class Cam:
+        fid = torch.tensor([0.25])
+
+    tr = T.Trainer.__new__(T.Trainer)
+    tr.is_blender, tr.time_interval, tr.smooth_term = True, 0.01, f
+    t = tr.time_input(Cam, 7, 5000)
+    assert t.shape == (7, 1) and t.stride(0) == 0 and float(t[3, 0]) == 0.25
+    tr.is_blender = False
+    torch.manual_seed(0)
+    t2 = tr.time_input(Cam, 7, 5000)
+    assert t2.stride(0) == 0 and float(t2[0, 0]) != 0.25 and abs(float(t2[0, 0]) - 0.25) < 0.01 * 0.1 * 6
+    assert torch.equal(t2[0], t2[6])
