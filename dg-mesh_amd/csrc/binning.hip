@@ -335,7 +335,8 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
 hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, unsigned long long* keys,
                             const float* rec, unsigned* point_list, unsigned* inv, const unsigned* big_list,
                             const unsigned* big_count) {
-    static bool attr_set = false;
+    static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
+    bool& attr_set = attr_set_dev[current_device_slot()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)tile_sort_big_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLargeCap * 8);

@@ -191,10 +191,10 @@ int check_launch(const char* what, bool debug, hipStream_t st) {
         if (check_launch(what, debug != 0, st)) return 1; \
     } while (0)
 
-// knn scratch arena (grow-only, per process; simple-knn is an init-time / anchoring-time call)
+// knn scratch arena (grow-only, one per device; simple-knn is an init-time / anchoring-time call)
 std::mutex g_knn_mu;
-char* g_knn_scratch = nullptr;
-size_t g_knn_cap = 0;
+char* g_knn_scratch_dev[DGM_MAX_DEVICES] = {nullptr};
+size_t g_knn_cap_dev[DGM_MAX_DEVICES] = {0};
 
 }  // namespace
 
@@ -335,18 +335,17 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
     DGM_CHECK("scan_blocks");
     tm.end(DGM_STAGE_PREPROCESS);
 
-    // R is needed on the host to size the binning buffer (rasterizer_impl.cu:281 does the same read-back)
-    unsigned R_host = 0;
-    DGM_HIP(hipMemcpyAsync(&R_host, counters, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    // R is needed on the host to size the binning buffer (rasterizer_impl.cu:281 does the same read-back); the
+    // "prefiltered but culled" flag of auxiliary.h:156-160 rides in the same 8-byte copy, so it is ALWAYS checked
+    // (the reference traps the kernel unconditionally), not only with debug on.
+    unsigned host_words[2] = {0, 0};
+    DGM_HIP(hipMemcpyAsync(host_words, counters, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     DGM_HIP(hipStreamSynchronize(st));
+    const unsigned R_host = host_words[0];
     if (R_host > 0x7fffffffu) return fail("rasterize_forward: %u tile instances overflow int", R_host);
     const int R = (int)R_host;
     if (num_rendered) *num_rendered = R;
-    if (debug) {
-        unsigned flags = 0;
-        DGM_HIP(hipMemcpy(&flags, counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
-        if (flags & 1u) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
-    }
+    if (host_words[1] & 1u) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
 
     compute_layout(P, width, height, R, &L);
     char* bin = binning_alloc(binning_ctx, L.binning_bytes);
@@ -465,6 +464,9 @@ int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, void* stre
     if (!points || !mean_dists) return fail("knn_mean_dist2: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_knn_mu);
+    const int slot = current_device_slot();
+    char*& g_knn_scratch = g_knn_scratch_dev[slot];
+    size_t& g_knn_cap = g_knn_cap_dev[slot];
     const size_t need = knn_scratch_bytes(P);
     if (need > g_knn_cap) {
         if (g_knn_scratch) {

@@ -71,6 +71,14 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->image_bytes = o + A;
 }
 
+// Per-device host caches (one process may drive several GPUs): index = current HIP device, clamped.
+static constexpr int DGM_MAX_DEVICES = 16;
+static inline int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < DGM_MAX_DEVICES ? dev : DGM_MAX_DEVICES - 1;
+}
+
 static inline char* align_ptr(char* p, size_t a = 256) {
     return (char*)(((uintptr_t)p + a - 1) / a * a);
 }

@@ -587,14 +587,16 @@ struct Ws {
     size_t bytes;
 };
 int num_cus() {
-    static const int v = [] {
+    static int cache[DGM_MAX_DEVICES] = {0};  // per device: one process may drive several GPUs
+    const int slot = current_device_slot();
+    if (cache[slot] == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             n <= 0)
             n = 256;
-        return n;
-    }();
-    return v;
+        cache[slot] = n;
+    }
+    return cache[slot];
 }
 // bf16x6 dW decomposition: about 512 workgroups (two per CU) whatever the layer's K
 struct DwPlan {

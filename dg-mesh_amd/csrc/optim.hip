@@ -84,12 +84,13 @@ extern "C" int dgm_adam_step(int n_tensors, float* const* params, const float* c
         return 1;
     }
     hipStream_t st = (hipStream_t)stream;
-    for (int base = 0; base < n_tensors; base += ADAM_MAX) {
+    int i = 0;  // next tensor to place: a batch takes the next ADAM_MAX NON-EMPTY tensors, wherever they end
+    while (i < n_tensors) {
         AdamArgs a;
         a.count = 0;
         a.b1 = beta1, a.b2 = beta2, a.eps = eps;
         int blocks = 0;
-        for (int i = base; i < n_tensors && a.count < ADAM_MAX; i++) {
+        for (; i < n_tensors && a.count < ADAM_MAX; i++) {
             if (numel[i] <= 0) continue;
             if (numel[i] > 0x7fffffffLL || step[i] < 1 || !params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) {
                 dgm::set_last_error("adam_step: bad tensor (NULL pointer, step < 1 or more than 2^31-1 elements)");

@@ -16,14 +16,11 @@
 //    SCALAR loop over the set bits of its masks (s_ff1 / s_andn2), so pairs that the reference would discard
 //    with `alpha < 1/255` after evaluating exp() are never issued.  The test is conservative (inflated box;
 //    NaN => keep), hence results are unchanged.
-#include <stdlib.h>
-
 #include "dgm_common.hpp"
 #include "render_common.hpp"
 
 namespace dgm {
 
-template <bool CULL, int MODE = 0>
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
@@ -49,9 +46,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     bool done = !inside;
 
     for (int i = 0; i < rounds; i++) {
-        if (MODE & 1) {
-            __syncthreads();
-        } else if (__syncthreads_and(done)) break;  // also orders the previous round's LDS reads before the refill
+        if (__syncthreads_and(done)) break;  // also orders the previous round's LDS reads before the refill
         const int at = (i << 8) + threadIdx.x;
         unsigned qm = 0;
         if (at < n) {
@@ -62,7 +57,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             sA[threadIdx.x] = r0;
             sB[threadIdx.x] = r1;
             sC[threadIdx.x] = cb;
-            qm = CULL ? quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx0, ty0) : 15u;
+            qm = quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx0, ty0);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -70,7 +65,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             if (lane == 0) sMask[wv][q] = bal;
         }
         __syncthreads();
-        if (!(MODE & 2) && __ballot(!done) == 0ull) continue;  // whole quadrant finished: keep helping with staging only
+        if (__ballot(!done) == 0ull) continue;  // whole quadrant finished: keep helping with staging only
         const unsigned base = (unsigned)(i << 8);
 #pragma unroll 1
         for (int sw = 0; sw < 4; sw++) {
@@ -115,23 +110,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
                        unsigned* n_contrib) {
-    static const bool no_cull = getenv("DGM_NO_CULL") != nullptr;  // debugging aid: blend every staged splat
-    const char* mode = getenv("DGM_FWD_MODE");
-    if (mode && mode[0] == '1')
-        hipLaunchKernelGGL((render_fwd_kernel<true, 1>), dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
-                           bg, out_color, final_T, n_contrib);
-    else if (mode && mode[0] == '2')
-        hipLaunchKernelGGL((render_fwd_kernel<true, 2>), dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
-                           bg, out_color, final_T, n_contrib);
-    else if (mode && mode[0] == '3')
-        hipLaunchKernelGGL((render_fwd_kernel<true, 3>), dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
-                           bg, out_color, final_T, n_contrib);
-    else if (no_cull)
-        hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
-                           bg, out_color, final_T, n_contrib);
-    else
-        hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec,
-                           bg, out_color, final_T, n_contrib);
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
+                       out_color, final_T, n_contrib);
 }
 
 }  // namespace dgm

@@ -103,11 +103,35 @@ def time_row(net, t_row):
     return _TimeNetFunction.apply(t_row, net.t_multires, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
 
 
+def check_supported(net, heads, t_emb):
+    """The fused kernels are specialised to the reference's only trunk shape (D=8, W=256, PE(x) with 10 frequencies, skip
+    after layer 4: R/utils/time_utils.py:60-103).  Anything else would make them read the weight tensors with wrong
+    strides, so refuse it here -- the C side cannot see the module."""
+    T = t_emb.shape[1]
+    in0 = 63 + T
+    ok = (getattr(net, "D", None) == 8 and getattr(net, "W", None) == 256 and getattr(net, "multires", None) == 10
+          and list(getattr(net, "skips", [])) == [4] and len(net.linear) == 8 and in0 <= 96)
+    if ok:
+        for l, lin in enumerate(net.linear):
+            want = (256, in0) if l == 0 else ((256, 256 + in0) if l == 5 else (256, 256))
+            ok = ok and tuple(lin.weight.shape) == want and lin.bias is not None and tuple(lin.bias.shape) == (256,)
+        for m in heads:
+            ok = ok and m.weight.shape[1] == 256 and m.bias is not None
+        ok = ok and 1 <= sum(m.weight.shape[0] for m in heads) <= 16
+    if not ok:
+        raise RuntimeError("trunk_impl='hip' supports the reference trunk only (D=8, W=256, multires=10, skips=[4], at most "
+                           "16 head outputs); build the network with trunk_impl='torch' for other shapes")
+
+
 def network_forward(net, heads, x, t_emb, bcast):
     if not x.is_cuda:
         raise RuntimeError("trunk_impl='hip' needs CUDA/HIP tensors (dg-mesh_amd has no CPU path for its kernels)")
+    if x.requires_grad:
+        raise RuntimeError("trunk_impl='hip' does not differentiate w.r.t. the positions (the training loop detaches them, "
+                           "R/train.py:156); pass xyz.detach() or use trunk_impl='torch'")
+    check_supported(net, heads, t_emb)
     Wh = torch.cat([m.weight for m in heads], 0)
     bh = torch.cat([m.bias for m in heads], 0)
     W = [l.weight for l in net.linear]
     b = [l.bias for l in net.linear]
-    return _MLPFunction.apply(x.detach() if not x.requires_grad else x, t_emb, bcast, Wh, bh, *W, *b)
+    return _MLPFunction.apply(x, t_emb, bcast, Wh, bh, *W, *b)

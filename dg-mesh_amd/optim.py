@@ -3,8 +3,8 @@
 The reference ends every iteration with `gaussians.optimizer.step(); deform.optimizer.step(); ...`
 (R/train.py:518-524), each a torch.optim.Adam(lr=0.0, eps=1e-15) whose group learning rates are rewritten every
 iteration by `update_learning_rate`.  MultiAdam keeps those optimizer objects as the source of truth for hyper
-parameters (it reads `param_groups[*]["lr"]`, betas, eps at every step, so the reference's lr schedulers keep working)
-but owns the moments itself and applies the update to every tensor of every group with a single HIP kernel.
+parameters (it reads `param_groups[*]["lr"]`, betas, eps at every step, so the reference's lr schedulers keep working),
+keeps the moments in those optimizers' own `state` (torch layout) and applies the update to every tensor of every group with a single HIP kernel.
 No CPU / PyTorch fallback: it needs the HIP library.
 """
 import ctypes
@@ -17,18 +17,24 @@ from . import _lib
 class MultiAdam:
     def __init__(self, optimizers):
         self.optimizers = list(optimizers)
-        self.state = {}  # id(param) -> [exp_avg, exp_avg_sq, step]
         for o in self.optimizers:
             for g in o.param_groups:
                 if g.get("amsgrad") or g.get("weight_decay", 0) != 0 or g.get("maximize"):
                     raise ValueError("MultiAdam implements plain Adam only (amsgrad / weight_decay / maximize unsupported)")
 
-    def _slot(self, p):
-        s = self.state.get(id(p))
-        if s is None or s[0].shape != p.shape:
-            s = [torch.zeros_like(p, memory_format=torch.contiguous_format),
-                 torch.zeros_like(p, memory_format=torch.contiguous_format), 0]
-            self.state[id(p)] = s
+    @staticmethod
+    def _slot(opt, p):
+        """Moments live in the OWNING optimizer's state[p] with torch.optim.Adam's own keys ('step', 'exp_avg',
+        'exp_avg_sq'), so the reference's optimizer surgery (_prune_optimizer / cat_tensors_to_optimizer /
+        replace_tensor_to_optimizer, R/scene/gaussian_model_dpsr_dynamic_anchor.py:364-440) and state_dict() see and
+        edit the real state; entries die with their parameter (no id() keyed side table)."""
+        s = opt.state[p]  # defaultdict: creates {} for a new / replaced Parameter
+        if "exp_avg" not in s:
+            s["step"] = torch.tensor(0.0)
+            s["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        elif s["exp_avg"].shape != p.shape or s["exp_avg_sq"].shape != p.shape:
+            raise ValueError("MultiAdam: optimizer state does not match its parameter's shape (surgery left it stale)")
         return s
 
     @torch.no_grad()
@@ -48,9 +54,15 @@ class MultiAdam:
                     if gr.dtype != torch.float32 or gr.shape != p.shape:
                         raise ValueError("MultiAdam: gradient / parameter mismatch")
                     gr = gr if gr.is_contiguous() else gr.contiguous()
-                    s = self._slot(p)
-                    s[2] += 1
-                    by_hyper.setdefault(key, []).append((p, gr, s, float(g["lr"])))
+                    s = self._slot(o, p)
+                    if not (s["exp_avg"].is_contiguous() and s["exp_avg_sq"].is_contiguous()):
+                        s["exp_avg"], s["exp_avg_sq"] = s["exp_avg"].contiguous(), s["exp_avg_sq"].contiguous()
+                    step = int(s["step"]) + 1  # a host scalar tensor, as torch.optim.Adam keeps it
+                    if torch.is_tensor(s["step"]) and not s["step"].is_cuda:
+                        s["step"].fill_(float(step))
+                    else:
+                        s["step"] = torch.tensor(float(step))
+                    by_hyper.setdefault(key, []).append((p, gr, (s["exp_avg"], s["exp_avg_sq"], step), float(g["lr"])))
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for (b1, b2, eps), items in by_hyper.items():
             n = len(items)

@@ -56,3 +56,22 @@ def oracle_backward(orc, fwd, a, dL):
     return orc.backward(fwd, a["bg"], a["means3D"], a["colors_precomp"], a["scales"], a["rotations"],
                         a["scale_modifier"], a["cov3D_precomp"], a["viewmatrix"], a["projmatrix"], a["tanfovx"],
                         a["tanfovy"], dL, a["sh"], a["degree"], a["campos"])
+
+
+def config_args(syn, cfg, seed=1, frame=7, kind="init"):
+    """Full-size rasterizer inputs of a BASELINE config: the config's camera (cfg4: off-centre
+    K through getProjectionMatrix_from_K), its background colour and P; scales from an analytic stand-in for the
+    3-NN distance (a KD-tree over 500k points would dominate the test time)."""
+    c = syn.CONFIGS[cfg]
+    cam = syn.config_camera(cfg, frame=frame)
+    P = c["P"]
+    ext = c.get("extent", 1.3)
+    d2 = np.full(P, (2.0 * ext / P ** (1 / 3.0)) ** 2 * 0.3, np.float32)
+    g = syn.make_gaussians(P, seed=seed, kind=kind, dist2=d2, extent=ext)
+    act = syn.activate(g)
+    bg = np.ones(3, np.float32) if c["white_bg"] else np.zeros(3, np.float32)
+    return dict(bg=bg, means3D=act["means3D"], colors_precomp=None, opacities=act["opacities"],
+                scales=act["scales"], rotations=act["rotations"], scale_modifier=1.0, cov3D_precomp=None,
+                viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2), H=c["H"], W=c["W"], sh=act["shs"],
+                degree=3, campos=cam.camera_center)

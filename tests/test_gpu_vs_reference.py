@@ -9,7 +9,7 @@ only; see oracle/build_ref.sh).  Two checks:
 import numpy as np
 import pytest
 
-from conftest import oracle_backward, oracle_forward, raster_args
+from conftest import config_args, oracle_backward, oracle_forward, raster_args
 import gpu_util as G
 import ref_util as R
 
@@ -69,6 +69,22 @@ def test_reference_cfg2_full_size(orc, syn):
     compare_forward(f_ref, f_hip, f_or["img"]["fragile"])
     dL = np.random.RandomState(0).randn(3, c["H"], c["W"]).astype(np.float32)
     dL[:, f_or["img"]["fragile"] != 0] = 0
+    compare_grads(R.backward(a, f_ref, dL), G.hip_backward(a, f_hip, dL))
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4", "cfg5"])
+def test_reference_remaining_configs_full_size(orc, syn, cfg):
+    """BASELINE cfg3 (800x800, black background), cfg4 (1080x1920 portrait, off-centre K, 300k) and cfg5 (1024^2,
+    500k) at FULL size: the reference's own kernels vs the HIP path -- integers exact, colour / final_T / all eight
+    gradient tensors <= 1e-4 (backward.cu:401-557, graphics_utils.py:79-100); fragile-pixel mask from the oracle."""
+    a = config_args(syn, cfg)
+    f_ref = R.forward(a)
+    f_hip = G.hip_forward(a)
+    f_or = oracle_forward(orc, a)
+    frag = f_or["img"]["fragile"]
+    compare_forward(f_ref, f_hip, frag)
+    dL = np.random.RandomState(5).randn(3, a["H"], a["W"]).astype(np.float32)
+    dL[:, frag != 0] = 0
     compare_grads(R.backward(a, f_ref, dL), G.hip_backward(a, f_hip, dL))
 
 

@@ -90,3 +90,74 @@ def test_multi_adam_refuses_cpu_tensors():
     assert torch.equal(p.detach(), torch.zeros(4))
     with pytest.raises(ValueError):
         O.MultiAdam([torch.optim.Adam([p], amsgrad=True)])
+
+
+@pytest.mark.gpu
+def test_multi_adam_state_lives_in_the_optimizer_and_survives_surgery():
+    """The moments are torch.optim.Adam-layout entries of optimizer.state, so reference-style surgery works on them:
+    pruning rows of exp_avg / exp_avg_sq (_prune_optimizer), replacing a Parameter with zeroed moments
+    (replace_tensor_to_optimizer, used by reset_opacity) -- and a replaced Parameter never inherits stale state."""
+    O = pkg("optim")
+    dev = "cuda"
+    p = torch.nn.Parameter(torch.ones(10, 3, device=dev))
+    ref = torch.nn.Parameter(p.detach().clone())
+    opt = torch.optim.Adam([{"params": [p], "lr": 0.1, "name": "xyz"}], lr=0.0, eps=1e-15)
+    opt_ref = torch.optim.Adam([{"params": [ref], "lr": 0.1, "name": "xyz"}], lr=0.0, eps=1e-15)
+    ma = O.MultiAdam([opt])
+    for _ in range(3):
+        p.grad = torch.full_like(p, 0.5)
+        ref.grad = torch.full_like(ref, 0.5)
+        ma.step()
+        opt_ref.step()
+    st = opt.state[p]
+    assert set(st) >= {"step", "exp_avg", "exp_avg_sq"} and int(st["step"]) == 3
+    assert torch.allclose(st["exp_avg"], opt_ref.state[ref]["exp_avg"], rtol=1e-6)
+    sd = opt.state_dict()
+    assert sd["state"][0]["exp_avg"].shape == (10, 3)
+    # _prune_optimizer (gaussian_model_dpsr_dynamic_anchor.py:383-401): keep rows 0..5, carry the moments along
+    mask = torch.arange(10, device=dev) < 6
+    for o, q in ((opt, p), (opt_ref, ref)):
+        g = o.param_groups[0]
+        s = o.state.pop(q)
+        s["exp_avg"], s["exp_avg_sq"] = s["exp_avg"][mask], s["exp_avg_sq"][mask]
+        g["params"][0] = torch.nn.Parameter(q.detach()[mask].clone().requires_grad_(True))
+        o.state[g["params"][0]] = s
+    p2, r2 = opt.param_groups[0]["params"][0], opt_ref.param_groups[0]["params"][0]
+    p2.grad, r2.grad = torch.full_like(p2, -0.25), torch.full_like(r2, -0.25)
+    ma.step()
+    opt_ref.step()
+    assert torch.allclose(p2, r2, rtol=1e-6, atol=1e-7) and int(opt.state[p2]["step"]) == 4
+    # a replaced Parameter without state starts from zero moments and step 0, whatever id() it got
+    del opt.state[p2]
+    p3 = torch.nn.Parameter(torch.ones(6, 3, device=dev))
+    opt.param_groups[0]["params"][0] = p3
+    p3.grad = torch.ones_like(p3)
+    ma.step()
+    assert int(opt.state[p3]["step"]) == 1
+    assert torch.allclose(p3, torch.full_like(p3, 1.0 - 0.1), rtol=1e-6)   # first Adam step moves by exactly lr
+
+
+@pytest.mark.gpu
+def test_adam_step_more_than_64_tensors_with_empty_ones():
+    """dgm_adam_step batches 64 tensors per launch; empty tensors are skipped without disturbing the batching (each
+    tensor must be updated exactly once)."""
+    import ctypes
+    L = pkg("_lib").lib()
+    dev = "cuda"
+    sizes = [0 if i % 7 == 3 else 5 + i for i in range(150)]
+    ps = [torch.zeros(max(n, 1), device=dev)[:n] for n in sizes]
+    gs = [torch.ones(max(n, 1), device=dev)[:n] for n in sizes]
+    ms = [torch.zeros(max(n, 1), device=dev)[:n] for n in sizes]
+    vs = [torch.zeros(max(n, 1), device=dev)[:n] for n in sizes]
+    n = len(sizes)
+    VP = ctypes.c_void_p * n
+    ptr = lambda ts: VP(*[t.data_ptr() if t.numel() else None for t in ts])
+    rc = L.dgm_adam_step(n, ptr(ps), ptr(gs), ptr(ms), ptr(vs), (ctypes.c_longlong * n)(*sizes),
+                         (ctypes.c_float * n)(*([0.5] * n)), (ctypes.c_int * n)(*([1] * n)), 0.9, 0.999, 1e-15,
+                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for i, (p, m) in enumerate(zip(ps, ms)):
+        if p.numel():
+            assert torch.allclose(p, torch.full_like(p, -0.5), rtol=1e-6), f"tensor {i} updated {p[0].item() / -0.5:.2f} times"
+            assert torch.allclose(m, torch.full_like(m, 0.1), rtol=1e-6)
