@@ -34,15 +34,19 @@ for k, c in agg.items():
                 e["frac_of_wave_cycles/" + n] = e[n] / wc
     if e.get("SQ_BUSY_CYCLES") and e.get("SQ_VALU_MFMA_BUSY_CYCLES"):
         e["mfma_busy_over_sq_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CYCLES"]
-    if e.get("GRBM_GUI_ACTIVE") and e.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-        # MFMA-busy cycles are summed over the chip's 1024 SIMDs (256 CU x 4); GRBM_GUI_ACTIVE = kernel wall clock cycles
-        e["mfma_util_of_chip"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 1024.0)
-    if e.get("GRBM_GUI_ACTIVE") and e.get("SQ_ACTIVE_INST_VALU"):
-        # quad-cycles of VALU issue summed over waves -> x4 cycles, over 1024 SIMDs
-        e["valu_issue_util_of_chip"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / (e["GRBM_GUI_ACTIVE"] * 1024.0)
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs (render_bwd2: 1.246e7 for a 0.67 ms kernel = 8 x 1.56e6 cycles), so
+    # the kernel's wall-clock cycles are GRBM_GUI_ACTIVE / 8; SQ cycle counters are summed over 1024 SIMDs (256 CU x 4).
+    wall = e.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    if wall:
+        e["wall_cycles"] = wall
+    if wall and e.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        e["mfma_util_of_chip"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (wall * 1024.0)
+    if wall and e.get("SQ_ACTIVE_INST_VALU"):
+        # quad-cycles of VALU execution summed over waves -> x4 cycles
+        e["valu_busy_of_chip"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / (wall * 1024.0)
     out[k] = e
 json.dump(out, open(os.path.join(root, f"pmc_sq_{tag}.json"), "w"), indent=1, sort_keys=True)
 for k, e in sorted(out.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", kv[1].get("SQ_BUSY_CYCLES", 0)) * kv[1]["dispatches"]):
     print(f"{k[:56]:56s} n={e['dispatches']:4d} " + " ".join(
         f"{n.split('/')[-1][3:] if n.startswith('frac') else n}={e[n]:.3g}" for n in sorted(e)
-        if n.startswith("frac_of") or n in ("mfma_util_of_chip", "valu_issue_util_of_chip", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU")))
+        if n.startswith("frac_of") or n in ("mfma_util_of_chip", "valu_busy_of_chip", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU")))
