@@ -24,6 +24,7 @@
 
 #include "dgm_common.hpp"
 #include "mlp_bf16x6.hpp"
+#include "mlp_f16x3.hpp"
 
 namespace dgm {
 
@@ -86,7 +87,7 @@ __global__ void mlp_embed_kernel(int N, const float* __restrict__ x, const float
 // two MFMA tiles, 32 accumulator VGPRs).  Small tiles keep the 100k-row problem balanced over 256 CUs (3126 tiles)
 // and the low register count lets 5 workgroups share a CU, which is what hides the global->LDS staging latency.
 static constexpr int GN = 128;
-template <int EPI, int ABL = 0>  // ABL: ablation switch for profiling only (1: no refills, 2: no MFMA)
+template <int EPI>
 __global__ void __launch_bounds__(256)
 mlp_gemm_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2, int K2,
                 const float* __restrict__ Bt, const float* __restrict__ bias, unsigned* __restrict__ mask,
@@ -133,7 +134,7 @@ mlp_gemm_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const flo
     const int a_off = lane & 31, b_off = wn * 32 + (lane & 31), kh = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if (ABL != 1 && kt + 1 < nk) MLP_LOAD_STAGE(kt + 1)
+        if (kt + 1 < nk) MLP_LOAD_STAGE(kt + 1)
         const float* as = As[buf];
         const float* bs = Bs[buf];
 #pragma unroll
@@ -141,14 +142,10 @@ mlp_gemm_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const flo
             const int k = 2 * kk + kh;
             const float a0 = as[k * GAP + a_off], a1 = as[k * GAP + a_off + 32];
             const float b0 = bs[k * GN + b_off];
-            if (ABL != 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
-            } else {
-                asm volatile("" ::"v"(a0), "v"(a1), "v"(b0));
-            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
         }
-        if (ABL != 1 && kt + 1 < nk) MLP_STORE_STAGE(buf ^ 1)
+        if (kt + 1 < nk) MLP_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
     // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
@@ -583,6 +580,9 @@ int mlp_fail(const char* msg) {
 struct Ws {
     float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb, *part2, *part2_db;
     uint4 *Wt6[8], *Wd6[8], *Wh6f, *Wh6b;  // bf16x6 weight planes
+    uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
+    float *wsc_f[8], *wsc_d[8];            // their inverse column scales
+    unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
     unsigned* mask[8];
     size_t bytes;
 };
@@ -615,13 +615,31 @@ DwPlan dw6_plan(int N, int Kp) {
     return d;
 }
 constexpr int DW_GROUPS = 8;  // first-level groups of the two-level dW partial reduction
-// 0: bf16x6 (fp32 operands split exactly into 3 bf16, 6 partial products on the bf16 matrix cores; default)
-// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f32|bf16x6.
+// 2: f16x3 (default; mlp_f16x3.hpp): power-of-two scaled operands split into 2 binary16, 3 partial products on the f16
+//    matrix cores for the 256-wide layers (layer 0 .. 4, 6, 7 forward, all backward-data, their weight gradients); the
+//    skip layer, the heads and the K = 96 / 352 weight gradients run the bf16x6 kernels
+// 0: bf16x6 everywhere (fp32 operands split exactly into 3 bf16, 6 partial products on the bf16 matrix cores)
+// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3|bf16x6|f32.
 int g_gemm_mode = [] {
     const char* e = getenv("DGM_MLP_GEMM");
-    return (e != nullptr && e[0] == 'f') ? 1 : 0;
+    if (e == nullptr) return 2;
+    if (e[0] == 'b') return 0;
+    if (e[0] == 'f' && e[1] == '3') return 1;
+    return 2;
 }();
 bool use_f32_mfma() { return g_gemm_mode == 1; }
+bool use_f16x3() { return g_gemm_mode == 2; }
+#define G3R_LDS(K_) (2 * 32 * (4 * (K_) + 16) + 256 + 8 * 32 * 4)  // A planes (double buffered) + row scales + mask words
+hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once per device
+    static bool done[DGM_MAX_DEVICES] = {false};
+    bool& d = done[current_device_slot()];
+    if (d) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<1, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+    if (e == hipSuccess) d = true;
+    return e;
+}
 Ws carve(char* base, int N) {
     Ws w;
     char* p = align_ptr(base);
@@ -653,6 +671,12 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.Wd6[l] = (uint4*)take((size_t)MLP_W * MLP_W * 6);
     w.Wh6f = (uint4*)take((size_t)MLP_W * 32 * 6);
     w.Wh6b = (uint4*)take((size_t)16 * MLP_W * 6);
+    for (int l = 0; l < 8; l++) w.Wt3[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 4);
+    for (int l = 0; l < 8; l++) w.Wd3[l] = (uint4*)take((size_t)MLP_W * MLP_W * 4);
+    for (int l = 0; l < 8; l++) w.wsc_f[l] = take(MLP_W * 4);
+    for (int l = 0; l < 8; l++) w.wsc_d[l] = take(MLP_W * 4);
+    w.cmaxY = (unsigned*)take(8 * MLP_W * 4);
+    w.cmaxG = (unsigned*)take(8 * MLP_W * 4);
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     w.partial_h = take((size_t)hchunks * 16 * MLP_W * 4);
     w.partial_hb = take((size_t)hchunks * 16 * 4);
@@ -686,7 +710,7 @@ extern "C" {
 
 int dgm_mlp_set_gemm(int mode) {
     const int prev = g_gemm_mode;
-    if (mode == 0 || mode == 1) g_gemm_mode = mode;
+    if (mode >= 0 && mode <= 2) g_gemm_mode = mode;
     return prev;
 }
 
@@ -710,7 +734,8 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             hipLaunchKernelGGL(mlp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, layer_in(p, l), Kp, p->emb_dim,
                                l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
         }
-    } else {  // all 17 weight re-layouts (8 forward, 7 backward-data, 2 head matrices) in one launch
+    } else {  // all weight re-layouts of the network in one launch per arithmetic
+        const bool x3 = use_f16x3();
         Prep6Batch pb;
         int nj = 0, max_threads = 0;
         auto add = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp,
@@ -720,13 +745,30 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             j.k_valid = k_valid, j.col_valid = col_valid, j.W = Wp, j.Bp = Bp;
             if (Kp / 8 * ncols > max_threads) max_threads = Kp / 8 * ncols;
         };
+        Prep3Batch p3;
+        int n3 = 0;
+        auto add3 = [&](int mode, int Kp, int in_features, int hoff, const float* Wp, uint4* Bp, float* inv_scale) {
+            Prep3Job& j = p3.job[n3++];
+            j.mode = mode, j.Kp = Kp, j.ncols = MLP_W, j.in_features = in_features, j.emb_dim = p->emb_dim, j.hoff = hoff;
+            j.k_valid = MLP_W, j.col_valid = MLP_W, j.W = Wp, j.Bp = Bp, j.inv_scale = inv_scale;
+        };
         for (int l = 0; l < 8; l++) {
-            add(0, layer_kp(p, l), MLP_W, layer_in(p, l), 0, 0, MLP_W, p->W[l], w.Wt6[l]);
-            if (l >= 1) add(1, MLP_W, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l], w.Wd6[l]);
+            const bool l3 = x3 && l != p->skip_layer;  // the K = 352 planes of the skip layer do not fit the register file
+            if (l3) add3(0, layer_kp(p, l), layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_f[l]);
+            else add(0, layer_kp(p, l), MLP_W, layer_in(p, l), 0, 0, MLP_W, p->W[l], w.Wt6[l]);
+            if (l >= 1) {
+                if (x3) add3(1, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, p->W[l], w.Wd3[l], w.wsc_d[l]);
+                else add(1, MLP_W, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l], w.Wd6[l]);
+            }
         }
         add(0, MLP_W, 32, MLP_W, 0, 0, p->n_out, p->Wh, w.Wh6f);
         add(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh6b);
         hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
+        if (n3 > 0) {
+            hipLaunchKernelGGL(mlp_prep3_batch_kernel, dim3(MLP_W / 64, n3), dim3(64), 0, st, p3);
+            if (hipMemsetAsync(w.cmaxY, 0, 8 * MLP_W * 4, st) != hipSuccess) return mlp_fail("mlp_forward: memset failed");
+            if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_forward: cannot raise the LDS limit of mlp_gemm3r_kernel");
+        }
     }
     {
         const size_t tot = (size_t)N * MLP_EMB;
@@ -745,39 +787,37 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         } else {
             A1 = w.Y[l - 1], lda1 = MLP_W, K1 = MLP_W;
         }
-        static const int abl = getenv("DGM_MLP_ABL") ? atoi(getenv("DGM_MLP_ABL")) : 0;  // profiling aid
         if (!f32) {
-#define G6_FWD(ABL_)                                                                                                         \
-    hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false, ABL_>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, \
-                       K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W)
-            if (abl == 1) G6_FWD(1);
-            else if (abl == 2) G6_FWD(2);
-            else if (abl == 3) G6_FWD(3);
-            else if (abl == 4) G6_FWD(4);
-            else if (abl == 9 || K1 + K2 == MLP_EMB + MLP_W) G6_FWD(0);  // skip layer: its 22 x 12 weight registers do not fit
-            else {
-                const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
+            const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
+            if (K1 + K2 == MLP_EMB + MLP_W) {  // skip layer: bf16x6, weights streamed through LDS
+                hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2,
+                                   lda2, K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W);
+                if (use_f16x3())  // this producer does not deliver the column maxima the next layer's dW scales need
+                    hipLaunchKernelGGL(mlp_colmax_kernel, dim3(num_cus()), dim3(256), 0, st, N, MLP_W, w.Y[l], MLP_W,
+                                       w.cmaxY + l * MLP_W);
+            } else if (use_f16x3()) {
                 if (K1 + K2 == MLP_W) {
                     dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                    hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
-                                       w.Wt6[l], p->b[l], w.mask[l], w.Y[l], (unsigned long long*)nullptr);
+                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 16, 2>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
+                                       nt32, A1, lda1, K1, A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l],
+                                       w.cmaxY + l * MLP_W);
                     dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
                 } else
-                    hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 6, 2, 4>), dim3(gx), dim3(256), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
-                                       w.Wt6[l], p->b[l], w.mask[l], w.Y[l], (unsigned long long*)nullptr);
-            }
-#undef G6_FWD
+                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 2>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
+                                       A1, lda1, K1, A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l],
+                                       w.cmaxY + l * MLP_W);
+            } else if (K1 + K2 == MLP_W) {
+                dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
+                hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
+                                   w.Wt6[l], p->b[l], w.mask[l], w.Y[l]);
+                dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
+            } else
+                hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 6, 2, 4>), dim3(gx), dim3(256), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
+                                   w.Wt6[l], p->b[l], w.mask[l], w.Y[l]);
             continue;
         }
-        if (abl == 1)
-            hipLaunchKernelGGL((mlp_gemm_kernel<0, 1>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
-                               w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
-        else if (abl == 2)
-            hipLaunchKernelGGL((mlp_gemm_kernel<0, 2>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
-                               w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
-        else
-            hipLaunchKernelGGL((mlp_gemm_kernel<0, 0>), dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2,
-                               w.Wt[l], p->b[l], w.mask[l], w.Y[l]);
+        hipLaunchKernelGGL(mlp_gemm_kernel<0>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2, w.Wt[l],
+                           p->b[l], w.mask[l], w.Y[l]);
     }
     if (f32)
         hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, p->n_out, w.Y[7], p->Wh, 1,
@@ -808,6 +848,12 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     else  // G7 = (dOut * Wh) masked by layer 7's ReLU bits: a K=16 GEMM
         hipLaunchKernelGGL((mlp_gemm6_kernel<1, 2, 2, 2, 4, true>), dim3(grid6), dim3(256), 0, st, N, dOut, p->n_out, 16,
                            (const float*)nullptr, 0, 0, p->n_out, w.Wh6b, (const float*)nullptr, w.mask[7], w.Ga, MLP_W, MLP_W);
+    const bool x3 = use_f16x3();
+    if (x3) {  // column maxima of G_7 for the first weight gradient's scales (the later G_l get theirs from the GEMM epilogue)
+        if (hipMemsetAsync(w.cmaxG, 0, 8 * MLP_W * 4, st) != hipSuccess) return mlp_fail("mlp_backward: memset failed");
+        hipLaunchKernelGGL(mlp_colmax_kernel, dim3(num_cus()), dim3(256), 0, st, N, MLP_W, w.Ga, MLP_W, w.cmaxG + 7 * MLP_W);
+        if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
+    }
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     hipLaunchKernelGGL(mlp_heads_dw_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, w.Y[7], w.partial_h,
                        w.partial_hb);
@@ -838,8 +884,12 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             const DwPlan d = dw6_plan(N, Kp);
             if (Kp == MLP_W) {
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
-                hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial,
-                                   w.partial_db);
+                if (x3)
+                    hipLaunchKernelGGL(mlp_dw3b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G,
+                                       w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial, w.partial_db);
+                else
+                    hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial,
+                                       w.partial_db);
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
             } else
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
@@ -863,9 +913,13 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             else {
                 const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
-                hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
-                                   (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn,
-                                   (unsigned long long*)nullptr);
+                if (x3)
+                    hipLaunchKernelGGL((mlp_gemm3r_kernel<1, 16, 2>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
+                                       nt32, G, MLP_W, MLP_W, (const float*)nullptr, 0, w.Wd3[l], w.wsc_d[l],
+                                       (const float*)nullptr, w.mask[l - 1], Gn, w.cmaxG + (l - 1) * MLP_W);
+                else
+                    hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
+                                       (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn);
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
             }
             float* t = G;

@@ -120,7 +120,7 @@ __global__ void mlp_prep6_kernel(int mode, int Kp, int ncols, int in_features, i
 //   EPI 1: C = acc where the saved mask bit is set, else 0   (backward data -> pre-masked gradient of the layer below)
 //   EPI 2: C[row * ldc + col] = acc + bias[col] for col < n_valid   (linear heads)
 //   NARROW: A1 is [M x a_valid] with a_valid <= 16 unaligned floats per row (head gradients); K is padded to 16
-template <int EPI, int WM, int WN, int MT, int NT, bool NARROW, int ABL = 0>  // ABL: profiling ablations only
+template <int EPI, int WM, int WN, int MT, int NT, bool NARROW>
 __global__ void __launch_bounds__(256, 2)
 mlp_gemm6_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2, int K2,
                  int a_valid, const uint4* __restrict__ Bp, const float* __restrict__ bias, unsigned* __restrict__ mask,
@@ -207,8 +207,8 @@ mlp_gemm6_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const fl
             ah[mt] = as_bf16x8(H), am[mt] = as_bf16x8(Mi), al[mt] = as_bf16x8(L);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 3 && kt + 1 < nk) G6_DMA(kt + 1, buf ^ 1)
-        if (ABL != 1 && kt + 1 < nk) G6_LOAD_A(kt + 1)
+        if (kt + 1 < nk) G6_DMA(kt + 1, buf ^ 1)
+        if (kt + 1 < nk) G6_LOAD_A(kt + 1)
         const uint4* bs = Bs[buf];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
@@ -216,11 +216,7 @@ mlp_gemm6_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const fl
             const bf16x8 bh = as_bf16x8(bs[bi]), bm = as_bf16x8(bs[2 * NCOLS + bi]), bl = as_bf16x8(bs[4 * NCOLS + bi]);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                if (ABL != 2) {
-                    DGM_MFMA6(acc[mt][nt], ah[mt], am[mt], al[mt], bh, bm, bl)
-                } else {
-                    asm volatile("" ::"v"(ah[mt]), "v"(am[mt]), "v"(al[mt]), "v"(bh), "v"(bm), "v"(bl));
-                }
+                DGM_MFMA6(acc[mt][nt], ah[mt], am[mt], al[mt], bh, bm, bl)
             }
         }
         // the stage copied during this step must have landed, and every wave must be done reading the current one
@@ -231,17 +227,6 @@ mlp_gemm6_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const fl
 #undef G6_LOAD_A
 
     // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
-    if (ABL == 4) {
-        float s = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) s += acc[mt][nt][r];
-        if (s == 12345.678f) C[0] = s;
-        return;
-    }
     float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
@@ -312,11 +297,11 @@ mlp_gemm6_kernel(int M, const float* __restrict__ A1, int lda1, int K1, const fl
 //   * per tile and wave: KS * 3 fragment reads feed KS * 6 * NT MFMAs; one barrier per tile; nothing but the
 //     activations ever crosses LDS, and no weight byte is re-read.
 // HBM traffic is the algorithmic minimum (A once, C once); rows are balanced over the CUs at 32-row granularity.
-template <int EPI, int KS, int NT, int NW, int ABL = 0, bool TIMING = false>  // NW waves, each NT*32 columns: NW * NT * 32 = 256 (or 128 with gridDim.y = 2)
+template <int EPI, int KS, int NT, int NW>  // NW waves, each NT*32 columns: NW * NT * 32 = 256 (or 128 with gridDim.y = 2)
 __global__ void __launch_bounds__(NW * 64)
 mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2,
                   const uint4* __restrict__ Bp, const float* __restrict__ bias, unsigned* __restrict__ mask,
-                  float* __restrict__ C, unsigned long long* __restrict__ dbg = nullptr) {
+                  float* __restrict__ C) {
     constexpr int K = KS * 16;
     constexpr int PU = KS * 6 * 32;     // granules per plane tile
     constexpr int NR = 4 * (K / 32) / NW;  // producer blocks (8 rows x 32 floats) per wave and tile
@@ -377,23 +362,21 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         bf16x8 ah = as_bf16x8(ps[0]), am = as_bf16x8(ps[64]), al = as_bf16x8(ps[128]);                                 \
         _Pragma("unroll") for (int ks = 0; ks < KS; ks++) {                                                            \
             const int nx = (ks + 1 < KS ? ks + 1 : ks) * 192;                                                          \
-            if (ABL == 2) asm volatile("" ::"v"(ah), "v"(am), "v"(al));                                                \
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) if (ABL != 2) {                                          \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                                       \
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks][nt], acc[nt], 0, 0, 0);                   \
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks][nt], acc[nt], 0, 0, 0);                   \
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks][nt], acc[nt], 0, 0, 0);                   \
             }                                                                                                          \
             ah = as_bf16x8(ps[nx]);                                                                                    \
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) if (ABL != 2) {                                          \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                                       \
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks][nt], acc[nt], 0, 0, 0);                   \
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks][nt], acc[nt], 0, 0, 0);                   \
             }                                                                                                          \
             am = as_bf16x8(ps[nx + 64]);                                                                               \
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) if (ABL != 2)                                            \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                         \
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks][nt], acc[nt], 0, 0, 0);                   \
             al = as_bf16x8(ps[nx + 128]);                                                                              \
         }                                                                                                              \
-        R6_T(2)                                                                                                        \
     }
 #define R6_EPILOGUE(tile_)                                                                                             \
     {                                                                                                                  \
@@ -402,7 +385,7 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         const int row0_ = (tile_) * 32 + 4 * g;                                                                        \
         float* cb_ = C + (size_t)row0_ * 256 + col0 + li;                                                              \
         unsigned* mb_ = mask + (size_t)row0_ * 8 + (col0 >> 5);                                                        \
-        const bool full_ = (ABL != 4) && ((tile_) * 32 + 32 <= M);                                                     \
+        const bool full_ = ((tile_) * 32 + 32 <= M);                                                                   \
         _Pragma("unroll") for (int rb = 0; rb < 16; rb += 8) {                                                         \
             unsigned mws[8][NT];                                                                                       \
             if (EPI == 1) { /* the mask words of eight rows first (clamped rows: no branches), so the loads overlap */  \
@@ -420,7 +403,7 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
             }                                                                                                          \
             _Pragma("unroll") for (int r = rb; r < rb + 8; r++) {                                                      \
                 const int ro = (r & 3) + 8 * (r >> 2);                                                                 \
-                const bool ok = full_ || ((ABL != 4) && (row0_ + ro < M));                                             \
+                const bool ok = full_ || (row0_ + ro < M);                                                             \
                 unsigned mw[NT];                                                                                       \
                 _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                                    \
                     float v = acc[nt][r];                                                                              \
@@ -431,17 +414,15 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
                     } else {                                                                                           \
                         v = ((mws[r - rb][nt] >> li) & 1u) ? v : 0.f;                                                  \
                     }                                                                                                  \
-                    if (ABL == 6) { if (v == 1234.5f) cb_[0] = v; }                                                    \
-                    else if (ok) cb_[ro * 256 + nt * 32] = v;                                                          \
+                    if (ok) cb_[ro * 256 + nt * 32] = v;                                                               \
                     acc[nt][r] = 0.f;                                                                                  \
                 }                                                                                                      \
-                if (EPI == 0 && li == 0 && ok && (ABL != 7 || mw[0] == 0x12345u)) {                                    \
+                if (EPI == 0 && li == 0 && ok) {                                                                       \
                     if (NT == 2) *reinterpret_cast<uint2*>(mb_ + ro * 8) = make_uint2(mw[0], mw[NT - 1]);              \
                     else mb_[ro * 8] = mw[0];                                                                          \
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
-        R6_T(3)                                                                                                        \
     }
 
     f32x16 acc[NT];
@@ -449,15 +430,6 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
-    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;  // split, load, mfma, epilogue, barrier
-#define R6_T(i_)                                                                                                       \
-    if (TIMING) {                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                                   \
-        tm[i_] += t1_ - t0;                                                                                            \
-        t0 = t1_;                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-    }
 
     if (my_tiles > 0) {
         R6_LOAD(blockIdx.x)
@@ -465,7 +437,6 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         if (my_tiles > 1) R6_LOAD(blockIdx.x + G)
     }
     __syncthreads();
-    if (TIMING) t0 = __builtin_amdgcn_s_memtime();
     // Waves w and w + 4 share a SIMD (NW == 8): the low wave runs [split, load | multiply, store], the high wave
     // [multiply, store | split, load].  Both MFMA phases overlap for most of the step ON PURPOSE: the A fragments are
     // single-buffered (no registers left), so one wave alone is bound by the ds_read -> MFMA latency (measured: 65
@@ -474,10 +445,8 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         const int tile = blockIdx.x + j * G;
         if (NW == 4 || wv < 4) {
             if (j + 1 < my_tiles) R6_SPLIT((j + 1) & 1)      // R holds tile j+1 (fetched during the previous step)
-            R6_T(0)
-            if (ABL != 5 && j + 2 < my_tiles) R6_LOAD(tile + 2 * G)
+            if (j + 2 < my_tiles) R6_LOAD(tile + 2 * G)
             __builtin_amdgcn_sched_barrier(0);
-            R6_T(1)
             R6_MFMA(j & 1)
             R6_EPILOGUE(tile)
         } else {
@@ -485,19 +454,10 @@ mlp_gemm6r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
             R6_EPILOGUE(tile)
             __builtin_amdgcn_sched_barrier(0);
             if (j + 1 < my_tiles) R6_SPLIT((j + 1) & 1)
-            R6_T(0)
-            if (ABL != 5 && j + 2 < my_tiles) R6_LOAD(tile + 2 * G)
-            R6_T(1)
+            if (j + 2 < my_tiles) R6_LOAD(tile + 2 * G)
         }
         __syncthreads();
-        R6_T(4)
     }
-    if (TIMING && dbg != nullptr && blockIdx.x == 0 && (wv == 0 || wv == 4) && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) dbg[(wv >> 2) * 8 + i] = tm[i];
-        dbg[(wv >> 2) * 8 + 6] = (unsigned long long)my_tiles;
-    }
-#undef R6_T
 #undef R6_LOAD
 #undef R6_SPLIT
 #undef R6_MFMA

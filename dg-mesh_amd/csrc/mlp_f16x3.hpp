@@ -1,0 +1,498 @@
+// fp32 GEMMs on the f16 matrix cores ("f16x3"): every fp32 operand is scaled by a power of two (exact) and split into
+// two binary16 numbers
+//     s x = h + l + e        h = rne16(s x),  l = rne16(s x - h),  |e| <= 2^-23 |s x|   (or 2^-25 absolute when l is subnormal)
+// and a product is evaluated as the three partial products  ah*bh + ah*bl + al*bh  on v_mfma_f32_32x32x16_f16 (each
+// product of two binary16 numbers is exact in fp32, accumulation in fp32).  What is dropped (al*bl) is below
+// 2^-22 |a b|; measured against fp64 the split error is 4e-8 of sum |a||b| -- the same as the bf16x6 split and an order
+// below the rounding error of an fp32 GEMM itself (tests/test_mlp.py::test_split_gemm_is_an_fp32_gemm).
+//
+// binary16 has 5 exponent bits, so operands must be brought into range first.  The scale only has to be constant along
+// the contraction index:
+//   * layer GEMM (contraction over features):  one scale per activation ROW (its max over K -> 2^14), one per weight
+//     COLUMN (prepared with the planes); the epilogue multiplies the accumulator by both inverse powers of two;
+//   * weight gradient (contraction over rows): one scale per COLUMN of X and of G, from column maxima that the
+//     producing GEMM's epilogue accumulates (one atomic per column and workgroup) -- no extra pass over the data.
+// With max |s x| in [2^14, 2^15) an element 2^-k of the maximum keeps 22 significant bits down to k = 11 and an absolute
+// error of 2^-39 of the maximum below that: better than fp32 wherever it matters for the sum.
+//
+// Why: three MFMAs per 16-deep K step instead of six (bf16x6), and two planes instead of three -- the stationary
+// weights of a wave shrink from 192 to 128 registers, which frees the registers the bf16x6 kernel lacked for deeper
+// prefetch.  With 48 MFMAs per 32-row tile and wave the 256-wide layers become HBM-bound (A in, C out, fp32).
+#pragma once
+#include "dgm_common.hpp"
+
+namespace dgm {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef DGM_F32X16_DEFINED
+#define DGM_F32X16_DEFINED
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
+
+__device__ __forceinline__ f16x8 as_f16x8(const uint4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// two already-scaled floats -> (h, l) dwords, first element in the low half (v_cvt_pk_f16_f32: round to nearest even)
+__device__ __forceinline__ void split2h(float a0, float a1, unsigned& h, unsigned& l) {
+    const f16x2 hh = __builtin_convertvector((f32x2){a0, a1}, f16x2);
+    const float r0 = a0 - (float)hh.x, r1 = a1 - (float)hh.y;
+    const f16x2 ll = __builtin_convertvector((f32x2){r0, r1}, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// scale = 2^(14 - floor(log2 max)) from the bits of a non-negative float maximum; the exponent is clamped so that both
+// the scale and its inverse are normal numbers (an all-zero row / column gets a harmless finite scale)
+__device__ __forceinline__ void scale_from_max_bits(unsigned bits, float& scale, float& inv) {
+    int e = (int)((bits >> 23) & 0xffu);
+    e = e < 20 ? 20 : (e > 250 ? 250 : e);
+    scale = __uint_as_float((unsigned)(268 - e) << 23);  // 2^(127 + 14 - e - 127 + 127 ...): exponent field 268 - e
+    inv = __uint_as_float((unsigned)(e - 14) << 23);     // its reciprocal
+}
+
+// wave-wide maximum of a non-negative float; the result is valid in lane 63 (DPP row_shr 1,2,4,8 + row_bcast 15,31)
+__device__ __forceinline__ float wave_max_nonneg_lane63(float v) {
+#define DGM_MAXDPP(ctrl_, rmask_)                                                                                      \
+    v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl_, rmask_, 0xf, false)))
+    DGM_MAXDPP(0x111, 0xf);
+    DGM_MAXDPP(0x112, 0xf);
+    DGM_MAXDPP(0x114, 0xf);
+    DGM_MAXDPP(0x118, 0xf);
+    DGM_MAXDPP(0x142, 0xa);
+    DGM_MAXDPP(0x143, 0xc);
+#undef DGM_MAXDPP
+    return v;
+}
+
+// ---- weight planes ------------------------------------------------------------------------------------------------
+// Bp[((stage*2 + plane)*2 + g)*ncols + col] holds the 8 halves B[k = stage*16 + g*8 + e][col] * scale[col], e = 0..7;
+// inv_scale[col] = 1 / scale[col].  Source mapping as in mlp_bf16x6.hpp (mode 0: forward, B = W^T through the trunk's K
+// mapping; mode 1: backward data, B = W[:, hoff:hoff+ncols]).
+struct Prep3Job {
+    int mode, Kp, ncols, in_features, emb_dim, hoff, k_valid, col_valid;
+    const float* W;
+    uint4* Bp;
+    float* inv_scale;
+};
+static constexpr int PREP3_MAX_JOBS = 16;
+struct Prep3Batch {
+    Prep3Job job[PREP3_MAX_JOBS];
+};
+
+__device__ __forceinline__ float prep3_src(const Prep3Job& j, int k, int col) {
+    if (j.mode == 0) {
+        int src = k;
+        if (j.Kp == 96) src = k < j.emb_dim ? k : -1;
+        else if (j.Kp == 352) src = k < 96 ? (k < j.emb_dim ? k : -1) : k - 96 + j.emb_dim;
+        return (src >= 0 && col < j.col_valid) ? j.W[(size_t)col * j.in_features + src] : 0.f;
+    }
+    return k < j.k_valid ? j.W[(size_t)k * j.in_features + j.hoff + col] : 0.f;
+}
+
+// blockIdx.y = job, one thread per column: column maximum -> scale, then the planes
+__global__ void __launch_bounds__(64) mlp_prep3_batch_kernel(const Prep3Batch b) {
+    const Prep3Job& j = b.job[blockIdx.y];
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= j.ncols) return;
+    float mx = 0.f;
+    for (int k = 0; k < j.Kp; k++) mx = fmaxf(mx, fabsf(prep3_src(j, k, col)));
+    float sc, inv;
+    scale_from_max_bits(__float_as_uint(mx), sc, inv);
+    j.inv_scale[col] = inv;
+    for (int kg = 0; kg < (j.Kp >> 3); kg++) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = prep3_src(j, kg * 8 + i, col) * sc;
+        uint4 H, L;
+        split2h(e[0], e[1], H.x, L.x);
+        split2h(e[2], e[3], H.y, L.y);
+        split2h(e[4], e[5], H.z, L.z);
+        split2h(e[6], e[7], H.w, L.w);
+        const int stage = kg >> 1, g = kg & 1;
+        uint4* dst = j.Bp + ((size_t)stage * 4 + g) * j.ncols + col;
+        dst[0] = H;
+        dst[2 * j.ncols] = L;
+    }
+}
+
+// column maxima of |X| (N x ncols, row stride ld) for producers that do not deliver them: out[col] = max(out[col], ..)
+// as float bits (non-negative floats order like unsigned integers)
+__global__ void __launch_bounds__(256) mlp_colmax_kernel(int N, int ncols, const float* __restrict__ X, int ld,
+                                                         unsigned* __restrict__ out) {
+    const int col = threadIdx.x;
+    if (col >= ncols) return;
+    float m = 0.f;
+    for (int r = blockIdx.x; r < N; r += gridDim.x) m = fmaxf(m, fabsf(X[(size_t)r * ld + col]));
+    atomicMax(out + col, __float_as_uint(m));
+}
+
+// ---- the trunk-layer GEMM, weights stationary in registers -------------------------------------------------------------
+// C[M x 256] = [A1 | A2] * B with K = KS * 16 (A1: first K1 columns, A2 the rest).
+//   EPI 0: C = relu(acc + bias), ReLU mask bits saved (mask[row][col / 32] bit col % 32)
+//   EPI 1: C = acc where the saved mask bit is set, else 0 (backward data)
+// Persistent grid of one 8-wave workgroup per CU; wave w owns output columns [32 w, 32 w + 32) and keeps both planes of
+// its B slice in registers for the whole kernel (KS * 8 VGPRs).  Activations stream in 32-row tiles:
+//   * producer role: wave w fetches rows 4w .. 4w+3 of a tile, ONE ROW PER INSTRUCTION (64 lanes x 16 B = 1 KiB
+//     coalesced), two tiles ahead; the row maximum is a wave reduction (DPP) -> per-row power-of-two scale in SGPRs;
+//     the scaled row is split into the two binary16 planes and written to LDS as [row][plane][k] (row pitch
+//     2 * 2K + 16 bytes): a wave's 8-byte stores of one row are contiguous, and a fragment read (lane = row, 16 B of 8
+//     consecutive k) walks the rows at an odd multiple of 16 B -- both conflict-free;
+//   * consumer role: per K step two ds_read_b128 (h, l fragments of the lane's row) feed three MFMAs;
+//   * epilogue: accumulator * (1/row scale) * (1/column scale), bias / ReLU / mask, stores, running column maxima of the
+//     output (for the weight-gradient kernel's scales): one atomicMax per column and workgroup at the very end.
+// Waves w and w + 4 share a SIMD and run the two roles in opposite order inside a tile step (one does split + loads
+// while the other multiplies), one barrier per tile.
+// wave-wide maxima of FOUR non-negative floats at once (valid in lane 63): the four DPP chains are interleaved, so each
+// stage's instructions fill the two wait states a DPP read needs after a VALU write of the same register
+__device__ __forceinline__ void wave_max4_nonneg_lane63(float& a, float& b, float& c, float& d) {
+#define DGM_ST(ctrl_)                                                       \
+    "v_max_f32_dpp %0, %0, %0 " ctrl_ "\n\t"                               \
+    "v_max_f32_dpp %1, %1, %1 " ctrl_ "\n\t"                               \
+    "v_max_f32_dpp %2, %2, %2 " ctrl_ "\n\t"                               \
+    "v_max_f32_dpp %3, %3, %3 " ctrl_ "\n\t"
+    asm volatile("s_nop 1\n\t" DGM_ST("row_shr:1 row_mask:0xf bank_mask:0xf") DGM_ST("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     DGM_ST("row_shr:4 row_mask:0xf bank_mask:0xf") DGM_ST("row_shr:8 row_mask:0xf bank_mask:0xf")
+                         DGM_ST("row_bcast:15 row_mask:0xa bank_mask:0xf") DGM_ST("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef DGM_ST
+}
+
+// epilogue of one 32 x 32 accumulator tile (lane: column li of the wave's 32, rows (r & 3) + 8 (r >> 2) + 4 g)
+template <int EPI, bool FULL>
+__device__ __forceinline__ void gemm3r_epilogue(f32x16& acc, const float* rinv_t, const unsigned* mlds_w, int row0, int M,
+                                                float* __restrict__ cb, unsigned* __restrict__ mb, int g, int li, float binv,
+                                                float bv, float& cmax) {
+    unsigned mwsel = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 iv = *reinterpret_cast<const float4*>(rinv_t + q * 8 + 4 * g);
+        const float ivs[4] = {iv.x * binv, iv.y * binv, iv.z * binv, iv.w * binv};
+        uint4 mq = make_uint4(0u, 0u, 0u, 0u);
+        if (EPI == 1) mq = *reinterpret_cast<const uint4*>(mlds_w + q * 8 + 4 * g);
+        const unsigned mws[4] = {mq.x, mq.y, mq.z, mq.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int r = q * 4 + e, ro = e + 8 * q;
+            float v = acc[r] * ivs[e];
+            if (EPI == 0) {
+                v = fmaxf(v + bv, 0.f);
+                const unsigned long long bal = __ballot(v > 0.f);  // low half: rows of g = 0, high half: g = 1
+                const unsigned mw = g ? (unsigned)(bal >> 32) : (unsigned)bal;
+                mwsel = (li == r) ? mw : mwsel;
+            } else {
+                v = ((mws[e] >> li) & 1u) ? v : 0.f;
+            }
+            if (FULL || row0 + ro < M) {
+                cb[ro * 256] = v;
+                cmax = fmaxf(cmax, fabsf(v));
+            }
+        }
+    }
+    if (EPI == 0 && li < 16) {  // lane li keeps the mask word of accumulator register li: one store for all sixteen rows
+        const int ro = (li & 3) + 8 * (li >> 2);
+        if (FULL || row0 + ro < M) mb[ro * 8] = mwsel;
+    }
+}
+
+template <int EPI, int KS, int PF>
+__global__ void __launch_bounds__(512)
+mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2,
+                  const uint4* __restrict__ Bp, const float* __restrict__ b_inv_scale, const float* __restrict__ bias,
+                  unsigned* __restrict__ mask, float* __restrict__ C, unsigned* __restrict__ colmax) {
+    constexpr int K = KS * 16;
+    constexpr int NI = (K + 255) / 256;        // row-load instructions per row
+    constexpr int RS = 4 * K + 16;             // bytes per LDS row: two planes of K halves + pad (odd multiple of 16 mod 256)
+    constexpr int PLANE = 2 * K;               // bytes per plane
+    static_assert((RS % 256) % 32 == 16, "row pitch must be an odd multiple of 16 bytes modulo 256");
+    static_assert(PF == 1 || PF == 2, "tiles in flight in registers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ps = smem;                                          // [2][32][RS]
+    float* rinv = reinterpret_cast<float*>(smem + 2 * 32 * RS);        // [2][32] inverse row scales
+    unsigned* mlds = reinterpret_cast<unsigned*>(rinv + 64);           // [8 waves][32] mask words of the current tile (EPI 1)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int col = wv * 32 + li;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+
+    f16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const uint4* b = Bp + ((size_t)ks * 4 + g) * 256 + col;
+        bh[ks] = as_f16x8(b[0]), bl[ks] = as_f16x8(b[512]);
+    }
+    const float binv = b_inv_scale[col];
+    const float bv = (EPI == 0) ? bias[col] : 0.f;
+    float cmax = 0.f;
+
+    float4 R[PF][4][NI];
+#define R3_LOAD(slot_, tile_)                                                                                          \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
+            int grow_ = (tile_) * 32 + wv * 4 + r_;                                                                    \
+            grow_ = grow_ < M ? grow_ : M - 1;                                                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) {                                                        \
+                const int k_ = i_ * 256 + lane * 4;                                                                    \
+                R[slot_][r_][i_] = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+                if (K % 256 == 0 || k_ < K) {                                                                          \
+                    const float* s_ = (k_ < K1) ? (A1 + (size_t)grow_ * lda1 + k_) : (A2 + (size_t)grow_ * lda2 + (k_ - K1)); \
+                    R[slot_][r_][i_] = *reinterpret_cast<const float4*>(s_);                                           \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+#define R3_SPLIT(slot_, pb_)                                                                                           \
+    {                                                                                                                  \
+        float m_[4];                                                                                                   \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
+            m_[r_] = 0.f;                                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) {                                                        \
+                const float4 v_ = R[slot_][r_][i_];                                                                    \
+                m_[r_] = fmaxf(fmaxf(m_[r_], fmaxf(fabsf(v_.x), fabsf(v_.y))), fmaxf(fabsf(v_.z), fabsf(v_.w)));       \
+            }                                                                                                          \
+        }                                                                                                              \
+        wave_max4_nonneg_lane63(m_[0], m_[1], m_[2], m_[3]);                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
+            const unsigned mb_ = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(m_[r_]), 63);                \
+            float sc_, inv_;                                                                                           \
+            scale_from_max_bits(mb_, sc_, inv_);                                                                       \
+            const int row_ = wv * 4 + r_;                                                                              \
+            rinv[(pb_) * 32 + row_] = inv_; /* every lane writes the same word: no exec juggling */                    \
+            unsigned char* d_ = Ps + ((pb_) * 32 + row_) * RS;                                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; i_++) {                                                        \
+                const int k_ = i_ * 256 + lane * 4;                                                                    \
+                if (K % 256 == 0 || k_ < K) {                                                                          \
+                    const float4 v_ = R[slot_][r_][i_];                                                                \
+                    unsigned h0_, l0_, h1_, l1_;                                                                       \
+                    split2h(v_.x * sc_, v_.y * sc_, h0_, l0_);                                                         \
+                    split2h(v_.z * sc_, v_.w * sc_, h1_, l1_);                                                         \
+                    *reinterpret_cast<uint2*>(d_ + 2 * k_) = make_uint2(h0_, h1_);                                     \
+                    *reinterpret_cast<uint2*>(d_ + PLANE + 2 * k_) = make_uint2(l0_, l1_);                             \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+    // fragments are fetched two K steps ahead of their MFMAs (ds_read latency ~ 100+ cycles, one step = 96 cycles of MFMA)
+#define R3_MFMA(pb_)                                                                                                   \
+    {                                                                                                                  \
+        const unsigned char* ps_ = Ps + ((pb_) * 32 + li) * RS + g * 16;                                               \
+        f16x8 fh_[3], fl_[3];                                                                                          \
+        fh_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_));                                                       \
+        fl_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE));                                               \
+        fh_[1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (KS > 1 ? 32 : 0)));                                   \
+        fl_[1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (KS > 1 ? 32 : 0)));                           \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks++) {                                                            \
+            if (ks + 2 < KS) {                                                                                         \
+                fh_[(ks + 2) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (ks + 2) * 32));                    \
+                fl_[(ks + 2) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (ks + 2) * 32));            \
+            }                                                                                                          \
+            if (ks == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bl[0], zero16, 0, 0, 0);                 \
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bl[ks], acc, 0, 0, 0);                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks % 3], bh[ks], acc, 0, 0, 0);                           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bh[ks], acc, 0, 0, 0);                           \
+        }                                                                                                              \
+    }
+#define R3_EPILOGUE(pb_, tile_)                                                                                        \
+    {                                                                                                                  \
+        const int row0_ = (tile_) * 32 + 4 * g;                                                                        \
+        float* cb_ = C + (size_t)row0_ * 256 + col;                                                                    \
+        unsigned* mb_ = mask + (size_t)row0_ * 8 + wv;                                                                 \
+        if (EPI == 1) mlds[wv * 32 + li] = mword; /* both halves write the same 32 words; read back by this wave only */ \
+        if ((tile_) * 32 + 32 <= M)                                                                                    \
+            gemm3r_epilogue<EPI, true>(acc, rinv + (pb_) * 32, mlds + wv * 32, row0_, M, cb_, mb_, g, li, binv, bv, cmax); \
+        else                                                                                                           \
+            gemm3r_epilogue<EPI, false>(acc, rinv + (pb_) * 32, mlds + wv * 32, row0_, M, cb_, mb_, g, li, binv, bv, cmax); \
+    }
+    // EPI 1: the tile's 32 mask words of this wave's column group, one per lane, requested before the MFMA phase
+#define R3_MASK(tile_)                                                                                                 \
+    if (EPI == 1) {                                                                                                    \
+        int mrow_ = (tile_) * 32 + li;                                                                                 \
+        mrow_ = mrow_ < M ? mrow_ : M - 1;                                                                             \
+        mword = mask[(size_t)mrow_ * 8 + wv];                                                                          \
+    }
+
+    f32x16 acc;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned mword = 0u;
+
+    // prologue: tile 0 split into buffer 0, tiles 1 .. PF in flight in the register slots (slot of tile j = j % PF)
+    if (my_tiles > 0) {
+        R3_LOAD(0, blockIdx.x)
+        R3_SPLIT(0, 0)
+        if (PF == 1) {
+            if (my_tiles > 1) R3_LOAD(0, blockIdx.x + G)
+        } else {
+            if (my_tiles > 1) R3_LOAD(PF - 1, blockIdx.x + G)
+            if (my_tiles > 2) R3_LOAD(0, blockIdx.x + 2 * G)
+        }
+    }
+    __syncthreads();
+    // one tile step; SLOT_ = register slot holding tile j + 1 (compile-time: two steps per loop trip)
+#define R3_STEP(j_, SLOT_)                                                                                             \
+    {                                                                                                                  \
+        const int tile = blockIdx.x + (j_) * G;                                                                        \
+        const int pb = (j_) & 1;                                                                                       \
+        R3_MASK(tile)                                                                                                  \
+        if (wv < 4) {                                                                                                  \
+            if ((j_) + 1 < my_tiles) {                                                                                 \
+                R3_SPLIT(SLOT_, pb ^ 1)                                                                                \
+                if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                      \
+            }                                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            R3_MFMA(pb)                                                                                                \
+            R3_EPILOGUE(pb, tile)                                                                                      \
+        } else {                                                                                                       \
+            R3_MFMA(pb)                                                                                                \
+            R3_EPILOGUE(pb, tile)                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if ((j_) + 1 < my_tiles) {                                                                                 \
+                R3_SPLIT(SLOT_, pb ^ 1)                                                                                \
+                if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        __syncthreads();                                                                                               \
+    }
+    for (int j = 0; j < my_tiles; j += 2) {
+        R3_STEP(j, PF - 1)          // tile j + 1 (odd) lives in slot 1 (PF == 2) / slot 0 (PF == 1)
+        if (j + 1 < my_tiles) R3_STEP(j + 1, 0)
+    }
+#undef R3_STEP
+    if (colmax != nullptr) {
+        // lanes li and li + 32 hold the same column: fold, then one atomic per column and workgroup
+        const float o = __shfl_xor(cmax, 32, 64);
+        cmax = fmaxf(cmax, o);
+        if (g == 0) atomicMax(colmax + col, __float_as_uint(cmax));
+    }
+#undef R3_LOAD
+#undef R3_SPLIT
+#undef R3_MFMA
+#undef R3_EPILOGUE
+#undef R3_MASK
+}
+
+// ---- weight gradient of the K = 256 layers --------------------------------------------------------------------------
+// partial[chunk][k][j] = sum_{rows of chunk} X[row][k] * G[row][j]   (then * 1 / (sx[k] sg[j])).
+// Same decomposition as mlp_dw6b_kernel (one 8-wave workgroup per chunk of rows covering all 256 x 256 outputs, waves
+// 4 x 2, wave tile 64 x 128, stages of 16 rows, every thread stages an 8-row x 2-column piece), with two binary16 planes:
+// the staging thread multiplies its two columns by their power-of-two scales (from the column maxima xmax / gmax the
+// producing kernels accumulated), splits, and writes one 16-byte granule (8 rows of one column) per plane.
+static constexpr int DW3_U = 4 * 256;  // uint4 per operand stage: [plane][row half][column]
+
+__global__ void __launch_bounds__(512)
+mlp_dw3b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx, const float* __restrict__ G,
+                const unsigned* __restrict__ xmax, const unsigned* __restrict__ gmax, float* __restrict__ partial,
+                float* __restrict__ partial_db) {
+    __shared__ uint4 Xs[2][DW3_U];
+    __shared__ uint4 Gs[2][DW3_U];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1, g = lane >> 5, li = lane & 31;
+    const int chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const int nst = (r1 - r0 + 15) >> 4;
+    const bool isG = tid >= 256;
+    const int rg = (tid >> 7) & 1, c2 = tid & 127;
+    const float* sp = isG ? (G + c2 * 2) : (X + c2 * 2);
+    const int sld = isG ? 256 : ldx;
+    uint4* sdst0 = (isG ? &Gs[0][0] : &Xs[0][0]) + rg * 256 + c2 * 2;
+    float sc0, sc1, inv_unused;
+    {
+        const unsigned* mx = isG ? gmax : xmax;
+        scale_from_max_bits(mx[c2 * 2], sc0, inv_unused);
+        scale_from_max_bits(mx[c2 * 2 + 1], sc1, inv_unused);
+    }
+    float2 v[8];
+    float2 colsum = make_float2(0.f, 0.f);
+
+#define DW3_LOAD(st_)                                                                                 \
+    {                                                                                                 \
+        const int rb_ = r0 + (st_) * 16 + rg * 8;                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                            \
+            v[i_] = make_float2(0.f, 0.f);                                                            \
+            if (rb_ + i_ < r1) v[i_] = *reinterpret_cast<const float2*>(sp + (size_t)(rb_ + i_) * sld); \
+        }                                                                                             \
+    }
+#define DW3_STORE(buf_)                                                                               \
+    {                                                                                                 \
+        uint4* d_ = sdst0 + (buf_) * DW3_U;                                                           \
+        uint4 H_, L_;                                                                                 \
+        split2h(v[0].x * sc0, v[1].x * sc0, H_.x, L_.x);                                              \
+        split2h(v[2].x * sc0, v[3].x * sc0, H_.y, L_.y);                                              \
+        split2h(v[4].x * sc0, v[5].x * sc0, H_.z, L_.z);                                              \
+        split2h(v[6].x * sc0, v[7].x * sc0, H_.w, L_.w);                                              \
+        d_[0] = H_, d_[512] = L_;                                                                     \
+        split2h(v[0].y * sc1, v[1].y * sc1, H_.x, L_.x);                                              \
+        split2h(v[2].y * sc1, v[3].y * sc1, H_.y, L_.y);                                              \
+        split2h(v[4].y * sc1, v[5].y * sc1, H_.z, L_.z);                                              \
+        split2h(v[6].y * sc1, v[7].y * sc1, H_.w, L_.w);                                              \
+        d_[1] = H_, d_[513] = L_;                                                                     \
+        if (isG) {                                                                                    \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) colsum.x += v[i_].x, colsum.y += v[i_].y; \
+        }                                                                                             \
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+
+    DW3_LOAD(0)
+    DW3_STORE(0)
+    if (nst > 1) DW3_LOAD(1)
+    __syncthreads();
+    for (int st = 0; st < nst; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nst) {
+            DW3_STORE(buf ^ 1)
+            if (st + 2 < nst) DW3_LOAD(st + 2)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4* xs = Xs[buf];
+        const uint4* gs = Gs[buf];
+        f16x8 ah[2], al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const int ai = g * 256 + wm * 64 + mt * 32 + li;
+            ah[mt] = as_f16x8(xs[ai]), al[mt] = as_f16x8(xs[512 + ai]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int bi = g * 256 + wn * 128 + nt * 32 + li;
+            const f16x8 gh = as_f16x8(gs[bi]), gl = as_f16x8(gs[512 + bi]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], gl, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], gh, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], gh, acc[mt][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef DW3_LOAD
+#undef DW3_STORE
+
+    float* out = partial + (size_t)chunk * 256 * 256;
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+        const int col = wn * 128 + nt * 32 + li;
+        float sg, ig;
+        scale_from_max_bits(gmax[col], sg, ig);
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float sx, ix;
+                scale_from_max_bits(xmax[k], sx, ix);
+                out[(size_t)k * 256 + col] = acc[mt][nt][r] * (ix * ig);
+            }
+        }
+    }
+    if (isG && partial_db != nullptr)
+        *reinterpret_cast<float2*>(partial_db + ((size_t)chunk * 2 + rg) * 256 + c2 * 2) = colsum;
+}
+
+}  // namespace dgm
