@@ -141,8 +141,8 @@ __global__ void __launch_bounds__(256) mlp_colmax_kernel(int N, int ncols, const
 //   * consumer role: per K step two ds_read_b128 (h, l fragments of the lane's row) feed three MFMAs;
 //   * epilogue: accumulator * (1/row scale) * (1/column scale), bias / ReLU / mask, stores, running column maxima of the
 //     output (for the weight-gradient kernel's scales): one atomicMax per column and workgroup at the very end.
-// Waves w and w + 4 share a SIMD and run the two roles in opposite order inside a tile step (one does split + loads
-// while the other multiplies), one barrier per tile.
+// Waves w and w + 4 share a SIMD and run the two halves of a tile step in opposite order (one does its VALU work --
+// split, loads, stores -- while the other multiplies), one barrier per tile.
 // wave-wide maxima of FOUR non-negative floats at once (valid in lane 63): the four DPP chains are interleaved, so each
 // stage's instructions fill the two wait states a DPP read needs after a VALU write of the same register
 __device__ __forceinline__ void wave_max4_nonneg_lane63(float& a, float& b, float& c, float& d) {
@@ -158,23 +158,31 @@ __device__ __forceinline__ void wave_max4_nonneg_lane63(float& a, float& b, floa
 #undef DGM_ST
 }
 
-// epilogue of one 32 x 32 accumulator tile (lane: column li of the wave's 32, rows (r & 3) + 8 (r >> 2) + 4 g)
-template <int EPI, bool FULL>
-__device__ __forceinline__ void gemm3r_epilogue(f32x16& acc, const float* rinv_t, const unsigned* mlds_w, int row0, int M,
-                                                float* __restrict__ cb, unsigned* __restrict__ mb, int g, int li, float binv,
-                                                float bv, float& cmax) {
-    unsigned mwsel = 0u;
+// first half of the epilogue, right after the MFMA phase (the row scales of the tile are still in LDS):
+// accumulator * (1 / row scale) * (1 / column scale)
+__device__ __forceinline__ void gemm3r_unscale(f32x16& acc, const float* rinv_t, int g, float binv) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float4 iv = *reinterpret_cast<const float4*>(rinv_t + q * 8 + 4 * g);
-        const float ivs[4] = {iv.x * binv, iv.y * binv, iv.z * binv, iv.w * binv};
+        acc[q * 4 + 0] *= iv.x * binv, acc[q * 4 + 1] *= iv.y * binv, acc[q * 4 + 2] *= iv.z * binv, acc[q * 4 + 3] *= iv.w * binv;
+    }
+}
+
+// second half: bias / ReLU / mask bits (EPI 0) or mask application (EPI 1), stores, running column maximum.
+// lane: column li of the wave's 32, rows (r & 3) + 8 (r >> 2) + 4 g
+template <int EPI, bool FULL>
+__device__ __forceinline__ void gemm3r_store(const f32x16& acc, const unsigned* mlds_w, int row0, int M, float* __restrict__ cb,
+                                             unsigned* __restrict__ mb, int g, int li, float bv, float& cmax) {
+    unsigned mwsel = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
         uint4 mq = make_uint4(0u, 0u, 0u, 0u);
         if (EPI == 1) mq = *reinterpret_cast<const uint4*>(mlds_w + q * 8 + 4 * g);
         const unsigned mws[4] = {mq.x, mq.y, mq.z, mq.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int r = q * 4 + e, ro = e + 8 * q;
-            float v = acc[r] * ivs[e];
+            float v = acc[r];
             if (EPI == 0) {
                 v = fmaxf(v + bv, 0.f);
                 const unsigned long long bal = __ballot(v > 0.f);  // low half: rows of g = 0, high half: g = 1
@@ -293,18 +301,17 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bh[ks], acc, 0, 0, 0);                           \
         }                                                                                                              \
     }
-#define R3_EPILOGUE(pb_, tile_)                                                                                        \
+#define R3_UNSCALE(pb_) gemm3r_unscale(acc, rinv + (pb_) * 32, g, binv);
+#define R3_STORE(tile_)                                                                                                \
     {                                                                                                                  \
         const int row0_ = (tile_) * 32 + 4 * g;                                                                        \
         float* cb_ = C + (size_t)row0_ * 256 + col;                                                                    \
         unsigned* mb_ = mask + (size_t)row0_ * 8 + wv;                                                                 \
         if (EPI == 1) mlds[wv * 32 + li] = mword; /* both halves write the same 32 words; read back by this wave only */ \
-        if ((tile_) * 32 + 32 <= M)                                                                                    \
-            gemm3r_epilogue<EPI, true>(acc, rinv + (pb_) * 32, mlds + wv * 32, row0_, M, cb_, mb_, g, li, binv, bv, cmax); \
-        else                                                                                                           \
-            gemm3r_epilogue<EPI, false>(acc, rinv + (pb_) * 32, mlds + wv * 32, row0_, M, cb_, mb_, g, li, binv, bv, cmax); \
+        if ((tile_) * 32 + 32 <= M) gemm3r_store<EPI, true>(acc, mlds + wv * 32, row0_, M, cb_, mb_, g, li, bv, cmax);   \
+        else gemm3r_store<EPI, false>(acc, mlds + wv * 32, row0_, M, cb_, mb_, g, li, bv, cmax);                       \
     }
-    // EPI 1: the tile's 32 mask words of this wave's column group, one per lane, requested before the MFMA phase
+    // EPI 1: the tile's 32 mask words of this wave's column group, one per lane, requested a phase before their use
 #define R3_MASK(tile_)                                                                                                 \
     if (EPI == 1) {                                                                                                    \
         int mrow_ = (tile_) * 32 + li;                                                                                 \
@@ -327,37 +334,59 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
             if (my_tiles > 2) R3_LOAD(0, blockIdx.x + 2 * G)
         }
     }
+    if (wv < 4 && my_tiles > 0) R3_MASK(blockIdx.x)
     __syncthreads();
-    // one tile step; SLOT_ = register slot holding tile j + 1 (compile-time: two steps per loop trip)
+    // One tile step.  Waves w and w + 4 share a SIMD and run the two halves of a step in opposite order, so that one
+    // multiplies while the other does its VALU work:
+    //   waves 0..3:  [ MFMA(j), unscale ]                     [ split(j+1), store(j), loads(j+1+PF) ]   barrier
+    //   waves 4..7:  [ split(j+1), store(j-1), loads(..) ]    [ MFMA(j), unscale ]                      barrier
+    // (the high waves keep tile j's scaled accumulators across the barrier and store them in the next step).
+    // Memory-counter discipline (gfx9's vmcnt counts loads AND stores; with both kinds pending the compiler can only wait
+    // with vmcnt(0)):  the one wait of a step sits at the top of split(), where everything outstanding -- the tile's row
+    // loads, the mask words, the previous stores -- was issued at least one MFMA phase earlier; new stores and then new
+    // loads are issued after it and nothing touches their results before the next step's split.  The barrier is an
+    // LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also drain vmcnt, i.e. stall every wave
+    // on the loads it has just prefetched.
+    // SLOT_ = register slot holding tile j + 1 (compile-time: two steps per loop trip).
+#define R3_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define R3_STEP(j_, SLOT_)                                                                                             \
     {                                                                                                                  \
         const int tile = blockIdx.x + (j_) * G;                                                                        \
         const int pb = (j_) & 1;                                                                                       \
-        R3_MASK(tile)                                                                                                  \
         if (wv < 4) {                                                                                                  \
-            if ((j_) + 1 < my_tiles) {                                                                                 \
-                R3_SPLIT(SLOT_, pb ^ 1)                                                                                \
-                if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                      \
-            }                                                                                                          \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            __builtin_amdgcn_s_setprio(0);                                                                             \
             R3_MFMA(pb)                                                                                                \
-            R3_EPILOGUE(pb, tile)                                                                                      \
+            R3_UNSCALE(pb)                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            __builtin_amdgcn_s_setprio(3);                                                                             \
+            if ((j_) + 1 < my_tiles) R3_SPLIT(SLOT_, pb ^ 1)                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            R3_STORE(tile)                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                          \
+            if ((j_) + 1 < my_tiles) R3_MASK(tile + G)                                                                 \
         } else {                                                                                                       \
-            R3_MFMA(pb)                                                                                                \
-            R3_EPILOGUE(pb, tile)                                                                                      \
+            __builtin_amdgcn_s_setprio(3);                                                                             \
+            if ((j_) + 1 < my_tiles) R3_SPLIT(SLOT_, pb ^ 1)                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
-            if ((j_) + 1 < my_tiles) {                                                                                 \
-                R3_SPLIT(SLOT_, pb ^ 1)                                                                                \
-                if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                      \
-            }                                                                                                          \
+            if ((j_) > 0) R3_STORE(tile - G)                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                          \
+            R3_MASK(tile)                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            __builtin_amdgcn_s_setprio(0);                                                                             \
+            R3_MFMA(pb)                                                                                                \
+            R3_UNSCALE(pb)                                                                                             \
         }                                                                                                              \
-        __syncthreads();                                                                                               \
+        R3_LDS_BARRIER();                                                                                              \
     }
     for (int j = 0; j < my_tiles; j += 2) {
         R3_STEP(j, PF - 1)          // tile j + 1 (odd) lives in slot 1 (PF == 2) / slot 0 (PF == 1)
         if (j + 1 < my_tiles) R3_STEP(j + 1, 0)
     }
+    if (wv >= 4 && my_tiles > 0) R3_STORE(blockIdx.x + (my_tiles - 1) * G)
 #undef R3_STEP
+#undef R3_LDS_BARRIER
     if (colmax != nullptr) {
         // lanes li and li + 32 hold the same column: fold, then one atomic per column and workgroup
         const float o = __shfl_xor(cmax, 32, 64);
@@ -367,7 +396,8 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
 #undef R3_LOAD
 #undef R3_SPLIT
 #undef R3_MFMA
-#undef R3_EPILOGUE
+#undef R3_UNSCALE
+#undef R3_STORE
 #undef R3_MASK
 }
 

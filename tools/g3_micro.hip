@@ -43,7 +43,7 @@ int main() {
     CK(hipMalloc(&binv, 1024));
     CK(hipMalloc(&bias, 1024));
     CK(hipMalloc(&mask, (size_t)M * 32));
-    CK(hipMalloc(&cmax, 1024));
+    CK(hipMalloc(&cmax, 4096));
     std::vector<float> h((size_t)M * 256);
     for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.3f;
     CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
@@ -66,6 +66,14 @@ int main() {
     RUN(1, 1, "bwd no MFMA")
     RUN(1, 2, "bwd no stores")
     RUN(1, 10, "bwd no stores, no loads")
+    {
+        run<0, 16>(M, ncu, A, Bp, binv, bias, mask, C, cmax);
+        unsigned long long hd[16];
+        CK(hipMemcpy(hd, cmax + 256, 128, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 2; w++)
+            printf("timing wave %d (%llu tiles): vmcnt-wait %llu  split %llu  mfma %llu  store(+loads) %llu  barrier %llu  cycles per tile\n", w * 4, hd[w * 8 + 5],
+                   hd[w * 8 + 4] / hd[w * 8 + 5], hd[w * 8 + 0] / hd[w * 8 + 5], hd[w * 8 + 1] / hd[w * 8 + 5], hd[w * 8 + 2] / hd[w * 8 + 5], hd[w * 8 + 3] / hd[w * 8 + 5]);
+    }
     // plain copy of the same bytes for reference
     {
         hipEvent_t a, b;
