@@ -40,15 +40,16 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* r
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib);
-void launch_render_bwd2(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
-                        int gridx, const float* bg, const float* rec, const float* final_T, const unsigned* n_contrib,
-                        const float* dL_dpix, float* slab, unsigned* nproc);
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, unsigned* nproc);
+// render_bwd3.hip
+void launch_render_bwd3(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
+                        int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
+                        const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc, float* slab);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
-                           const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                           const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
                            const float* rec, const unsigned* tiles_touched, const unsigned* offs, const unsigned* inv,
                            const float* slab, const uint2* ranges, const unsigned* nproc, float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
@@ -288,6 +289,8 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
     float* final_T = (float*)(img + L.final_T);
     unsigned* n_contrib = (unsigned*)(img + L.n_contrib);
     uint2* ranges = (uint2*)(img + L.ranges);
+    unsigned* nproc = (unsigned*)(img + L.nproc);
+    float4* cfin = (float4*)(img + L.cfin);
 
     if (P == 0) {  // reference: kernels skipped, rendered = 0, out_color stays 0 (rasterize_points.cu:68,81)
         DGM_HIP(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), st));
@@ -354,6 +357,7 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
     unsigned long long* keys = (unsigned long long*)(bin + L.keys);
     unsigned* point_list = (unsigned*)(bin + L.point_list);
     unsigned* inv = (unsigned*)(bin + L.inv);
+    float4* ckpt = (float4*)(bin + L.ckpt);
 
     tm.begin(DGM_STAGE_BIN_COUNT);
     DGM_HIP(launch_count(st, P, L.chunk_size, L.n_chunks, tiles, gridx, tiles_touched, rec, block_offs, offs, hist));
@@ -380,7 +384,7 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
 
     tm.begin(DGM_STAGE_RENDER_FWD);
     launch_render_fwd(st, tiles, ranges, point_list, width, height, gridx, rec, background, out_color, final_T,
-                      n_contrib);
+                      n_contrib, ckpt, cfin, nproc);
     DGM_CHECK("render_fwd");
     tm.end(DGM_STAGE_RENDER_FWD);
     tm.finish();
@@ -419,10 +423,11 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
     const unsigned* point_list = (const unsigned*)(bin + L.point_list);
     const unsigned* inv = (const unsigned*)(bin + L.inv);
     float* slab = (float*)(bin + L.slab);
-    const float* final_T = (const float*)(img + L.final_T);
     const unsigned* n_contrib = (const unsigned*)(img + L.n_contrib);
     const uint2* ranges = (const uint2*)(img + L.ranges);
-    unsigned* nproc = (unsigned*)(img + L.nproc);
+    const unsigned* nproc = (const unsigned*)(img + L.nproc);
+    const float4* cfin = (const float4*)(img + L.cfin);
+    const float4* ckpt = (const float4*)(bin + L.ckpt);
     if (!radii) radii = radii_int;  // rasterizer_impl.cu:375-378
 
     const float focal_y = height / (2.0f * tan_fovy);
@@ -430,8 +435,8 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
 
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
-    launch_render_bwd2(st, tiles, ranges, point_list, width, height, gridx, background, rec, final_T, n_contrib,
-                       dL_dpix, slab, nproc);
+    launch_render_bwd3(st, tiles, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, n_contrib,
+                       dL_dpix, nproc, slab);
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);
 
@@ -440,7 +445,7 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
     // with precomputed colours the SH branch is skipped (backward.cu:390: `if (shs)`)
     launch_preprocess_bwd(st, P, D, M, gridx, means3D, radii, colors_precomp ? nullptr : shs, clamped, scales, rotations,
                           scale_modifier, cov3D_ptr, viewmatrix, projmatrix, campos, focal_x, focal_y, tan_fovx,
-                          tan_fovy, rec, tiles_touched, offs, inv, slab, ranges, nproc, dL_dmean2D, dL_dconic,
+                          tan_fovy, width, height, rec, tiles_touched, offs, inv, slab, ranges, nproc, dL_dmean2D, dL_dconic,
                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     DGM_CHECK("preprocess_bwd");
     tm.end(DGM_STAGE_PREPROCESS_BWD);

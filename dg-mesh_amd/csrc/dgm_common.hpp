@@ -62,12 +62,14 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->point_list = take(Rz * 4);
     L->inv = take(Rz * 4);
     L->slab = take(Rz * DGM_SLAB_STRIDE * 4);
+    L->ckpt = take((Rz / 256 + 1) * 256 * 16);  // per (tile, 256-entry round boundary): (T, C) of the tile's 256 pixels
     L->binning_bytes = o + A;
     o = 0;
     L->final_T = take((size_t)W * H * 4);
     L->n_contrib = take((size_t)W * H * 4);
     L->ranges = take(tiles * 8);
     L->nproc = take(tiles * 4);
+    L->cfin = take(tiles * 256 * 16);  // final (T, C) per pixel, tile-major in the backward's lane order
     L->image_bytes = o + A;
 }
 

@@ -29,7 +29,7 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
                       const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
                       const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
                       const float* __restrict__ cov3Ds, const float* __restrict__ vm, const float* __restrict__ proj,
-                      const float* __restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy,
+                      const float* __restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, int W, int H,
                       const float* __restrict__ rec, const unsigned* __restrict__ tiles_touched,
                       const unsigned* __restrict__ offs, const unsigned* __restrict__ inv,
                       const float* __restrict__ slab, const uint2* __restrict__ ranges,
@@ -119,6 +119,22 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
                     }
                 }
             }
+        }
+        if (live) {
+            // render_bwd3 rows hold colour sums and the moments of g = G dL/dalpha about the splat centre
+            // (d = xy - pixel): acc[3..8] = sum g dx, g dy, g dx^2, g dx dy, g dy^2, g.  The gradients of
+            // backward.cu:536-554 are linear in them with per-Gaussian coefficients (dL/dG = opacity dL/dalpha):
+            //   dL/dmean2D = -o (a Mx + b My) W/2,  -o (c My + b Mx) H/2        (dG/ddel = -G (a dx + b dy), ...)
+            //   dL/dconic  = -o/2 (Mxx, Mxy, Myy),   dL/dopacity = M0
+            const float4 r0 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[0];
+            const float4 r1 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[1];
+            const float ca = r0.z, cb = r0.w, cc = r1.x, op = r1.y;
+            const float mx = acc[3], my = acc[4];
+            acc[3] = -op * (ca * mx + cb * my) * (0.5f * W);
+            acc[4] = -op * (cc * my + cb * mx) * (0.5f * H);
+            acc[5] *= -0.5f * op;
+            acc[6] *= -0.5f * op;
+            acc[7] *= -0.5f * op;
         }
         // outputs of the blend backward (reference: atomically accumulated arrays)
         dL_dcolor[3 * idx + 0] = acc[0];
@@ -386,7 +402,7 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
-                           const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                           const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
                            const float* rec, const unsigned* tiles_touched, const unsigned* offs, const unsigned* inv,
                            const float* slab, const uint2* ranges, const unsigned* nproc, float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
@@ -395,7 +411,7 @@ void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const
     const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, gridx, means3D,
                        radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, viewmatrix, projmatrix, campos,
-                       focal_x, focal_y, tan_fovx, tan_fovy, rec, tiles_touched, offs, inv, slab, ranges, nproc,
+                       focal_x, focal_y, tan_fovx, tan_fovy, W, H, rec, tiles_touched, offs, inv, slab, ranges, nproc,
                        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
 }
 

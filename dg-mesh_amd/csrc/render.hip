@@ -1,4 +1,4 @@
-// Tile alpha-compositing for gfx950: the forward blend (the backward replay lives in render_bwd2.hip).
+// Tile alpha-compositing for gfx950: the forward blend (the backward replay lives in render_bwd3.hip).
 //
 // Replaces FORWARD::render / renderCUDA<3> (DGR/cuda_rasterizer/forward.cu:263-374).  Same tile size (16x16), same
 // per-pixel arithmetic (power, alpha = min(.99, o*exp(power)), 1/255 and 1e-4 thresholds, n_contrib / final_T
@@ -24,11 +24,13 @@ namespace dgm {
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-                  float* __restrict__ final_T, unsigned* __restrict__ n_contrib) {
+                  float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
+                  float4* __restrict__ cfin, unsigned* __restrict__ nproc_out) {
     __shared__ float4 sA[256];  // x, y, conic a, conic b
     __shared__ float4 sB[256];  // conic c, opacity, r, g
     __shared__ float sC[256];   // b
     __shared__ unsigned long long sMask[4][4];  // [staging wave][quadrant]
+    __shared__ unsigned sMaxC[4];               // per-wave maximum of last_contributor
     const int tile = blockIdx.x;
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -47,6 +49,14 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
     for (int i = 0; i < rounds; i++) {
         if (__syncthreads_and(done)) break;  // also orders the previous round's LDS reads before the refill
+        if (i > 0) {
+            // state after the first 256 i list entries, for the segment-parallel backward (render_bwd3.hip): slot
+            // floor((range.x + 256 i) / 256) is unique per (tile, i); pixel order = the backward's lane mapping
+            // (row = 4 j + (l >> 4), column = l & 15  ->  index 64 j + l)
+            const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
+            const size_t slot = (size_t)((range.x + ((unsigned)i << 8)) >> 8);
+            ckpt[slot * 256 + (size_t)((ly >> 2) * 64 + ((ly & 3) << 4) + lx)] = make_float4(T, C0, C1, C2);
+        }
         const int at = (i << 8) + threadIdx.x;
         unsigned qm = 0;
         if (at < n) {
@@ -96,6 +106,16 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             }
         }
     }
+    {   // per-tile bound of the backward replay: the deepest contributor index of any pixel
+        const unsigned m = wave_max_u32(inside ? last_contributor : 0u);
+        if (lane == 0) sMaxC[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) nproc_out[tile] = min(max(max(sMaxC[0], sMaxC[1]), max(sMaxC[2], sMaxC[3])), (unsigned)n);
+    }
+    {   // final state (T, C without background) in the backward's pixel order, for every lane of the tile
+        const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
+        cfin[(size_t)tile * 256 + (size_t)((ly >> 2) * 64 + ((ly & 3) << 4) + lx)] = make_float4(T, C0, C1, C2);
+    }
     if (inside) {
         const size_t pid = (size_t)W * py + px;
         const size_t plane = (size_t)W * H;
@@ -109,9 +129,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib) {
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, unsigned* nproc) {
     hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                       out_color, final_T, n_contrib);
+                       out_color, final_T, n_contrib, ckpt, cfin, nproc);
 }
 
 }  // namespace dgm

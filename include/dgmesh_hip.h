@@ -112,13 +112,17 @@ typedef struct {
     size_t keys;       /* u64[R]  (depth_bits << 32 | gaussian), grouped by tile, unsorted within a tile */
     size_t point_list; /* u32[R]  gaussian ids, by tile then depth then id: identical to the reference's */
     size_t inv;        /* u32[R]  inv[offs[g] + k] = slot of g's k-th tile instance in point_list */
-    size_t slab;       /* float[R][12] per-instance gradient rows written by backward */
+    size_t slab;       /* float[R][12] per-instance gradient rows written by backward: colour r,g,b | moments of
+                          g = G dL/dalpha about the splat centre: 1, dx, dy, dx^2, dx dy, dy^2 | 3 pad */
+    size_t ckpt;       /* float4[R/256 + 1][256]: (T, C.rgb) of a tile's pixels after each 256 list entries (forward ->
+                          segment-parallel backward) */
     size_t binning_bytes;
     /* image buffer */
     size_t final_T;   /* float[H*W] */
     size_t n_contrib; /* u32[H*W] */
     size_t ranges;    /* uint2[tiles] */
-    size_t nproc;     /* u32[tiles] instances replayed by backward */
+    size_t nproc;     /* u32[tiles] list entries the backward has to replay (deepest contributor of the tile) */
+    size_t cfin;      /* float4[tiles][256]: final (T, C.rgb without background) per pixel, backward lane order */
     size_t image_bytes;
     int tiles_x, tiles_y, n_chunks, chunk_size;
 } dgm_state_layout;
