@@ -61,6 +61,10 @@ SYMBOLS = {
     "dgm_cycle_loss_forward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_cycle_loss_backward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dgm_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp]),
+    "dgm_densify_scratch_bytes": (_c.c_size_t, [_i]),
+    "dgm_densify_totals_offset": (_c.c_size_t, [_i]),
+    "dgm_densify_decide": (_i, [_i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "dgm_densify_apply": (_i, [_i, _c.c_uint, _c.c_uint, _c.c_uint, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "dgm_mlp_set_gemm": (_i, [_i]),
     "dgm_timenet_forward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_timenet_backward": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -5,8 +5,8 @@
                      :679-682 (add_densification_stats)
   render()        <- R/gaussian_renderer/__init__.py:32-119 (same signature, same returned dict)
   l1_loss / ssim  <- R/utils/loss_utils.py:18-19, 32-76
-(R/ = /root/reference/dgmesh/.)  Mesh branch (DPSR / DiffMC / nvdiffrast), densification surgery, PLY I/O and
-dataset readers are out of scope.
+(R/ = /root/reference/dgmesh/.)  Densification / pruning: densify.py.  Mesh branch (DiffMC / nvdiffrast) and dataset
+readers are out of scope.
 """
 import math
 from math import exp
@@ -155,6 +155,19 @@ class GaussianModel:
                 group["lr"] = self.normal_scheduler_args(iteration)
             elif group["name"] == "rotation":
                 group["lr"] = self.rotation_scheduler_args(iteration)
+
+    # -- densification / pruning / opacity reset (gaussian_model_dpsr_dynamic_anchor.py:291-294, 383-551) on the device --
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        from . import densify
+        return densify.densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator)
+
+    def prune_points(self, mask):
+        from . import densify
+        return densify.prune_points(self, mask)
+
+    def reset_opacity(self):
+        from . import densify
+        densify.reset_opacity(self)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,

@@ -3,7 +3,8 @@
 Single-rank semantics follow R/train.py:129-321 and :517-530 (R/ = /root/reference/dgmesh/):
   lr update -> pick camera -> deform MLP (iteration >= warm_up) -> render -> deform_back MLP + cycle losses ->
   0.8*L1 + 0.2*(1-SSIM) -> backward -> Adam steps (eps 1e-15) -> zero grads.
-The mesh branch (iteration >= dpsr_iter: DPSR / DiffMC / nvdiffrast) is out of scope, and
+Densification / pruning / opacity reset run inside the loop when `densify=True` (densify.py).  The mesh branch
+(iteration >= dpsr_iter: DiffMC / nvdiffrast) is out of scope, and
 host synchronisations of the reference's loop that do not change results are dropped
 (torch.cuda.empty_cache() every iteration, R/train.py:130; get_psnr's .item(), :315).
 
@@ -46,17 +47,19 @@ class FlatGradBucket:
 
     def pack(self):
         """Copy the parameters' current .grad tensors into the bucket (one multi-tensor kernel); absent gradients
-        count as zero.  Returns {id(param): view}."""
-        src, dst = [], []
+        count as zero in the exchange.  Returns {id(param): view} for the parameters that HAD a gradient (a parameter
+        without one is not stepped, like torch.optim.Adam)."""
+        src, dst, out = [], [], {}
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
             else:
                 src.append(p.grad)
                 dst.append(v)
+                out[id(p)] = v
         if src:
             torch._foreach_copy_(dst, src)
-        return {id(p): v for p, v in zip(self.params, self.views)}
+        return out
 
     def zero(self):
         self.flat.zero_()
@@ -80,7 +83,8 @@ def frame_schedule(n_frames, step, rank, world, seed=0):
 class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
-                 process_group=None, fused_loss=True, fused_glue=None, track_stats=True):
+                 process_group=None, fused_loss=True, fused_glue=None, track_stats=True, densify=False,
+                 cameras_extent=1.0, prune_threshold=0.005, white_background=True):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
         self.cameras = cameras
         self.opt = opt or S.OptimizationParams()
@@ -92,6 +96,9 @@ class Trainer:
         self.group = process_group
         self.fused_loss = fused_loss
         self.track_stats = track_stats
+        # densification / pruning / opacity reset inside the loop (R/train.py:488-515); off = fixed-P steps (bench.py)
+        self.densify = densify
+        self.cameras_extent, self.prune_threshold, self.white_background = cameras_extent, prune_threshold, white_background
         self.step_count = 0
         # fused per-Gaussian glue (activations + deformation, cycle loss): GPU, stock render(), plain (non-6dof) networks
         self.fused_glue = bool(fused_glue) if fused_glue is not None else (
@@ -106,6 +113,21 @@ class Trainer:
         if fused:  # same update rule, ONE kernel for every tensor of the three optimizers
             from .optim import MultiAdam
             self.multi_adam = MultiAdam(self.optimizers)
+        self.pack = self.multi_adam is not None
+        self._bind_parameters()
+        # normal samples of densify_and_split: one generator per rank, seeded alike, advanced in lockstep
+        self.densify_generator = None
+        if dev.type == "cuda":
+            self.densify_generator = torch.Generator(device=dev)
+            self.densify_generator.manual_seed(1234567 + seed)
+        self.time_interval = 1.0 / max(len(cameras), 1)
+        from .deform import get_linear_noise_func
+        self.smooth_term = get_linear_noise_func(lr_init=0.1, lr_final=1e-15, lr_delay_mult=0.01, max_steps=20000)
+
+    def _bind_parameters(self):
+        """(Re)collect the parameters that receive gradients and (re)build the flat gradient bucket; called at start and
+        after every change of the Gaussian set (densify / prune / opacity reset replace Parameter objects)."""
+        gaussians, deform, deform_back = self.g, self.deform, self.deform_back
         # parameters that receive gradients in the Gaussian branch (the normal parameter is only used by the
         # mesh branch; leaving its .grad None mirrors zero_grad(set_to_none=True))
         params = [gaussians._xyz, gaussians._features_dc, gaussians._features_rest, gaussians._opacity,
@@ -113,11 +135,25 @@ class Trainer:
         params += list(deform.net.parameters()) + list(deform_back.net.parameters())
         self.params = [p for p in params if p.requires_grad]
         # "pack": gradients are fresh tensors every step (no accumulate kernels); "views": .grad lives in the bucket
-        self.pack = self.multi_adam is not None
-        self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or world > 1) else None
-        self.time_interval = 1.0 / max(len(cameras), 1)
-        from .deform import get_linear_noise_func
-        self.smooth_term = get_linear_noise_func(lr_init=0.1, lr_final=1e-15, lr_delay_mult=0.01, max_steps=20000)
+        self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or self.world > 1) else None
+
+    def maybe_densify(self, iteration):
+        """R/train.py:499-515: every densification_interval iterations after densify_from_iter clone / split / prune
+        (statistics of all ranks' frames summed first), and the periodic opacity reset.  Returns True if the Gaussian
+        set was replaced (their gradients of this iteration are dropped, exactly like the reference, where the new
+        Parameters have .grad None when optimizer.step() runs)."""
+        opt, g = self.opt, self.g
+        changed = False
+        if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+            self.sync_densification_stats()
+            size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+            g.densify_and_prune(opt.densify_grad_threshold, self.prune_threshold, self.cameras_extent, size_threshold,
+                                generator=self.densify_generator)
+            changed = True
+        if iteration % opt.opacity_reset_interval == 0 or (self.white_background and iteration == opt.densify_from_iter):
+            g.reset_opacity()
+            changed = True
+        return changed
 
     def sync_densification_stats(self):
         """Before a densify/prune decision every rank must see the statistics of ALL frames:
@@ -191,17 +227,22 @@ class Trainer:
         losses, pkg = self.loss_terms(cam, iteration)
         loss = sum(losses.values())
         loss.backward()
+        rebound = False
         if self.track_stats and iteration < self.opt.densify_until_iter:  # R/train.py:488-496
             g.track_densification_stats(pkg.get("viewspace_points"), pkg["visibility_filter"], pkg["radii"])
+            if self.densify:
+                rebound = self.maybe_densify(iteration)
         grads = None
         if self.world > 1:
             if self.pack:
-                grads = self.bucket.pack()
+                grads = self.bucket.pack()  # replaced Parameters are not in this (old) bucket: no update for them
             self.bucket.all_reduce(self.group)
         if self.multi_adam is not None:
             self.multi_adam.step(grads)
         else:
             for o in self.optimizers:
                 o.step()
+        if rebound:
+            self._bind_parameters()
         self.step_count += 1
         return loss.detach(), pkg

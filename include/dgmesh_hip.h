@@ -257,6 +257,28 @@ int dgm_adam_step(int n_tensors, float* const* params, const float* const* grads
                   float* const* exp_avg_sq, const long long* numel, const float* lr, const int* step, float beta1,
                   float beta2, float eps, void* stream);
 
+/* ---- densification / pruning on the device (csrc/densify.hip) ----------------------------------------------------------
+ * Replaces GaussianModelDPSRDynamicAnchor.densify_and_prune / prune_points
+ * (dgmesh/scene/gaussian_model_dpsr_dynamic_anchor.py:383-551): decide keep / clone / split / prune per Gaussian, scan,
+ * then gather every parameter and Adam moment into the final set with one multi-tensor launch.
+ *   dgm_densify_decide: grad = grad_accum / denom (NaN -> 0); clone if grad >= thr and max(exp(scaling)) <= dense_extent,
+ *     split if grad >= thr and larger; pruned if sigmoid(opacity) < min_opacity or max(exp(scaling)) > big_extent
+ *     (pass +inf to switch the size limit off).  With keep_mask != NULL (bytes 0/1, device) the decision is the mask
+ *     (prune_points).  After the stream reaches this point the three u32 at scratch + dgm_densify_totals_offset(P) hold
+ *     the numbers of kept originals K, kept clones C and kept split parents S; new size = K + C + 2 S, ordered
+ *     [originals | clones | first children | second children] like the reference's cat / prune sequence.
+ *   dgm_densify_apply: out[t][j] = in[t][source(j)] for all n_tensors (<= 24) tensors of row width width[t] floats; rows of
+ *     new points are zero where is_moment[t] != 0; the xyz / scaling rows of split children are rewritten from the
+ *     caller's standard-normal samples z[2][P][3] (device).  src_scratch: (K + C + 2 S) * 4 bytes. */
+size_t dgm_densify_scratch_bytes(int P);
+size_t dgm_densify_totals_offset(int P);
+int dgm_densify_decide(int P, const float* grad_accum, const float* denom, const float* scaling, const float* opacity,
+                       float grad_threshold, float dense_extent, float min_opacity, float big_extent,
+                       const uint8_t* keep_mask, char* scratch, void* stream);
+int dgm_densify_apply(int P, unsigned K, unsigned C, unsigned S, const char* scratch, unsigned* src_scratch, int n_tensors,
+                      const float* const* in, float* const* out, const int* width, const int* is_moment, int xyz_index,
+                      int scaling_index, int rotation_index, const float* z, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
