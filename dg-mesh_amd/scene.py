@@ -156,6 +156,38 @@ class GaussianModel:
             elif group["name"] == "rotation":
                 group["lr"] = self.rotation_scheduler_args(iteration)
 
+    # -- PLY checkpoints (gaussian_model_dpsr_dynamic_anchor.py:238-289, 296-362): same elements / property names --
+    def save_ply(self, path):
+        from . import ply_io
+        n = lambda t: t.detach().cpu().numpy().astype(np.float32)
+        ply_io.save_gaussians(path, n(self._xyz), n(self._normal), n(self._features_dc), n(self._features_rest), n(self._opacity),
+                              n(self._scaling), n(self._rotation), float(getattr(self, "density_thres_param", 0.0)),
+                              tuple(float(v) for v in torch.as_tensor(getattr(self, "gaussian_center", [0.0, 0.0, 0.0])).reshape(-1).tolist()),
+                              float(torch.as_tensor(getattr(self, "gaussian_scale", 1.0)).reshape(-1)[0]))
+
+    def load_ply(self, path, og_number_points=-1, iteration=-1):
+        """`path` is either a .ply file or a model directory laid out like the reference
+        (<path>/point_cloud/iteration_<N>/point_cloud.ply, newest iteration when iteration == -1)."""
+        import os
+        from . import ply_io
+        if os.path.isdir(path):
+            root = os.path.join(path, "point_cloud")
+            if iteration == -1:  # searchForMaxIteration, R/utils/system_utils.py:29-31
+                iteration = max(int(f.split("_")[-1]) for f in os.listdir(root))
+            path = os.path.join(root, f"iteration_{iteration}", "point_cloud.ply")
+        d = ply_io.load_gaussians(path, self.max_sh_degree)
+        self.og_number_points = og_number_points
+        self.load_raw(d["xyz"], d["features_dc"], d["features_rest"], d["scaling"], d["rotation"], d["opacity"], d["normal"])
+        dev = self.device
+        self.density_thres_param = torch.tensor(float(d["density_thres"]), dtype=torch.float32, device=dev)
+        self.gaussian_center = torch.tensor(d["gaussian_center"], dtype=torch.float32, device=dev)
+        self.gaussian_scale = torch.tensor(float(d["gaussian_scale"]), dtype=torch.float32, device=dev)
+        P = self._xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+        self.denom = torch.zeros((P, 1), device=dev)
+        self.max_radii2D = torch.zeros((P,), device=dev)
+        self.active_sh_degree = self.max_sh_degree
+
     # -- densification / pruning / opacity reset (gaussian_model_dpsr_dynamic_anchor.py:291-294, 383-551) on the device --
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
         from . import densify

@@ -84,6 +84,24 @@ def raster_golden():
     print("wrote raster_small", f["num_rendered"])
 
 
+
+
+def state_dict_layouts():
+    """Key order and shapes of the reference modules' state_dict (what DeformModel*.load_weights must accept)."""
+    import json
+    sys.path.insert(0, "/root/reference/dgmesh")
+    from utils import time_utils as ref
+
+    out = {}
+    for cls in ("DeformNetwork", "DeformNetworkNormal", "DeformNetworkNormalSep", "AppearanceNetwork"):
+        for blender in (True, False):
+            net = getattr(ref, cls)(is_blender=blender)
+            out[f"{cls}/{'blender' if blender else 'real'}"] = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    json.dump(out, open(os.path.join(HERE, "state_dict_layouts.json"), "w"), indent=0)
+    print("wrote state_dict_layouts.json")
+
+
 if __name__ == "__main__":
     mlp_goldens()
     raster_golden()
+    state_dict_layouts()
