@@ -583,6 +583,7 @@ struct Ws {
     uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
     float *wsc_f[8], *wsc_d[8];            // their inverse column scales
     unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
+    unsigned *cmaxW;                       // [16][256] column maxima of the weight matrices (prep3 pass 1)
     unsigned* mask[8];
     size_t bytes;
 };
@@ -677,6 +678,7 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.wsc_d[l] = take(MLP_W * 4);
     w.cmaxY = (unsigned*)take(8 * MLP_W * 4);
     w.cmaxG = (unsigned*)take(8 * MLP_W * 4);
+    w.cmaxW = (unsigned*)take(PREP3_MAX_JOBS * MLP_W * 4);
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     w.partial_h = take((size_t)hchunks * 16 * MLP_W * 4);
     w.partial_hb = take((size_t)hchunks * 16 * 4);
@@ -765,8 +767,12 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         add(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh6b);
         hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
         if (n3 > 0) {
-            hipLaunchKernelGGL(mlp_prep3_batch_kernel, dim3(MLP_W / 64, n3), dim3(64), 0, st, p3);
-            if (hipMemsetAsync(w.cmaxY, 0, 8 * MLP_W * 4, st) != hipSuccess) return mlp_fail("mlp_forward: memset failed");
+            // cmaxY | cmaxG | cmaxW are adjacent in the workspace: one fill clears the forward's two
+            if (hipMemsetAsync(w.cmaxY, 0, 8 * MLP_W * 4, st) != hipSuccess || hipMemsetAsync(w.cmaxW, 0, PREP3_MAX_JOBS * MLP_W * 4, st) != hipSuccess)
+                return mlp_fail("mlp_forward: memset failed");
+            const int pthreads = (MLP_EMB + MLP_W) / 8 * MLP_W;
+            hipLaunchKernelGGL(mlp_prep3_max_kernel, dim3((pthreads + 255) / 256, n3), dim3(256), 0, st, p3, w.cmaxW);
+            hipLaunchKernelGGL(mlp_prep3_batch_kernel, dim3((pthreads + 255) / 256, n3), dim3(256), 0, st, p3, (const unsigned*)w.cmaxW);
             if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_forward: cannot raise the LDS limit of mlp_gemm3r_kernel");
         }
     }
@@ -793,7 +799,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
                 hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2,
                                    lda2, K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W);
                 if (use_f16x3())  // this producer does not deliver the column maxima the next layer's dW scales need
-                    hipLaunchKernelGGL(mlp_colmax_kernel, dim3(num_cus()), dim3(256), 0, st, N, MLP_W, w.Y[l], MLP_W,
+                    hipLaunchKernelGGL(mlp_colmax_kernel, dim3(4 * num_cus()), dim3(256), 0, st, N, MLP_W, w.Y[l], MLP_W,
                                        w.cmaxY + l * MLP_W);
             } else if (use_f16x3()) {
                 if (K1 + K2 == MLP_W) {
@@ -851,7 +857,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     const bool x3 = use_f16x3();
     if (x3) {  // column maxima of G_7 for the first weight gradient's scales (the later G_l get theirs from the GEMM epilogue)
         if (hipMemsetAsync(w.cmaxG, 0, 8 * MLP_W * 4, st) != hipSuccess) return mlp_fail("mlp_backward: memset failed");
-        hipLaunchKernelGGL(mlp_colmax_kernel, dim3(num_cus()), dim3(256), 0, st, N, MLP_W, w.Ga, MLP_W, w.cmaxG + 7 * MLP_W);
+        hipLaunchKernelGGL(mlp_colmax_kernel, dim3(4 * num_cus()), dim3(256), 0, st, N, MLP_W, w.Ga, MLP_W, w.cmaxG + 7 * MLP_W);
         if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
     }
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;

@@ -90,41 +90,59 @@ __device__ __forceinline__ float prep3_src(const Prep3Job& j, int k, int col) {
     return k < j.k_valid ? j.W[(size_t)k * j.in_features + j.hoff + col] : 0.f;
 }
 
-// blockIdx.y = job, one thread per column: column maximum -> scale, then the planes
-__global__ void __launch_bounds__(64) mlp_prep3_batch_kernel(const Prep3Batch b) {
+// pass 1 (blockIdx.y = job, one thread per (8-deep k group, column)): column maxima of |B| into cmax[job][col] (float
+// bits, zeroed by the caller) -- one atomic per thread, ~40 per address
+__global__ void __launch_bounds__(256) mlp_prep3_max_kernel(const Prep3Batch b, unsigned* __restrict__ cmax) {
     const Prep3Job& j = b.job[blockIdx.y];
-    const int col = blockIdx.x * 64 + threadIdx.x;
-    if (col >= j.ncols) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (j.Kp >> 3) * j.ncols) return;
+    const int kg = idx / j.ncols, col = idx % j.ncols;
     float mx = 0.f;
-    for (int k = 0; k < j.Kp; k++) mx = fmaxf(mx, fabsf(prep3_src(j, k, col)));
-    float sc, inv;
-    scale_from_max_bits(__float_as_uint(mx), sc, inv);
-    j.inv_scale[col] = inv;
-    for (int kg = 0; kg < (j.Kp >> 3); kg++) {
-        float e[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) e[i] = prep3_src(j, kg * 8 + i, col) * sc;
-        uint4 H, L;
-        split2h(e[0], e[1], H.x, L.x);
-        split2h(e[2], e[3], H.y, L.y);
-        split2h(e[4], e[5], H.z, L.z);
-        split2h(e[6], e[7], H.w, L.w);
-        const int stage = kg >> 1, g = kg & 1;
-        uint4* dst = j.Bp + ((size_t)stage * 4 + g) * j.ncols + col;
-        dst[0] = H;
-        dst[2 * j.ncols] = L;
-    }
+    for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(prep3_src(j, kg * 8 + i, col)));
+    atomicMax(cmax + blockIdx.y * 256 + col, __float_as_uint(mx));
 }
 
-// column maxima of |X| (N x ncols, row stride ld) for producers that do not deliver them: out[col] = max(out[col], ..)
-// as float bits (non-negative floats order like unsigned integers)
+// pass 2: scale by the column's power of two, split, write the two planes (and the inverse scales)
+__global__ void __launch_bounds__(256) mlp_prep3_batch_kernel(const Prep3Batch b, const unsigned* __restrict__ cmax) {
+    const Prep3Job& j = b.job[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (j.Kp >> 3) * j.ncols) return;
+    const int kg = idx / j.ncols, col = idx % j.ncols;
+    float sc, inv;
+    scale_from_max_bits(cmax[blockIdx.y * 256 + col], sc, inv);
+    if (kg == 0) j.inv_scale[col] = inv;
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = prep3_src(j, kg * 8 + i, col) * sc;
+    uint4 H, L;
+    split2h(e[0], e[1], H.x, L.x);
+    split2h(e[2], e[3], H.y, L.y);
+    split2h(e[4], e[5], H.z, L.z);
+    split2h(e[6], e[7], H.w, L.w);
+    const int stage = kg >> 1, g = kg & 1;
+    uint4* dst = j.Bp + ((size_t)stage * 4 + g) * j.ncols + col;
+    dst[0] = H;
+    dst[2 * j.ncols] = L;
+}
+
+// column maxima of |X| (N x ncols <= 256, row stride ld) for producers that do not deliver them:
+// out[col] = max(out[col], ..) as float bits (non-negative floats order like unsigned integers).  Thread = column,
+// eight rows in flight per thread, one atomic per column and workgroup.
 __global__ void __launch_bounds__(256) mlp_colmax_kernel(int N, int ncols, const float* __restrict__ X, int ld,
                                                          unsigned* __restrict__ out) {
     const int col = threadIdx.x;
     if (col >= ncols) return;
-    float m = 0.f;
-    for (int r = blockIdx.x; r < N; r += gridDim.x) m = fmaxf(m, fabsf(X[(size_t)r * ld + col]));
-    atomicMax(out + col, __float_as_uint(m));
+    float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int G = gridDim.x;
+    int r = blockIdx.x;
+    for (; r + 7 * G < N; r += 8 * G) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) m[u] = fmaxf(m[u], fabsf(X[(size_t)(r + u * G) * ld + col]));
+    }
+    for (; r < N; r += G) m[0] = fmaxf(m[0], fabsf(X[(size_t)r * ld + col]));
+    const float mm = fmaxf(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])), fmaxf(fmaxf(m[4], m[5]), fmaxf(m[6], m[7])));
+    atomicMax(out + col, __float_as_uint(mm));
 }
 
 // ---- the trunk-layer GEMM, weights stationary in registers -------------------------------------------------------------
