@@ -320,12 +320,12 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         }                                                                                                              \
     }
 #define R3_UNSCALE(pb_) gemm3r_unscale(acc, rinv + (pb_) * 32, g, binv);
+#define R3_MWORD() if (EPI == 1) mlds[wv * 32 + li] = mword; /* both halves write the same 32 words; read back by this wave only */
 #define R3_STORE(tile_)                                                                                                \
     {                                                                                                                  \
         const int row0_ = (tile_) * 32 + 4 * g;                                                                        \
         float* cb_ = C + (size_t)row0_ * 256 + col;                                                                    \
         unsigned* mb_ = mask + (size_t)row0_ * 8 + wv;                                                                 \
-        if (EPI == 1) mlds[wv * 32 + li] = mword; /* both halves write the same 32 words; read back by this wave only */ \
         if ((tile_) * 32 + 32 <= M) gemm3r_store<EPI, true>(acc, mlds + wv * 32, row0_, M, cb_, mb_, g, li, bv, cmax);   \
         else gemm3r_store<EPI, false>(acc, mlds + wv * 32, row0_, M, cb_, mb_, g, li, bv, cmax);                       \
     }
@@ -356,15 +356,15 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
     __syncthreads();
     // One tile step.  Waves w and w + 4 share a SIMD and run the two halves of a step in opposite order, so that one
     // multiplies while the other does its VALU work:
-    //   waves 0..3:  [ MFMA(j), unscale ]                     [ split(j+1), store(j), loads(j+1+PF) ]   barrier
-    //   waves 4..7:  [ split(j+1), store(j-1), loads(..) ]    [ MFMA(j), unscale ]                      barrier
+    //   waves 0..3:  [ MFMA(j), unscale ]                     [ split(j+1), loads(j+1+PF), store(j) ]   barrier
+    //   waves 4..7:  [ split(j+1), loads(..), store(j-1) ]    [ MFMA(j), unscale ]                      barrier
     // (the high waves keep tile j's scaled accumulators across the barrier and store them in the next step).
     // Memory-counter discipline (gfx9's vmcnt counts loads AND stores; with both kinds pending the compiler can only wait
-    // with vmcnt(0)):  the one wait of a step sits at the top of split(), where everything outstanding -- the tile's row
-    // loads, the mask words, the previous stores -- was issued at least one MFMA phase earlier; new stores and then new
-    // loads are issued after it and nothing touches their results before the next step's split.  The barrier is an
-    // LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also drain vmcnt, i.e. stall every wave
-    // on the loads it has just prefetched.
+    // with vmcnt(0)):  the ONE wait of a step sits at the top of split(), where everything outstanding -- the tile's row
+    // loads, the mask words, the previous stores -- was issued a whole step (minus the split) earlier: the new loads go
+    // out right after the wait, the stores after them, and nothing touches their results before the next step's split.
+    // The barrier is an LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also drain vmcnt, i.e.
+    // stall every wave on the loads it has just prefetched.
     // SLOT_ = register slot holding tile j + 1 (compile-time: two steps per loop trip).
 #define R3_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define R3_STEP(j_, SLOT_)                                                                                             \
@@ -372,27 +372,25 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         const int tile = blockIdx.x + (j_) * G;                                                                        \
         const int pb = (j_) & 1;                                                                                       \
         if (wv < 4) {                                                                                                  \
-            __builtin_amdgcn_s_setprio(0);                                                                             \
             R3_MFMA(pb)                                                                                                \
             R3_UNSCALE(pb)                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
-            __builtin_amdgcn_s_setprio(3);                                                                             \
             if ((j_) + 1 < my_tiles) R3_SPLIT(SLOT_, pb ^ 1)                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
-            R3_STORE(tile)                                                                                             \
+            R3_MWORD()                                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                          \
             if ((j_) + 1 < my_tiles) R3_MASK(tile + G)                                                                 \
-        } else {                                                                                                       \
-            __builtin_amdgcn_s_setprio(3);                                                                             \
-            if ((j_) + 1 < my_tiles) R3_SPLIT(SLOT_, pb ^ 1)                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
-            if ((j_) > 0) R3_STORE(tile - G)                                                                           \
+            R3_STORE(tile)                                                                                             \
+        } else {                                                                                                       \
+            if ((j_) + 1 < my_tiles) R3_SPLIT(SLOT_, pb ^ 1)                                                           \
+            if ((j_) > 0) R3_MWORD()                                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             if ((j_) + 1 + PF < my_tiles) R3_LOAD(SLOT_, tile + (1 + PF) * G)                                          \
             R3_MASK(tile)                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
-            __builtin_amdgcn_s_setprio(0);                                                                             \
+            if ((j_) > 0) R3_STORE(tile - G)                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
             R3_MFMA(pb)                                                                                                \
             R3_UNSCALE(pb)                                                                                             \
         }                                                                                                              \
@@ -402,7 +400,10 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         R3_STEP(j, PF - 1)          // tile j + 1 (odd) lives in slot 1 (PF == 2) / slot 0 (PF == 1)
         if (j + 1 < my_tiles) R3_STEP(j + 1, 0)
     }
-    if (wv >= 4 && my_tiles > 0) R3_STORE(blockIdx.x + (my_tiles - 1) * G)
+    if (wv >= 4 && my_tiles > 0) {
+        R3_MWORD()
+        R3_STORE(blockIdx.x + (my_tiles - 1) * G)
+    }
 #undef R3_STEP
 #undef R3_LDS_BARRIER
     if (colmax != nullptr) {
@@ -416,6 +417,7 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
 #undef R3_MFMA
 #undef R3_UNSCALE
 #undef R3_STORE
+#undef R3_MWORD
 #undef R3_MASK
 }
 

@@ -30,6 +30,14 @@ kern = rep(kern, block, line("            if (!(VAR & 1)) {") + block +
 kern = kern.replace("gemm3r_store<EPI, true>(acc,", "g3_store<EPI, true, VAR>(acc,").replace("gemm3r_store<EPI, false>(acc,", "g3_store<EPI, false, VAR>(acc,")
 ld = [l for l in kern.split("\n") if "if (K % 256 == 0 || k_ < K) {" in l]
 kern = rep(kern, ld[0] + "\n", line("                if ((K % 256 == 0 || k_ < K) && !(VAR & 8)) {"))
+kern = rep(kern, line("        wave_max4_nonneg_lane63(m_[0], m_[1], m_[2], m_[3]);"),
+           line("        if (!(VAR & 32)) wave_max4_nonneg_lane63(m_[0], m_[1], m_[2], m_[3]);"))
+kern = rep(kern, line("                    *reinterpret_cast<uint2*>(d_ + 2 * k_) = make_uint2(h0_, h1_);"),
+           line("                    if (!(VAR & 64) || h0_ == 0x12345u) *reinterpret_cast<uint2*>(d_ + 2 * k_) = make_uint2(h0_, h1_);"))
+kern = rep(kern, line("                    *reinterpret_cast<uint2*>(d_ + PLANE + 2 * k_) = make_uint2(l0_, l1_);"),
+           line("                    if (!(VAR & 64) || l0_ == 0x12345u) *reinterpret_cast<uint2*>(d_ + PLANE + 2 * k_) = make_uint2(l0_, l1_);"))
+kern = rep(kern, line("            rinv[(pb_) * 32 + row_] = inv_; /* every lane writes the same word: no exec juggling */"),
+           line("            if (!(VAR & 128) || lane == 0) rinv[(pb_) * 32 + row_] = inv_;"))
 # timing hooks
 kern = rep(kern, "    f32x16 acc;\n    const f32x16 zero16",
            "    unsigned long long tm_[6] = {0, 0, 0, 0, 0, 0}, t0_ = 0;\n#define TT(i_) if (VAR & 16) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = "
@@ -60,9 +68,6 @@ for l in lines:
             continue
         if branch == "B" and s.strip() == "if ((j_) > 0) R3_STORE(tile - G)":
             out.append(line("            TT(0)").rstrip("\n"))
-            out.append(l)
-            continue
-        if branch == "B" and s.strip() == "R3_MASK(tile)":
             out.append(l)
             out.append(line("            TT(2)").rstrip("\n"))
             continue

@@ -62,6 +62,11 @@ int main() {
     RUN(0, 9, "no MFMA, no loads")
     RUN(0, 10, "no stores, no loads")
     RUN(0, 11, "no MFMA/stores/loads (split+epilogue VALU)")
+    RUN(0, 32, "no row-max DPP chain")
+    RUN(0, 64, "no plane ds_writes")
+    RUN(0, 128, "rinv written by lane 0 only")
+    RUN(0, 96, "no max chain, no plane writes")
+    RUN(0, 256, "all waves same order")
     RUN(1, 0, "bwd full")
     RUN(1, 1, "bwd no MFMA")
     RUN(1, 2, "bwd no stores")
