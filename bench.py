@@ -11,9 +11,16 @@ rasterizer and both MLPs -> (N>1: one flat-bucket RCCL all-reduce) -> Adam updat
 Frames shard across ranks (weak scaling: every rank renders its own 800x800 frame each step).
 
 Rank 0 prints ONE JSON line.  `value` = frames trained per second over all ranks, inputs resident in HBM.
-`roofline` describes the dominant hand-written kernel (render backward), timed with hipEvents recorded on the
-launch stream inside the timed region (deferred read-out, no extra sync).  `cpu_baseline` = the same step on
-the host cores (oracle rasterizer + PyTorch-CPU MLPs), rank 0 at N=1 only, on a bounded sample.
+`roofline` describes the DOMINANT hand-written kernel of the step -- chosen at run time as the instrumented kernel
+with the largest (average launch time x launches per step); today one 256 -> 256 trunk-layer GEMM of the deformation
+MLP (mlp_gemm3r_kernel) -- timed with hipEvents recorded on the launch stream inside the timed region (deferred
+read-out, no extra sync) and priced against BOTH roofs it can hit: HBM (algorithmic bytes / 8 TB/s) and the f16
+matrix pipe it issues on (3 MFMAs per fp32 product: 3 x flops / 2.5 PFLOP/s); `bound` is the nearer one.
+`roofline_render_bwd` is the rasterizer backward, the kernel group BASELINE.json's north_star grades against HBM.
+`kernels` lists the same two fractions for every instrumented kernel.  When K < 200 a second, 200-step steady-state
+region is timed and reported as `steady_state` (SURVEY.md section 8d asks for >= 200 iterations).
+`cpu_baseline` = the same step on the host cores (oracle rasterizer + PyTorch-CPU MLPs; a port of the reference's CPU
+path, not the reference itself, which is not on the GPU box), rank 0 at N=1 only, on a bounded sample.
 """
 import argparse
 import importlib
@@ -33,7 +40,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_FP32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32: 64 cycles/SIMD)
-MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
+MFMA_16BIT_PEAK_TF = 2500.0  # dense f16 / bf16 MFMA
+STEADY_STEPS = int(os.environ.get("DGM_BENCH_STEADY_STEPS", "200"))
 WORKLOAD = "cfg2"
 
 
@@ -139,8 +147,8 @@ def cpu_baseline(P, W, H, max_threads=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mlp", default=os.environ.get("DGM_MLP_IMPL", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -174,27 +182,39 @@ def main():
         tr.step(it0)
     for i in range(args.warmup):
         tr.step(it0 + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    L.lib().dgm_set_profiling(2)
-    torch.cuda.synchronize()
     RZ = importlib.import_module("dg-mesh_amd.rasterizer")
-    RZ.FORWARD_CALL_SECONDS = 0.0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        _, pkg = tr.step(it0 + args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    stages = L.collect_stage_ms()
-    L.lib().dgm_set_profiling(0)
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+
+    def timed(n_steps, first_it):
+        """Barrier + synchronize on both sides, max over ranks; stage timers collected over exactly this region."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        L.lib().dgm_set_profiling(2)
+        torch.cuda.synchronize()
+        RZ.FORWARD_CALL_SECONDS = 0.0
+        t0 = time.perf_counter()
+        pk = None
+        for i in range(n_steps):
+            _, pk = tr.step(first_it + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = L.collect_stage_ms()
+        L.lib().dgm_set_profiling(0)
+        blocked = RZ.FORWARD_CALL_SECONDS
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, st, blocked, pk
+
+    elapsed, stages, blocked_s, pkg = timed(args.steps, it0 + args.warmup)
+    steady = None
+    if args.steps < STEADY_STEPS:
+        s_dt, _, _, _ = timed(STEADY_STEPS, it0 + args.warmup + args.steps)
+        steady = {"steps": STEADY_STEPS, "value": STEADY_STEPS * world / s_dt, "ms_per_step": 1e3 * s_dt / STEADY_STEPS}
 
     if rank == 0:
         # R of the last frame (all frames of the synthetic orbit are statistically alike)
@@ -203,54 +223,91 @@ def main():
         bwd_ms, bwd_n = stages.get("render_bwd", (0.0, 0))
         alg_bytes = 40.0 * n_inst + 20.0 * W * H + 36.0 * P  # render bwd per frame
         achieved = (alg_bytes / (bwd_ms * 1e-3) / 1e9) if bwd_ms > 0 else 0.0
-        gemm_ms, gemm_n = stages.get("mlp_layer_fwd", (0.0, 0))
-        gemm_flops = 2.0 * P * 256 * 256  # 2 * 65536 MAC-flops per row and layer
-        gemm_tf = (gemm_flops / (gemm_ms * 1e-3) / 1e12) if gemm_ms > 0 else 0.0
-        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_render_bwd2.json), same workload
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_render_bwd2.json")) as fh:
-                pmc = json.load(fh)
-            if pmc.get("workload") == WORKLOAD:
-                traffic = float(pmc["fetch_bytes"]) + float(pmc["write_bytes"])
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        gemm_traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_gemm6r.json")) as fh:
-                pmc = json.load(fh)
-            if pmc.get("workload") == WORKLOAD:
-                gemm_traffic = float(pmc["fetch_bytes"]) + float(pmc["write_bytes"])
-        except (OSError, ValueError, KeyError):
-            gemm_traffic = None
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+
+        def pmc_traffic(name):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload); offline data
+            try:
+                with open(os.path.join(prof_dir, name)) as fh:
+                    pmc = json.load(fh)
+                if pmc.get("workload") == WORKLOAD:
+                    return float(pmc["fetch_bytes"]) + float(pmc["write_bytes"]), name
+            except (OSError, ValueError, KeyError):
+                pass
+            return None, None
+
+        f16x3 = mlp_impl == "hip" and L.lib().dgm_mlp_set_gemm(-1) == 2  # (-1: query, mode unchanged)
+        mfma_per_product = 3.0 if f16x3 else 6.0  # f16x3: 3 MFMAs per fp32 product on the f16 pipe; bf16x6: 6 on the bf16 pipe
+        layer_flops = 2.0 * P * 256 * 256                       # one 256 -> 256 layer over N = P rows
+        layer_bytes = 2.0 * P * 256 * 4 + P * 32 + 256 * 256 * 4  # A in + C out (fp32) + ReLU mask bits + the weights once
+        dw_bytes = 2.0 * P * 256 * 4 + 256 * 256 * 4  # X in + G in + the gradient once (the per-CU partial tiles are overhead)
+        kern = {  # stage -> (kernel name, algorithmic flops, algorithmic bytes, committed PMC file)
+            "mlp_layer_fwd": ("mlp_gemm3r_kernel<0,16,2> (256->256 layer forward, N rows)" if f16x3 else "mlp_gemm6r_kernel<0,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_fwd.json"),
+            "mlp_layer_bwd": ("mlp_gemm3r_kernel<1,16,2> (256->256 layer backward-data, N rows)" if f16x3 else "mlp_gemm6r_kernel<1,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_bwd.json"),
+            "mlp_layer_dw": ("mlp_dw3b_kernel (256x256 weight gradient over N rows)" if f16x3 else "mlp_dw6b_kernel", layer_flops, dw_bytes, "pmc_dw3b.json"),
+            "render_bwd": ("render_bwd3_kernel", 0.0, alg_bytes, "pmc_render_bwd3.json"),
+            "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
+            "tile_sort": ("tile_sort_small_kernel (+big)", 0.0, 20.0 * n_inst, None),
+            "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 48.0 * n_inst, None),
+            "preprocess_fwd": ("preprocess_fwd_kernel", 0.0, 311.0 * P, None),
+        }
+        kernels, best, best_ms = {}, None, -1.0
+        for st_name, (kname, fl, by, pmc_file) in kern.items():
+            ms, n = stages.get(st_name, (0.0, 0))
+            if ms <= 0 or n == 0:
+                continue
+            per_step = ms * n / args.steps
+            hbm_gbs = by / (ms * 1e-3) / 1e9
+            rec = {"kernel": kname, "avg_ms": round(ms, 5), "launches_per_step": round(n / args.steps, 2), "ms_per_step": round(per_step, 4),
+                   "hbm_GBps": round(hbm_gbs, 1), "frac_hbm": round(hbm_gbs / HBM_PEAK_GBS, 4)}
+            if fl > 0:
+                tf = fl / (ms * 1e-3) / 1e12
+                rec.update({"fp32_equiv_TFLOPs": round(tf, 1), "mfma_issued_TFLOPs": round(mfma_per_product * tf, 1),
+                            "frac_mfma_pipe": round(mfma_per_product * tf / MFMA_16BIT_PEAK_TF, 4)})
+            kernels[st_name] = rec
+            if per_step > best_ms:
+                best, best_ms = st_name, per_step
+        roof = {"kernel": None, "bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+        if best is not None:
+            r = kernels[best]
+            kname, fl, by, pmc_file = kern[best]
+            traffic, src = pmc_traffic(pmc_file) if pmc_file else (None, None)
+            if r.get("frac_mfma_pipe", 0.0) > r["frac_hbm"]:
+                roof = {"kernel": kname, "bound": "mfma", "achieved": r["mfma_issued_TFLOPs"], "peak": MFMA_16BIT_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": r["frac_mfma_pipe"]}
+            else:
+                roof = {"kernel": kname, "bound": "hbm", "achieved": r["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac_hbm"]}
+            roof.update({"traffic": traffic, "traffic_source": (f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                                 "workload, committed (not measured in this run)") if src else None,
+                         "algorithmic_bytes": by, "algorithmic_flops": fl, "avg_ms": r["avg_ms"], "launches_per_step": r["launches_per_step"],
+                         "ms_per_step": r["ms_per_step"], "frac_hbm": r["frac_hbm"], "frac_mfma_pipe": r.get("frac_mfma_pipe"),
+                         "arithmetic": ("f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
+                                        if f16x3 else "bf16x6: 3 bf16 planes, 6 MFMAs per product")})
+        rb_traffic, rb_src = pmc_traffic("pmc_render_bwd3.json")
         out = {
             "metric": "train-step iters/sec (800x800, ~100k Gaussians)", "value": args.steps * world / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "D-NeRF jumpingjacks-like cfg2: 800x800, P=100000 Gaussians, deformation MLP on "
-                                   "(deform + deform_back, is_blender), 1 frame per rank per step",
+                                   "(deform + deform_back, is_blender), 1 frame per rank per step, fixed P (no densification "
+                                   "inside the timed region)",
                        "P": P, "W": W, "H": H, "num_rendered": n_inst, "visible": R, "mlp_impl": mlp_impl,
                        "parallelism": f"dp{world} (frame-parallel, flat-bucket all-reduce {tr.grad_bytes() / 1e6:.1f} MB)"},
-            # dominant kernel of the step: the 256 -> 256 trunk-layer GEMM (12 forward + 14 backward-data launches per
-            # step, 1/3 of the GPU time).  Bound: matrix cores; priced against the DENSE fp32 MFMA peak because the
-            # path computes fp32 GEMMs -- its bf16x6 arithmetic (6 bf16 MFMAs per fp32 K step) is also given against
-            # the dense bf16 peak.
-            "roofline": {"kernel": "mlp_gemm6r_kernel<0,16,1,8> (one 256->256 layer forward, N rows)", "bound": "mfma",
-                         "achieved": gemm_tf, "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": gemm_tf / MFMA_FP32_PEAK_TF, "traffic": gemm_traffic,
-                         "algorithmic_flops": gemm_flops, "avg_ms": gemm_ms, "launches": gemm_n,
-                         "bf16_mfma_flops": 6.0 * gemm_flops,
-                         "frac_of_bf16_peak": 6.0 * gemm_tf / MFMA_BF16_PEAK_TF},
-            # the rasterizer's dominant kernel, graded against HBM by BASELINE.json's north_star
-            "roofline_render_bwd": {"kernel": "render_bwd2_kernel", "bound": "hbm", "achieved": achieved,
+            "roofline": roof,
+            # the rasterizer backward, graded against HBM by BASELINE.json's north_star (VALU-bound in practice:
+            # profiles/*pmc_sq*.json)
+            "roofline_render_bwd": {"kernel": "render_bwd3_kernel", "bound": "hbm", "achieved": achieved,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                    "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms,
+                                    "traffic": rb_traffic, "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms,
                                     "launches": bwd_n},
+            "kernels": kernels,
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
             # host side: time blocked in the rasterizer forward (its R read-back is the step's only sync) vs busy
-            "host_ms_per_step": {"blocked_on_gpu": round(1e3 * RZ.FORWARD_CALL_SECONDS / args.steps, 3),
-                                 "busy": round(1e3 * (elapsed - RZ.FORWARD_CALL_SECONDS) / args.steps, 3)},
+            "host_ms_per_step": {"blocked_on_gpu": round(1e3 * blocked_s / args.steps, 3),
+                                 "busy": round(1e3 * (elapsed - blocked_s) / args.steps, 3)},
         }
+        if steady is not None:
+            out["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(P, W, H)

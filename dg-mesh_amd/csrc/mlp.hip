@@ -635,9 +635,9 @@ hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once 
     static bool done[DGM_MAX_DEVICES] = {false};
     bool& d = done[current_device_slot()];
     if (d) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<0, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<1, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+        e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<1, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
     if (e == hipSuccess) d = true;
     return e;
 }
@@ -804,12 +804,12 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             } else if (use_f16x3()) {
                 if (K1 + K2 == MLP_W) {
                     dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 16, 2>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
+                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 16, 1>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
                                        nt32, A1, lda1, K1, A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l],
                                        w.cmaxY + l * MLP_W);
                     dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
                 } else
-                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 2>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
+                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
                                        A1, lda1, K1, A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l],
                                        w.cmaxY + l * MLP_W);
             } else if (K1 + K2 == MLP_W) {
@@ -920,7 +920,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                 const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
                 if (x3)
-                    hipLaunchKernelGGL((mlp_gemm3r_kernel<1, 16, 2>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
+                    hipLaunchKernelGGL((mlp_gemm3r_kernel<1, 16, 1>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
                                        nt32, G, MLP_W, MLP_W, (const float*)nullptr, 0, w.Wd3[l], w.wsc_d[l],
                                        (const float*)nullptr, w.mask[l - 1], Gn, w.cmaxG + (l - 1) * MLP_W);
                 else

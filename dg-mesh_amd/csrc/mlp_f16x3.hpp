@@ -313,13 +313,22 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
                 fh_[(ks + 2) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (ks + 2) * 32));                    \
                 fl_[(ks + 2) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (ks + 2) * 32));            \
             }                                                                                                          \
-            if (ks == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bl[0], zero16, 0, 0, 0);                 \
-            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bl[ks], acc, 0, 0, 0);                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks % 3], bh[ks], acc, 0, 0, 0);                           \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bh[ks], acc, 0, 0, 0);                           \
+            /* two accumulator chains (cross terms | leading term): a dependent MFMA waits for its predecessor's */    \
+            /* result, alternating chains keeps the matrix pipe issuing every 32 cycles                           */    \
+            if (ks == 0) {                                                                                             \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bl[0], zero16, 0, 0, 0);                         \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bh[0], zero16, 0, 0, 0);                          \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[0], bh[0], acc2, 0, 0, 0);                           \
+            } else {                                                                                                   \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bl[ks], acc2, 0, 0, 0);                     \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bh[ks], acc, 0, 0, 0);                       \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks % 3], bh[ks], acc2, 0, 0, 0);                     \
+            }                                                                                                          \
         }                                                                                                              \
     }
-#define R3_UNSCALE(pb_) gemm3r_unscale(acc, rinv + (pb_) * 32, g, binv);
+#define R3_UNSCALE(pb_)                                                                                                \
+    acc += acc2;                                                                                                       \
+    gemm3r_unscale(acc, rinv + (pb_) * 32, g, binv);
 #define R3_MWORD() if (EPI == 1) mlds[wv * 32 + li] = mword; /* both halves write the same 32 words; read back by this wave only */
 #define R3_STORE(tile_)                                                                                                \
     {                                                                                                                  \
@@ -337,7 +346,7 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         mword = mask[(size_t)mrow_ * 8 + wv];                                                                          \
     }
 
-    f32x16 acc;
+    f32x16 acc, acc2;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned mword = 0u;
 

@@ -23,10 +23,13 @@ def rep(text, a, b):
 
 
 mf = [l for l in kern.split("\n") if "__builtin_amdgcn_mfma_f32_32x32x16_f16" in l]
-assert len(mf) == 4
-block = "\n".join(mf) + "\n"
+assert len(mf) == 6
+lines_ = kern.split("\n")
+i0_ = lines_.index(mf[0]) - 1
+i1_ = lines_.index(mf[-1]) + 1
+block = "\n".join(lines_[i0_:i1_ + 1]) + "\n"
 kern = rep(kern, block, line("            if (!(VAR & 1)) {") + block +
-           line('            } else { if (ks == 0) acc = zero16; asm volatile("" ::"v"(fh_[ks % 3]), "v"(fl_[ks % 3])); }'))
+           line('            } else { if (ks == 0) { acc = zero16; acc2 = zero16; } asm volatile("" ::"v"(fh_[ks % 3]), "v"(fl_[ks % 3])); }'))
 kern = kern.replace("gemm3r_store<EPI, true>(acc,", "g3_store<EPI, true, VAR>(acc,").replace("gemm3r_store<EPI, false>(acc,", "g3_store<EPI, false, VAR>(acc,")
 ld = [l for l in kern.split("\n") if "if (K % 256 == 0 || k_ < K) {" in l]
 kern = rep(kern, ld[0] + "\n", line("                if ((K % 256 == 0 || k_ < K) && !(VAR & 8)) {"))
@@ -39,9 +42,9 @@ kern = rep(kern, line("                    *reinterpret_cast<uint2*>(d_ + PLANE 
 kern = rep(kern, line("            rinv[(pb_) * 32 + row_] = inv_; /* every lane writes the same word: no exec juggling */"),
            line("            if (!(VAR & 128) || lane == 0) rinv[(pb_) * 32 + row_] = inv_;"))
 # timing hooks
-kern = rep(kern, "    f32x16 acc;\n    const f32x16 zero16",
+kern = rep(kern, "    f32x16 acc, acc2;\n    const f32x16 zero16",
            "    unsigned long long tm_[6] = {0, 0, 0, 0, 0, 0}, t0_ = 0;\n#define TT(i_) if (VAR & 16) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = "
-           "__builtin_amdgcn_s_memtime(); tm_[i_] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); }\n    f32x16 acc;\n    const f32x16 zero16")
+           "__builtin_amdgcn_s_memtime(); tm_[i_] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); }\n    f32x16 acc, acc2;\n    const f32x16 zero16")
 kern = rep(kern, line("#define R3_SPLIT(slot_, pb_)") + line("    {"),
            line("#define R3_SPLIT(slot_, pb_)") + line("    {") + line('        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TT(4)'))
 lines = kern.split("\n")

@@ -15,14 +15,14 @@ template <int EPI, int VAR>
 float run(int M, int ncu, const float* A, const uint4* Bp, const float* binv, const float* bias, unsigned* mask, float* C, unsigned* cmax) {
     const int nt = (M + 31) / 32, gx = nt < ncu ? nt : ncu;
     const int lds = 2 * 32 * (4 * 256 + 16) + 256 + 1024;
-    hipFuncSetAttribute((const void*)g3_kernel<EPI, 16, 2, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)g3_kernel<EPI, 16, 1, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t a, b;
     hipEventCreate(&a), hipEventCreate(&b);
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL((g3_kernel<EPI, 16, 2, VAR>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, 256, (const float*)nullptr, 0, Bp, binv, bias, mask, C, cmax);
+        hipLaunchKernelGGL((g3_kernel<EPI, 16, 1, VAR>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, 256, (const float*)nullptr, 0, Bp, binv, bias, mask, C, cmax);
     hipEventRecord(a);
     for (int i = 0; i < 20; i++)
-        hipLaunchKernelGGL((g3_kernel<EPI, 16, 2, VAR>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, 256, (const float*)nullptr, 0, Bp, binv, bias, mask, C, cmax);
+        hipLaunchKernelGGL((g3_kernel<EPI, 16, 1, VAR>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, 256, (const float*)nullptr, 0, Bp, binv, bias, mask, C, cmax);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms = 0;
