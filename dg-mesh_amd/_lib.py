@@ -65,6 +65,11 @@ SYMBOLS = {
     "dgm_densify_totals_offset": (_c.c_size_t, [_i]),
     "dgm_densify_decide": (_i, [_i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     "dgm_densify_apply": (_i, [_i, _c.c_uint, _c.c_uint, _c.c_uint, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "dgm_dpsr_splat_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "dgm_dpsr_splat_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgm_dpsr_interp_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "dgm_dpsr_interp_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgm_dpsr_spectral": (_i, [_i, _f, _vp, _vp, _i, _vp]),
     "dgm_mlp_set_gemm": (_i, [_i]),
     "dgm_timenet_forward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_timenet_backward": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

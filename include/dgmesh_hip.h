@@ -279,6 +279,22 @@ int dgm_densify_apply(int P, unsigned K, unsigned C, unsigned S, const char* scr
                       const float* const* in, float* const* out, const int* width, const int* is_moment, int xyz_index,
                       int scaling_index, int rotation_index, const float* z, void* stream);
 
+/* ---- DPSR pieces (csrc/dpsr.hip) --------------------------------------------------------------------------------------
+ * Replace point_rasterize / grid_interp (dgmesh/nvdiffrast_utils/dpsr_utils.py:69-198) and the spectral solve between the
+ * two FFTs of DPSR.forward (dgmesh/nvdiffrast_utils/dpsr.py:28-69).  V: points in (0,1)^3 [n][3]; N: normals [n][3];
+ * grids are res^3 (periodic), row-major [x][y][z]; spectra are the rfftn layout [res][res][res/2+1] of float2.
+ *   splat_forward : grid[3][res^3] = sum_p w_c(p) N[p]  (the callee zeroes grid);  splat_backward: dV, dN from dgrid
+ *   interp_forward: fv[p] = trilinear phi(V[p]);  interp_backward: dphi (zeroed by the callee, then accumulated), dV
+ *   spectral      : adjoint == 0: out[k] = sum_d (-i c_d) in[d][k];  adjoint != 0: out[d][k] = (+i c_d) in[k];
+ *                   c_d = omega_d G / (Lap + 1e-6), G = exp(-0.5 (2 sig |f| / res)^2), out(0) = 0. */
+int dgm_dpsr_splat_forward(int n, int res, const float* V, const float* N, float* grid, void* stream);
+int dgm_dpsr_splat_backward(int n, int res, const float* V, const float* N, const float* dgrid, float* dV, float* dN,
+                            void* stream);
+int dgm_dpsr_interp_forward(int n, int res, const float* phi, const float* V, float* fv, void* stream);
+int dgm_dpsr_interp_backward(int n, int res, const float* phi, const float* V, const float* dfv, float* dphi, float* dV,
+                             void* stream);
+int dgm_dpsr_spectral(int res, float sig, const float* in, float* out, int adjoint, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

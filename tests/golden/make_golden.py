@@ -101,7 +101,41 @@ def state_dict_layouts():
     print("wrote state_dict_layouts.json")
 
 
+def dpsr_golden():
+    """phi and its gradients from the REFERENCE's own DPSR code (CPU, float32).  nvdiffrast_utils/dpsr_utils.py imports
+    half of the mesh stack at module level (trimesh, open3d, pytorch3d ...), none of which the functions used here need,
+    so the six functions and the class are executed from their source text in a namespace holding torch / numpy only."""
+    import ast
+    ns = {"torch": torch, "np": np, "nn": torch.nn}
+    src = open("/root/reference/dgmesh/nvdiffrast_utils/dpsr_utils.py").read()
+    tree = ast.parse(src)
+    want = {"fftfreqs", "img", "spec_gaussian_filter", "grid_interp", "scatter_to_grid", "point_rasterize"}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in want:
+            exec(compile(ast.Module([node], []), "dpsr_utils.py", "exec"), ns)
+    src = open("/root/reference/dgmesh/nvdiffrast_utils/dpsr.py").read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == "DPSR":
+            exec(compile(ast.Module([node], []), "dpsr.py", "exec"), ns)
+    rng = np.random.RandomState(11)
+    n, res = 3000, 32
+    d = rng.randn(n, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    V = (0.5 + 0.27 * d * (1 + 0.05 * rng.randn(n, 1))).astype(np.float32)     # a noisy sphere in (0, 1)^3
+    N = (d + 0.1 * rng.randn(n, 3)).astype(np.float32)
+    Vt, Nt = torch.tensor(V, requires_grad=True), torch.tensor(N, requires_grad=True)
+    phi = ns["DPSR"](res=(res, res, res), sig=2.0)(Vt.unsqueeze(0), Nt.unsqueeze(0))
+    wgt = torch.tensor(np.random.RandomState(12).randn(1, res, res, res).astype(np.float32))
+    (phi * wgt).sum().backward()
+    ras = ns["point_rasterize"](torch.tensor(V).unsqueeze(0), torch.tensor(N).unsqueeze(0), (res, res, res))
+    np.savez_compressed(os.path.join(HERE, "dpsr_small.npz"), V=V, N=N, res=res, sig=np.float32(2.0), phi=phi.detach().numpy()[0],
+                        weight_seed=np.int64(12), dV=Vt.grad.numpy(), dN=Nt.grad.numpy(),
+                        raster_sub=ras.numpy()[0][:, ::2, ::2, ::2].astype(np.float32), raster_abs_sum=np.float64(np.abs(ras.numpy()).sum()))
+    print("wrote dpsr_small", float(phi.min()), float(phi.max()))
+
+
 if __name__ == "__main__":
     mlp_goldens()
     raster_golden()
     state_dict_layouts()
+    dpsr_golden()
