@@ -70,6 +70,8 @@ SYMBOLS = {
     "dgm_dpsr_interp_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "dgm_dpsr_interp_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgm_dpsr_spectral": (_i, [_i, _f, _vp, _vp, _i, _vp]),
+    "dgm_opacity_field_scratch_bytes": (_c.c_size_t, [_i]),
+    "dgm_opacity_field": (_i, [_i, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "dgm_mlp_set_gemm": (_i, [_i]),
     "dgm_timenet_forward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_timenet_backward": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

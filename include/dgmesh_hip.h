@@ -295,6 +295,16 @@ int dgm_dpsr_interp_backward(int n, int res, const float* phi, const float* V, c
                              void* stream);
 int dgm_dpsr_spectral(int res, float sig, const float* in, float* out, int adjoint, void* stream);
 
+/* ---- opacity field on a regular grid (csrc/opacity_field.hip) ------------------------------------------------------------
+ * Replaces get_opacity_field_from_gaussians (dgmesh/utils/mesh_utils.py:7-76): occ[res^3] = sum over the Gaussians of the
+ * cell's block (centre strictly inside the block's box grown by `margin`, opacity > opacity_threshold) of
+ * opacity * exp(-0.5 d^T Sigma^-1 d), Sigma from (scalings, rotations) as build_covariance_from_scaling_rotation,
+ * inverse by cofactors + 1e-24 (gaussian_3d_coeff).  coords[res]: the grid coordinates along an axis. */
+size_t dgm_opacity_field_scratch_bytes(int P);
+int dgm_opacity_field(int P, const float* xyz, const float* rotations, const float* scalings, const float* opacities,
+                      float opacity_threshold, int res, int num_blocks, float margin, const float* coords, char* scratch,
+                      float* occ, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
