@@ -12,8 +12,9 @@ Data parallelism (absent in the reference; BASELINE.json north_star): one proces
 ranks, every rank holds a full replica of the Gaussians and MLPs.
   * all ranks derive the same shuffled camera order from a shared seed; rank r takes entries r, r+W, ... so one
     step consumes W frames (effective batch W);
-  * gradients are exchanged as ONE flat fp32 bucket, a single all-reduce(SUM) per step over RCCL/xGMI -- 35 MB at
-    P=100k: latency-bound, one collective beats many.  On the GPU the step's fresh gradients are packed into the
+  * gradients are exchanged as flat fp32 buckets over RCCL/xGMI: on the GPU two of them -- the Gaussian gradients
+    (25 MB at P=100k), whose all-reduce is launched from an autograd hook as soon as they are final and runs under the
+    two MLP backward passes, and the MLP gradients (4 MB) after backward; on the CPU test path one.  On the GPU the step's fresh gradients are packed into the
     bucket by one multi-tensor copy ("pack" mode; no per-tensor accumulate kernels, no zero-fill), on the CPU test
     path every .grad is a view into the bucket ("views" mode, which also supports accumulating several frames);
   * every rank then applies the identical Adam update, so replicas stay bit-identical without broadcasting.  On the
@@ -84,7 +85,7 @@ class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
                  process_group=None, fused_loss=True, fused_glue=None, track_stats=True, densify=False,
-                 cameras_extent=1.0, prune_threshold=0.005, white_background=True):
+                 cameras_extent=1.0, prune_threshold=0.005, white_background=True, overlap=True):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
         self.cameras = cameras
         self.opt = opt or S.OptimizationParams()
@@ -98,6 +99,7 @@ class Trainer:
         self.track_stats = track_stats
         # densification / pruning / opacity reset inside the loop (R/train.py:488-515); off = fixed-P steps (bench.py)
         self.densify = densify
+        self.overlap = overlap
         self.cameras_extent, self.prune_threshold, self.white_background = cameras_extent, prune_threshold, white_background
         self.step_count = 0
         # fused per-Gaussian glue (activations + deformation, cycle loss): GPU, stock render(), plain (non-6dof) networks
@@ -136,6 +138,30 @@ class Trainer:
         self.params = [p for p in params if p.requires_grad]
         # "pack": gradients are fresh tensors every step (no accumulate kernels); "views": .grad lives in the bucket
         self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or self.world > 1) else None
+        # Overlap (pack mode, world > 1): the Gaussian gradients (6 tensors, 25 MB at P = 100k) are final as soon as the
+        # rasterizer / glue backward has run, long before the two MLP backward passes finish.  A post-accumulate hook
+        # counts them down and launches their all-reduce asynchronously (RCCL's own stream) while autograd is still in the
+        # MLPs; the MLP bucket follows after backward, and both are awaited right before the Adam launch.
+        self._early = None
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks = []
+        if self.pack and self.world > 1 and self.overlap:
+            gp = [p for p in params[:6] if p.requires_grad]
+            mp = [p for p in params[6:] if p.requires_grad]
+            self._early = {"g": FlatGradBucket(gp, attach=False), "m": FlatGradBucket(mp, attach=False), "left": 0, "work": None,
+                           "views": None, "n": len(gp), "armed": False}
+            for p in gp:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._gaussian_grad_ready))
+
+    def _gaussian_grad_ready(self, _param):
+        e = self._early
+        if e is None or not e["armed"]:
+            return
+        e["left"] -= 1
+        if e["left"] == 0:
+            e["views"] = e["g"].pack()
+            e["work"] = dist.all_reduce(e["g"].flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def maybe_densify(self, iteration):
         """R/train.py:499-515: every densification_interval iterations after densify_from_iter clone / split / prune
@@ -226,14 +252,27 @@ class Trainer:
             self.bucket.zero()
         losses, pkg = self.loss_terms(cam, iteration)
         loss = sum(losses.values())
+        if self._early is not None:
+            self._early.update(left=self._early["n"], work=None, views=None, armed=True)
         loss.backward()
+        if self._early is not None:
+            self._early["armed"] = False
         rebound = False
         if self.track_stats and iteration < self.opt.densify_until_iter:  # R/train.py:488-496
             g.track_densification_stats(pkg.get("viewspace_points"), pkg["visibility_filter"], pkg["radii"])
             if self.densify:
                 rebound = self.maybe_densify(iteration)
         grads = None
-        if self.world > 1:
+        if self.world > 1 and self._early is not None:
+            e = self._early
+            if e["work"] is None:  # (a step in which some Gaussian tensor got no gradient: exchange it now)
+                e["views"] = e["g"].pack()
+                e["work"] = dist.all_reduce(e["g"].flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            grads = e["m"].pack()
+            dist.all_reduce(e["m"].flat, op=dist.ReduceOp.SUM, group=self.group)
+            e["work"].wait()
+            grads.update(e["views"])  # replaced Parameters are in neither bucket's dict: no update for them
+        elif self.world > 1:
             if self.pack:
                 grads = self.bucket.pack()  # replaced Parameters are not in this (old) bucket: no update for them
             self.bucket.all_reduce(self.group)
