@@ -8,4 +8,4 @@ cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "
 cd "$GRAFT_REPO_ROOT"
 find gpurun_out/prof_$tag -name "*kernel_trace.csv" -delete
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
-python tools/prof_summary.py "$f" 13 40
+python tools/prof_summary.py "$f" 223 45
