@@ -630,14 +630,14 @@ int g_gemm_mode = [] {
 }();
 bool use_f32_mfma() { return g_gemm_mode == 1; }
 bool use_f16x3() { return g_gemm_mode == 2; }
-#define G3R_LDS(K_) (2 * 32 * (4 * (K_) + 16) + 256 + 8 * 32 * 4)  // A planes (double buffered) + row scales + mask words
+#define G3R_LDS(K_) (2 * 32 * (4 * (K_) + 16) + 256 + 2 * 8 * 32 * 4)  // A planes (double buffered) + row scales + mask words
 hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once per device
     static bool done[DGM_MAX_DEVICES] = {false};
     bool& d = done[current_device_slot()];
     if (d) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<0, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_gemm3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)mlp_gemm3r_kernel<1, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+        e = hipFuncSetAttribute((const void*)mlp_gemm3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
     if (e == hipSuccess) d = true;
     return e;
 }
@@ -804,9 +804,8 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             } else if (use_f16x3()) {
                 if (K1 + K2 == MLP_W) {
                     dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 16, 1>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
-                                       nt32, A1, lda1, K1, A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l],
-                                       w.cmaxY + l * MLP_W);
+                    hipLaunchKernelGGL((mlp_gemm3p_kernel<0>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
+                                       w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W);
                     dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
                 } else
                     hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
@@ -920,9 +919,9 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                 const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
                 if (x3)
-                    hipLaunchKernelGGL((mlp_gemm3r_kernel<1, 16, 1>), dim3(gx), dim3(512), G3R_LDS(256), st, N,
-                                       nt32, G, MLP_W, MLP_W, (const float*)nullptr, 0, w.Wd3[l], w.wsc_d[l],
-                                       (const float*)nullptr, w.mask[l - 1], Gn, w.cmaxG + (l - 1) * MLP_W);
+                    hipLaunchKernelGGL((mlp_gemm3p_kernel<1>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
+                                       w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
+                                       w.cmaxG + (l - 1) * MLP_W);
                 else
                     hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
                                        (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn);

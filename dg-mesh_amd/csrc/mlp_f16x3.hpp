@@ -162,18 +162,27 @@ __global__ void __launch_bounds__(256) mlp_colmax_kernel(int N, int ncols, const
 // Waves w and w + 4 share a SIMD and run the two halves of a tile step in opposite order (one does its VALU work --
 // split, loads, stores -- while the other multiplies), one barrier per tile.
 // wave-wide maxima of FOUR non-negative floats at once (valid in lane 63): the four DPP chains are interleaved, so each
-// stage's instructions fill the two wait states a DPP read needs after a VALU write of the same register
-__device__ __forceinline__ void wave_max4_nonneg_lane63(float& a, float& b, float& c, float& d) {
+// stage's instructions fill the two wait states a DPP read needs after a VALU write of the same register.  Two halves
+// (stages 1-3, 4-6) so that a software-pipelined caller can place them in different MFMA shadows.
 #define DGM_ST(ctrl_)                                                       \
     "v_max_f32_dpp %0, %0, %0 " ctrl_ "\n\t"                               \
     "v_max_f32_dpp %1, %1, %1 " ctrl_ "\n\t"                               \
     "v_max_f32_dpp %2, %2, %2 " ctrl_ "\n\t"                               \
     "v_max_f32_dpp %3, %3, %3 " ctrl_ "\n\t"
+__device__ __forceinline__ void wave_max4_stage_a(float& a, float& b, float& c, float& d) {
     asm volatile("s_nop 1\n\t" DGM_ST("row_shr:1 row_mask:0xf bank_mask:0xf") DGM_ST("row_shr:2 row_mask:0xf bank_mask:0xf")
-                     DGM_ST("row_shr:4 row_mask:0xf bank_mask:0xf") DGM_ST("row_shr:8 row_mask:0xf bank_mask:0xf")
-                         DGM_ST("row_bcast:15 row_mask:0xa bank_mask:0xf") DGM_ST("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+                     DGM_ST("row_shr:4 row_mask:0xf bank_mask:0xf") "s_nop 1"
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void wave_max4_stage_b(float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1\n\t" DGM_ST("row_shr:8 row_mask:0xf bank_mask:0xf") DGM_ST("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     DGM_ST("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 #undef DGM_ST
+__device__ __forceinline__ void wave_max4_nonneg_lane63(float& a, float& b, float& c, float& d) {
+    wave_max4_stage_a(a, b, c, d);
+    wave_max4_stage_b(a, b, c, d);
 }
 
 // first half of the epilogue, right after the MFMA phase (the row scales of the tile are still in LDS):
@@ -428,6 +437,204 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
 #undef R3_STORE
 #undef R3_MWORD
 #undef R3_MASK
+}
+
+// ---- the K = 256 layer GEMM, software-pipelined ----------------------------------------------------------------------
+// Same data flow as mlp_gemm3r_kernel (weights stationary, [row][plane][k] LDS tiles, per-row scales), but every wave runs
+// ONE instruction stream in which the VALU work of the neighbouring tiles is sliced between the MFMAs of the current one:
+// per 16-deep K step (3 MFMAs, 2 fragment reads) a wave also executes
+//   steps 0..7 : the epilogue of the PREVIOUS tile, two accumulator registers per step (bias / ReLU / mask, store, column max);
+//   step  8    : the one memory wait of the tile, the loads of tile j+2, the element maxima of tile j+1's rows;
+//   steps 9..11: the cross-lane row maxima (two halves of the DPP chain), the scales;
+//   steps 12..15: the split of tile j+1, one row per step, into the other LDS buffer.
+// Measured on the two-role kernel (tools/g3_micro.hip): MFMA and VALU phases of DIFFERENT waves of a SIMD do not overlap in
+// this instruction mix, while VALU instructions issued by the same wave right behind an MFMA run in its shadow (about five
+// per MFMA).  The stores sit in the first half of a tile step and the wait in the middle, so the (unavoidable, gfx9 vmcnt
+// counts loads and stores together) vmcnt(0) finds stores that are half a step old and loads that are a whole step old.
+// Tail handling keeps the loop body branch-free: tile indices beyond the workgroup's last tile are clamped (the extra
+// split lands in an LDS buffer nobody reads), the first step has its own copy without an epilogue, and the globally last --
+// possibly partial -- tile is always some workgroup's final tile and is stored by the predicated path after the loop.
+template <int EPI>
+__global__ void __launch_bounds__(512)
+mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const uint4* __restrict__ Bp,
+                  const float* __restrict__ b_inv_scale, const float* __restrict__ bias, unsigned* __restrict__ mask,
+                  float* __restrict__ C, unsigned* __restrict__ colmax) {
+    constexpr int KS = 16, K = 256, RS = 4 * K + 16, PLANE = 2 * K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ps = smem;                                          // [2][32][RS]
+    float* rinv = reinterpret_cast<float*>(smem + 2 * 32 * RS);        // [2][32] inverse row scales
+    unsigned* mlds = reinterpret_cast<unsigned*>(rinv + 64);           // [2][8 waves][32] mask words of tile t in mlds[t & 1] (EPI 1)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int col = wv * 32 + li;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+    const int last_tile = blockIdx.x + (my_tiles - 1) * G;
+
+    f16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const uint4* b = Bp + ((size_t)ks * 4 + g) * 256 + col;
+        bh[ks] = as_f16x8(b[0]), bl[ks] = as_f16x8(b[512]);
+    }
+    const float binv = b_inv_scale[col];
+    const float bv = (EPI == 0) ? bias[col] : 0.f;
+    float cmax = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc, out;
+    float4 R[2][4];     // rows of tile t live in R[t & 1]
+    unsigned mw[2] = {0u, 0u};  // EPI 1: mask word (row li of the tile, this wave's column group) of tile t in mw[t & 1]
+
+#define P3_TILE(j_) min(blockIdx.x + (j_) * G, last_tile)
+#define P3_LOAD(slot_, tile_)                                                                                          \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
+            int grow_ = (tile_) * 32 + wv * 4 + r_;                                                                    \
+            grow_ = grow_ < M ? grow_ : M - 1;                                                                         \
+            R[slot_][r_] = *reinterpret_cast<const float4*>(A + (size_t)grow_ * lda + lane * 4);                       \
+        }                                                                                                              \
+        if (EPI == 1) {                                                                                                \
+            int mrow_ = (tile_) * 32 + li;                                                                             \
+            mrow_ = mrow_ < M ? mrow_ : M - 1;                                                                         \
+            mw[slot_] = mask[(size_t)mrow_ * 8 + wv];                                                                  \
+        }                                                                                                              \
+    }
+#define P3_ROWMAX(slot_)                                                                                               \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
+            const float4 v_ = R[slot_][r_];                                                                            \
+            m_[r_] = fmaxf(fmaxf(fabsf(v_.x), fabsf(v_.y)), fmaxf(fabsf(v_.z), fabsf(v_.w)));                          \
+        }                                                                                                              \
+    }
+#define P3_SCALES(pb_)                                                                                                 \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
+            const unsigned mb_ = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(m_[r_]), 63);                \
+            float inv_;                                                                                                \
+            scale_from_max_bits(mb_, sc_[r_], inv_);                                                                   \
+            rinv[(pb_) * 32 + wv * 4 + r_] = inv_;                                                                     \
+        }                                                                                                              \
+    }
+#define P3_SPLIT_ROW(slot_, pb_, r_)                                                                                   \
+    {                                                                                                                  \
+        const float4 v_ = R[slot_][r_];                                                                                \
+        unsigned h0_, l0_, h1_, l1_;                                                                                   \
+        split2h(v_.x * sc_[r_], v_.y * sc_[r_], h0_, l0_);                                                             \
+        split2h(v_.z * sc_[r_], v_.w * sc_[r_], h1_, l1_);                                                             \
+        unsigned char* d_ = Ps + ((pb_) * 32 + wv * 4 + (r_)) * RS + 8 * lane;                                         \
+        *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                                          \
+        *reinterpret_cast<uint2*>(d_ + PLANE) = make_uint2(l0_, l1_);                                                  \
+    }
+    // epilogue of accumulator register r_ of the previous tile (full tile: no predicates)
+#define P3_STORE_REG(r_)                                                                                               \
+    {                                                                                                                  \
+        const int ro_ = ((r_) & 3) + 8 * ((r_) >> 2);                                                                  \
+        float v_ = out[r_];                                                                                            \
+        if (EPI == 0) {                                                                                                \
+            v_ = fmaxf(v_ + bv, 0.f);                                                                                  \
+            const unsigned long long bal_ = __ballot(v_ > 0.f);                                                        \
+            const unsigned mwd_ = g ? (unsigned)(bal_ >> 32) : (unsigned)bal_;                                         \
+            mwsel = (li == (r_)) ? mwd_ : mwsel;                                                                       \
+        } else {                                                                                                       \
+            const unsigned mq_ = mlp_[ro_]; /* mask word of the row: the two halves read two broadcast addresses */   \
+            v_ = ((mq_ >> li) & 1u) ? v_ : 0.f;                                                                        \
+        }                                                                                                              \
+        cb[ro_ * 256] = v_;                                                                                            \
+        cmax = fmaxf(cmax, fabsf(v_));                                                                                 \
+    }
+
+    // one tile step.  FIRST: no previous tile to store.  SN = register slot of tile j+1 (compile-time).
+#define P3_STEP(j_, SN_, FIRST_)                                                                                       \
+    {                                                                                                                  \
+        const int pb = (j_) & 1;                                                                                       \
+        const unsigned char* ps_ = Ps + (pb * 32 + li) * RS + g * 16;                                                  \
+        const int ptile_ = blockIdx.x + ((j_) - 1) * G;                                                                \
+        float* cb = C + (size_t)(ptile_ * 32 + 4 * g) * 256 + col;                                                     \
+        unsigned* mb = mask + (size_t)(ptile_ * 32 + 4 * g) * 8 + wv;                                                  \
+        unsigned mwsel = 0u;                                                                                           \
+        const unsigned* mlp_ = mlds + (1 - pb) * 256 + wv * 32 + 4 * g; /* previous tile's mask words */               \
+        float m_[4], sc_[4];                                                                                           \
+        f16x8 fh_[2], fl_[2]; /* fragments one K step ahead (the slices between the MFMAs cover the LDS latency) */      \
+        fh_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_));                                                       \
+        fl_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE));                                               \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ks++) {                                                            \
+            if (ks + 1 < KS) {                                                                                         \
+                fh_[(ks + 1) & 1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (ks + 1) * 32));                    \
+                fl_[(ks + 1) & 1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (ks + 1) * 32));            \
+            }                                                                                                          \
+            /* one accumulator chain: the VALU slices between the MFMAs cover the dependent-issue latency, and the */   \
+            /* second chain's 16 registers are what keeps this kernel out of scratch                                */   \
+            if (ks == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bl[0], zero16, 0, 0, 0);                 \
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks & 1], bl[ks], acc, 0, 0, 0);                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks & 1], bh[ks], acc, 0, 0, 0);                           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks & 1], bh[ks], acc, 0, 0, 0);                           \
+            if (!(FIRST_) && ks < 8) {                                                                                 \
+                P3_STORE_REG(2 * ks)                                                                                   \
+                P3_STORE_REG(2 * ks + 1)                                                                               \
+                if (EPI == 0 && ks == 7 && li < 16) mb[((li & 3) + 8 * (li >> 2)) * 8] = mwsel;                        \
+            }                                                                                                          \
+            if (EPI == 1 && ks == 0) mlds[pb * 256 + wv * 32 + li] = mw[1 - (SN_)]; /* this tile's mask words */        \
+            if (ks == 8) {                                                                                             \
+                P3_ROWMAX(SN_) /* first use of tile j+1's rows: the tile's one memory wait */                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+                P3_LOAD(1 - (SN_), P3_TILE((j_) + 2))                                                                  \
+            }                                                                                                          \
+            if (ks == 9) wave_max4_stage_a(m_[0], m_[1], m_[2], m_[3]);                                                \
+            if (ks == 10) wave_max4_stage_b(m_[0], m_[1], m_[2], m_[3]);                                               \
+            if (ks == 11) P3_SCALES(pb ^ 1)                                                                            \
+            if (ks >= 12) P3_SPLIT_ROW(SN_, pb ^ 1, ks - 12)                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                              \
+        /* unscale into `out` (stored during the next step) */                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                \
+            const float4 iv = *reinterpret_cast<const float4*>(rinv + pb * 32 + q * 8 + 4 * g);                        \
+            out[q * 4 + 0] = acc[q * 4 + 0] * (iv.x * binv);                                       \
+            out[q * 4 + 1] = acc[q * 4 + 1] * (iv.y * binv);                                       \
+            out[q * 4 + 2] = acc[q * 4 + 2] * (iv.z * binv);                                       \
+            out[q * 4 + 3] = acc[q * 4 + 3] * (iv.w * binv);                                       \
+        }                                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                \
+    }
+
+    // prologue: tile 0 split into buffer 0 (not overlapped), tile 1 in flight
+    {
+        float m_[4], sc_[4];
+        P3_LOAD(0, P3_TILE(0))
+        P3_ROWMAX(0)
+        wave_max4_nonneg_lane63(m_[0], m_[1], m_[2], m_[3]);
+        P3_SCALES(0)
+#pragma unroll
+        for (int r = 0; r < 4; r++) P3_SPLIT_ROW(0, 0, r)
+        P3_LOAD(1, P3_TILE(1))
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    P3_STEP(0, 1, true)
+    for (int j = 1; j < my_tiles; j += 2) {
+        P3_STEP(j, 0, false)
+        if (j + 1 < my_tiles) P3_STEP(j + 1, 1, false)
+    }
+    {   // the workgroup's final tile (the only one that can be partial): predicated store of `out`
+        const int tile = last_tile;
+        const int row0 = tile * 32 + 4 * g;
+        float* cb = C + (size_t)row0 * 256 + col;
+        unsigned* mb = mask + (size_t)row0 * 8 + wv;
+        const unsigned* ml = mlds + ((my_tiles - 1) & 1) * 256 + wv * 32;
+        if (tile * 32 + 32 <= M) gemm3r_store<EPI, true>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
+        else gemm3r_store<EPI, false>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
+    }
+    if (colmax != nullptr) {
+        const float o = __shfl_xor(cmax, 32, 64);
+        cmax = fmaxf(cmax, o);
+        if (g == 0) atomicMax(colmax + col, __float_as_uint(cmax));
+    }
+#undef P3_TILE
+#undef P3_LOAD
+#undef P3_ROWMAX
+#undef P3_SCALES
+#undef P3_SPLIT_ROW
+#undef P3_STORE_REG
+#undef P3_STEP
 }
 
 // ---- weight gradient of the K = 256 layers --------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dg-mesh_amd/csrc tools/g3_micro.hip -o tools/bin/g3_micro
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "mlp_f16x3.hpp"
 namespace dgm {
@@ -23,6 +24,25 @@ float run(int M, int ncu, const float* A, const uint4* Bp, const float* binv, co
     hipEventRecord(a);
     for (int i = 0; i < 20; i++)
         hipLaunchKernelGGL((g3_kernel<EPI, 16, 1, VAR>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, 256, (const float*)nullptr, 0, Bp, binv, bias, mask, C, cmax);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / 20 * 1000.f;
+}
+
+template <int EPI>
+float run_p(int M, int ncu, const float* A, const uint4* Bp, const float* binv, const float* bias, unsigned* mask, float* C, unsigned* cmax) {
+    const int nt = (M + 31) / 32, gx = nt < ncu ? nt : ncu;
+    const int lds = 2 * 32 * (4 * 256 + 16) + 256 + 2048;
+    hipFuncSetAttribute((const void*)mlp_gemm3p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    for (int i = 0; i < 3; i++)
+        hipLaunchKernelGGL((mlp_gemm3p_kernel<EPI>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax);
+    hipEventRecord(a);
+    for (int i = 0; i < 20; i++)
+        hipLaunchKernelGGL((mlp_gemm3p_kernel<EPI>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms = 0;
@@ -54,6 +74,9 @@ int main() {
     CK(hipMemset(cmax, 0, 1024));
     printf("CUs %d, M %d; times in us per launch\n", ncu, M);
 #define RUN(E, V, what) printf("EPI %d VAR %2d %-40s %8.1f\n", E, V, what, run<E, V>(M, ncu, A, Bp, binv, bias, mask, C, cmax));
+    printf("product mlp_gemm3p_kernel<0> (software-pipelined)   %8.1f\n", run_p<0>(M, ncu, A, Bp, binv, bias, mask, C, cmax));
+    printf("product mlp_gemm3p_kernel<1>                         %8.1f\n", run_p<1>(M, ncu, A, Bp, binv, bias, mask, C, cmax));
+    if (getenv("G3_ONLY_P")) return 0;
     RUN(0, 0, "full")
     RUN(0, 1, "no MFMA")
     RUN(0, 2, "no stores")
