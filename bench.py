@@ -13,7 +13,7 @@ Frames shard across ranks (weak scaling: every rank renders its own 800x800 fram
 Rank 0 prints ONE JSON line.  `value` = frames trained per second over all ranks, inputs resident in HBM.
 `roofline` describes the DOMINANT hand-written kernel of the step -- chosen at run time as the instrumented kernel
 with the largest (average launch time x launches per step); today one 256 -> 256 trunk-layer GEMM of the deformation
-MLP (mlp_gemm3r_kernel) -- timed with hipEvents recorded on the launch stream inside the timed region (deferred
+MLP (mlp_gemm3p_kernel) -- timed with hipEvents recorded on the launch stream inside the timed region (deferred
 read-out, no extra sync) and priced against BOTH roofs it can hit: HBM (algorithmic bytes / 8 TB/s) and the f16
 matrix pipe it issues on (3 MFMAs per fp32 product: 3 x flops / 2.5 PFLOP/s); `bound` is the nearer one.
 `roofline_render_bwd` is the rasterizer backward, the kernel group BASELINE.json's north_star grades against HBM.
@@ -241,8 +241,8 @@ def main():
         layer_bytes = 2.0 * P * 256 * 4 + P * 32 + 256 * 256 * 4  # A in + C out (fp32) + ReLU mask bits + the weights once
         dw_bytes = 2.0 * P * 256 * 4 + 256 * 256 * 4  # X in + G in + the gradient once (the per-CU partial tiles are overhead)
         kern = {  # stage -> (kernel name, algorithmic flops, algorithmic bytes, committed PMC file)
-            "mlp_layer_fwd": ("mlp_gemm3r_kernel<0,16,2> (256->256 layer forward, N rows)" if f16x3 else "mlp_gemm6r_kernel<0,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_fwd.json"),
-            "mlp_layer_bwd": ("mlp_gemm3r_kernel<1,16,2> (256->256 layer backward-data, N rows)" if f16x3 else "mlp_gemm6r_kernel<1,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_bwd.json"),
+            "mlp_layer_fwd": ("mlp_gemm3p_kernel<0> (256->256 layer forward, N rows)" if f16x3 else "mlp_gemm6r_kernel<0,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_fwd.json"),
+            "mlp_layer_bwd": ("mlp_gemm3p_kernel<1> (256->256 layer backward-data, N rows)" if f16x3 else "mlp_gemm6r_kernel<1,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_bwd.json"),
             "mlp_layer_dw": ("mlp_dw3b_kernel (256x256 weight gradient over N rows)" if f16x3 else "mlp_dw6b_kernel", layer_flops, dw_bytes, "pmc_dw3b.json"),
             "render_bwd": ("render_bwd3_kernel", 0.0, alg_bytes, "pmc_render_bwd3.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),

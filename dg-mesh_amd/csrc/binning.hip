@@ -243,7 +243,7 @@ __device__ __forceinline__ void emit_sorted(const unsigned long long* s, int n, 
     }
 }
 
-// small segments (1..kSmallCap keys): one 256-thread workgroup per tile, 16 KB of LDS
+// small segments (1..kSmallCap keys): one 256-thread workgroup per tile, 32 KB of LDS
 __global__ void __launch_bounds__(256)
 tile_sort_small_kernel(int cap, int gridx, const uint2* __restrict__ ranges,
                        const unsigned long long* __restrict__ keys, const float* __restrict__ rec,
@@ -286,7 +286,7 @@ tile_sort_big_kernel(int cap, int gridx, const unsigned* __restrict__ big_list, 
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------------
-static constexpr int kSmallCap = 2048;   // 16 KB of LDS keys, 256 threads
+static constexpr int kSmallCap = 4096;   // 32 KB of LDS keys, 256 threads (cfg2 centre tiles reach 2-3 k entries on some frames)
 static constexpr int kLargeCap = 16384;  // 128 KB of LDS keys, 1024 threads
 
 int binning_lds_limit_tiles() { return 36 * 1024; }  // 144 KB of u32 counters

@@ -105,7 +105,7 @@ typedef struct {
     size_t hist;          /* u32[n_chunks][tiles] */
     size_t tile_count;    /* u32[tiles] */
     size_t tile_offset;   /* u32[tiles+1] */
-    size_t big_list;      /* u32[tiles] worklist of tiles with more than 2048 instances */
+    size_t big_list;      /* u32[tiles] worklist of tiles with more than 4096 instances */
     size_t counters;      /* u32[8]: [0] = num_rendered, [1] = error flags, [2] = big_list length */
     size_t geometry_bytes;
     /* binning buffer */

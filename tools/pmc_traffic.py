@@ -10,7 +10,7 @@ import os
 import sys
 
 fetch_csv, write_csv, out_dir, workload = sys.argv[1:5]
-KERNELS = {"gemm3r_fwd": "mlp_gemm3r_kernel<0, 16, 2>", "gemm3r_bwd": "mlp_gemm3r_kernel<1, 16, 2>", "dw3b": "mlp_dw3b_kernel",
+KERNELS = {"gemm3r_fwd": "mlp_gemm3p_kernel<0>", "gemm3r_bwd": "mlp_gemm3p_kernel<1>", "dw3b": "mlp_dw3b_kernel",
            "render_bwd3": "render_bwd3_kernel", "render_fwd": "render_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
            "tile_sort_small": "tile_sort_small_kernel"}
 
