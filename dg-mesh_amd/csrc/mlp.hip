@@ -635,9 +635,10 @@ hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once 
     static bool done[DGM_MAX_DEVICES] = {false};
     bool& d = done[current_device_slot()];
     if (d) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_gemm3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)mlp_gemm3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+    hipError_t e = hipSuccess;
+    const void* fns[4] = {(const void*)mlp_gemm3p_kernel<0, false>, (const void*)mlp_gemm3p_kernel<0, true>,
+                          (const void*)mlp_gemm3p_kernel<1, false>, (const void*)mlp_gemm3p_kernel<1, true>};
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
     if (e == hipSuccess) d = true;
     return e;
 }
@@ -798,14 +799,19 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             if (K1 + K2 == MLP_EMB + MLP_W) {  // skip layer: bf16x6, weights streamed through LDS
                 hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2,
                                    lda2, K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W);
-                if (use_f16x3())  // this producer does not deliver the column maxima the next layer's dW scales need
-                    hipLaunchKernelGGL(mlp_colmax_kernel, dim3(4 * num_cus()), dim3(256), 0, st, N, MLP_W, w.Y[l], MLP_W,
-                                       w.cmaxY + l * MLP_W);
             } else if (use_f16x3()) {
                 if (K1 + K2 == MLP_W) {
                     dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                    hipLaunchKernelGGL((mlp_gemm3p_kernel<0>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
-                                       w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W);
+                    // the skip layer (bf16x6) does not deliver the column maxima of its output, which the next layer's
+                    // weight gradient needs for its scales: the layer that READS that output accumulates them on the way
+                    if (l == p->skip_layer + 1)
+                        hipLaunchKernelGGL((mlp_gemm3p_kernel<0, true>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
+                                           w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
+                                           w.cmaxY + (l - 1) * MLP_W);
+                    else
+                        hipLaunchKernelGGL((mlp_gemm3p_kernel<0, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
+                                           w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
+                                           (unsigned*)nullptr);
                     dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
                 } else
                     hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
@@ -854,9 +860,8 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
         hipLaunchKernelGGL((mlp_gemm6_kernel<1, 2, 2, 2, 4, true>), dim3(grid6), dim3(256), 0, st, N, dOut, p->n_out, 16,
                            (const float*)nullptr, 0, 0, p->n_out, w.Wh6b, (const float*)nullptr, w.mask[7], w.Ga, MLP_W, MLP_W);
     const bool x3 = use_f16x3();
-    if (x3) {  // column maxima of G_7 for the first weight gradient's scales (the later G_l get theirs from the GEMM epilogue)
+    if (x3) {  // column maxima of the G_l for the weight gradients' scales: accumulated by the backward-data GEMMs
         if (hipMemsetAsync(w.cmaxG, 0, 8 * MLP_W * 4, st) != hipSuccess) return mlp_fail("mlp_backward: memset failed");
-        hipLaunchKernelGGL(mlp_colmax_kernel, dim3(4 * num_cus()), dim3(256), 0, st, N, MLP_W, w.Ga, MLP_W, w.cmaxG + 7 * MLP_W);
         if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
     }
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
@@ -877,6 +882,29 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             X1 = w.emb, ldx1 = MLP_EMB, K1 = MLP_EMB, X2 = w.Y[l - 1], ldx2 = MLP_W, K2 = MLP_W;
         } else {
             X1 = w.Y[l - 1], ldx1 = MLP_W, K1 = MLP_W;
+        }
+        // backward data first: G_{l-1} = (G_l W_l) masked, into the other buffer -- it also delivers the column maxima the
+        // weight gradient below needs (of G_7 through CMAX_IN, of the later G_l through the previous launch's epilogue)
+        if (l >= 1) {
+            if (f32)
+                hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W,
+                                   (const float*)nullptr, 0, 0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
+            else {
+                const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
+                dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
+                if (x3 && l == 7)  // G_7 comes from the heads kernel without column maxima: accumulated while it is read here
+                    hipLaunchKernelGGL((mlp_gemm3p_kernel<1, true>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
+                                       w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
+                                       w.cmaxG + (l - 1) * MLP_W, w.cmaxG + l * MLP_W);
+                else if (x3)
+                    hipLaunchKernelGGL((mlp_gemm3p_kernel<1, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
+                                       w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
+                                       w.cmaxG + (l - 1) * MLP_W, (unsigned*)nullptr);
+                else
+                    hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
+                                       (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn);
+                dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
+            }
         }
         const int Kp = K1 + K2;
         if (f32) {
@@ -911,22 +939,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                 hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N,
                                    p->t_dim - c0 < 16 ? p->t_dim - c0 : 16, G, p->W[l] + MLP_XE + c0, layer_in(p, l), 1,
                                    (const float*)nullptr, dtemb + c0, p->t_dim, l == 0 ? 1 : 0);
-        if (l >= 1) {
-            if (f32)
-                hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W,
-                                   (const float*)nullptr, 0, 0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
-            else {
-                const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
-                dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
-                if (x3)
-                    hipLaunchKernelGGL((mlp_gemm3p_kernel<1>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
-                                       w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
-                                       w.cmaxG + (l - 1) * MLP_W);
-                else
-                    hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
-                                       (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn);
-                dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
-            }
+        if (l >= 1) {  // (the backward-data GEMM of this layer was launched above: G_l stays intact in its buffer)
             float* t = G;
             G = Gn;
             Gn = t;

@@ -454,11 +454,12 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
 // Tail handling keeps the loop body branch-free: tile indices beyond the workgroup's last tile are clamped (the extra
 // split lands in an LDS buffer nobody reads), the first step has its own copy without an epilogue, and the globally last --
 // possibly partial -- tile is always some workgroup's final tile and is stored by the predicated path after the loop.
-template <int EPI>
+// CMAX_IN: also accumulate the column maxima of the INPUT rows (for a producer that cannot deliver them) into colmax_in.
+template <int EPI, bool CMAX_IN>
 __global__ void __launch_bounds__(512)
 mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const uint4* __restrict__ Bp,
                   const float* __restrict__ b_inv_scale, const float* __restrict__ bias, unsigned* __restrict__ mask,
-                  float* __restrict__ C, unsigned* __restrict__ colmax) {
+                  float* __restrict__ C, unsigned* __restrict__ colmax, unsigned* __restrict__ colmax_in) {
     constexpr int KS = 16, K = 256, RS = 4 * K + 16, PLANE = 2 * K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ps = smem;                                          // [2][32][RS]
@@ -481,6 +482,7 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
     const float binv = b_inv_scale[col];
     const float bv = (EPI == 0) ? bias[col] : 0.f;
     float cmax = 0.f;
+    float4 cin = make_float4(0.f, 0.f, 0.f, 0.f);  // CMAX_IN: running maxima of input columns 4 lane .. 4 lane + 3
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc, out;
     float4 R[2][4];     // rows of tile t live in R[t & 1]
@@ -505,6 +507,10 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
         _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
             const float4 v_ = R[slot_][r_];                                                                            \
             m_[r_] = fmaxf(fmaxf(fabsf(v_.x), fabsf(v_.y)), fmaxf(fabsf(v_.z), fabsf(v_.w)));                          \
+            if (CMAX_IN) {                                                                                             \
+                cin.x = fmaxf(cin.x, fabsf(v_.x)), cin.y = fmaxf(cin.y, fabsf(v_.y));                                  \
+                cin.z = fmaxf(cin.z, fabsf(v_.z)), cin.w = fmaxf(cin.w, fabsf(v_.w));                                  \
+            }                                                                                                          \
         }                                                                                                              \
     }
 #define P3_SCALES(pb_)                                                                                                 \
@@ -622,6 +628,19 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
         const unsigned* ml = mlds + ((my_tiles - 1) & 1) * 256 + wv * 32;
         if (tile * 32 + 32 <= M) gemm3r_store<EPI, true>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
         else gemm3r_store<EPI, false>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
+    }
+    if (CMAX_IN && colmax_in != nullptr) {
+        // the clamped tail re-reads the last tile (same values: harmless for a maximum); fold the eight waves through LDS
+        unsigned* red = reinterpret_cast<unsigned*>(smem);  // the plane buffers are dead after the last barrier ...
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... once every wave is past its last fragment read
+        if (tid < 256) red[tid] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        atomicMax(red + 4 * lane + 0, __float_as_uint(cin.x));
+        atomicMax(red + 4 * lane + 1, __float_as_uint(cin.y));
+        atomicMax(red + 4 * lane + 2, __float_as_uint(cin.z));
+        atomicMax(red + 4 * lane + 3, __float_as_uint(cin.w));
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < 256) atomicMax(colmax_in + tid, red[tid]);
     }
     if (colmax != nullptr) {
         const float o = __shfl_xor(cmax, 32, 64);

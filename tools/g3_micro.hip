@@ -35,14 +35,14 @@ template <int EPI>
 float run_p(int M, int ncu, const float* A, const uint4* Bp, const float* binv, const float* bias, unsigned* mask, float* C, unsigned* cmax) {
     const int nt = (M + 31) / 32, gx = nt < ncu ? nt : ncu;
     const int lds = 2 * 32 * (4 * 256 + 16) + 256 + 2048;
-    hipFuncSetAttribute((const void*)mlp_gemm3p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)mlp_gemm3p_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t a, b;
     hipEventCreate(&a), hipEventCreate(&b);
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL((mlp_gemm3p_kernel<EPI>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax);
+        hipLaunchKernelGGL((mlp_gemm3p_kernel<EPI, false>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax, (unsigned*)nullptr);
     hipEventRecord(a);
     for (int i = 0; i < 20; i++)
-        hipLaunchKernelGGL((mlp_gemm3p_kernel<EPI>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax);
+        hipLaunchKernelGGL((mlp_gemm3p_kernel<EPI, false>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax, (unsigned*)nullptr);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms = 0;
