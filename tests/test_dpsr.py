@@ -52,7 +52,8 @@ def test_dpsr_properties_at_training_resolution():
     dpsr = D.DPSR(res=(res, res, res), sig=2.0)
     phi = dpsr(V.unsqueeze(0), N.unsqueeze(0))[0]
     c = res // 2
-    assert float(phi[c, c, c]) * float(phi[0, 0, 0]) < 0 and abs(abs(float(phi[0, 0, 0])) - 0.5) < 1e-5
+    pd = phi.detach()
+    assert float(pd[c, c, c]) * float(pd[0, 0, 0]) < 0 and abs(abs(float(pd[0, 0, 0])) - 0.5) < 1e-5
     fv = D.grid_interp(phi.detach().unsqueeze(0).unsqueeze(-1), V.unsqueeze(0))[0, :, 0]
     assert abs(float(fv.mean())) < 2e-3 * float(phi.abs().max())
     w = torch.randn(res, res, res, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
