@@ -48,6 +48,7 @@ SYMBOLS = {
     "dgm_image_bytes": (_c.c_size_t, [_i, _i]),
     "dgm_describe_state": (_i, [_i, _i, _i, _i, _c.POINTER(StateLayout)]),
     "dgm_set_profiling": (None, [_i]),
+    "dgm_set_profiling_sampling": (None, [_i]),
     "dgm_get_stage_ms": (_i, [_c.POINTER(_f), _i]),
     "dgm_collect_stage_ms": (_i, [_c.POINTER(_f), _c.POINTER(_i), _i]),
     "dgm_stage_name": (_c.c_char_p, [_i]),

@@ -85,6 +85,11 @@ constexpr int kMaxDeferred = 4096;
 EventPair g_deferred[DGM_STAGE_COUNT][kMaxDeferred];
 int g_deferred_n[DGM_STAGE_COUNT] = {0};
 int g_deferred_created[DGM_STAGE_COUNT] = {0};
+// sampling: only every g_sample_every-th launch of a stage is bracketed (two hipEventRecord per bracket cost host time
+// and a marker packet each; ~90 brackets per train step otherwise)
+int g_sample_every = 1;
+int g_calls[DGM_STAGE_COUNT] = {0};
+bool g_open[DGM_STAGE_COUNT] = {false};
 
 int fail(const char* fmt, ...) {
     char buf[1024];
@@ -119,7 +124,7 @@ struct StageTimer {
             used[s] = true;
         } else if (mode == 2) {
             std::lock_guard<std::mutex> lk(g_prof_mu);
-            if (g_deferred_n[s] >= kMaxDeferred) return;
+            if ((g_calls[s]++ % g_sample_every) != 0 || g_deferred_n[s] >= kMaxDeferred) return;
             const int i = g_deferred_n[s];
             if (i >= g_deferred_created[s]) {
                 (void)hipEventCreate(&g_deferred[s][i].a);
@@ -158,7 +163,9 @@ namespace dgm {
 void prof_begin(int s, hipStream_t st) {
     if (g_profile != 2) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_deferred_n[s] >= kMaxDeferred) return;
+    g_open[s] = false;
+    if ((g_calls[s]++ % g_sample_every) != 0 || g_deferred_n[s] >= kMaxDeferred) return;
+    g_open[s] = true;
     const int i = g_deferred_n[s];
     if (i >= g_deferred_created[s]) {
         (void)hipEventCreate(&g_deferred[s][i].a);
@@ -170,6 +177,8 @@ void prof_begin(int s, hipStream_t st) {
 void prof_end(int s, hipStream_t st) {
     if (g_profile != 2) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_open[s]) return;
+    g_open[s] = false;
     if (g_deferred_n[s] >= kMaxDeferred || g_deferred_n[s] >= g_deferred_created[s]) return;
     (void)hipEventRecord(g_deferred[s][g_deferred_n[s]].b, st);
     g_deferred_n[s]++;
@@ -208,7 +217,11 @@ void dgm_set_profiling(int mode) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_profile = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     if (g_profile == 2)
-        for (int s = 0; s < DGM_STAGE_COUNT; s++) g_deferred_n[s] = 0;
+        for (int s = 0; s < DGM_STAGE_COUNT; s++) g_deferred_n[s] = 0, g_calls[s] = 0, g_open[s] = false;
+}
+void dgm_set_profiling_sampling(int every) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_sample_every = every < 1 ? 1 : every;
 }
 int dgm_collect_stage_ms(float* avg_ms, int* counts, int capacity) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -224,8 +237,9 @@ int dgm_collect_stage_ms(float* avg_ms, int* counts, int capacity) {
             }
         }
         avg_ms[s] = ok ? (float)(tot / ok) : 0.f;
-        if (counts) counts[s] = ok;
+        if (counts) counts[s] = ok ? g_calls[s] : 0;  // launches since the mode was set (the average is over the sampled ones)
         g_deferred_n[s] = 0;
+        g_calls[s] = 0;
     }
     return n;
 }

@@ -37,40 +37,54 @@ class MultiAdam:
             raise ValueError("MultiAdam: optimizer state does not match its parameter's shape (surgery left it stale)")
         return s
 
-    @torch.no_grad()
-    def step(self, grads=None):
-        """grads: optional dict id(param) -> gradient tensor overriding param.grad (e.g. views of a reduced bucket)."""
-        L = _lib.lib()
+    def _plan(self):
+        """Everything that only changes when the parameter set does (pointers of parameters and moments, sizes, grouping by
+        hyper-parameters) is gathered once and reused; only gradients, learning rates and step counts are per call."""
+        sig = tuple(id(p) for o in self.optimizers for g in o.param_groups for p in g["params"])
+        if getattr(self, "_sig", None) == sig:
+            return self._cached
         by_hyper = {}
         for o in self.optimizers:
             for g in o.param_groups:
                 key = (float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
                 for p in g["params"]:
-                    gr = grads.get(id(p)) if grads is not None else p.grad
-                    if gr is None:
-                        continue
-                    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                        raise ValueError("MultiAdam: parameters must be contiguous fp32 device tensors")
-                    if gr.dtype != torch.float32 or gr.shape != p.shape:
-                        raise ValueError("MultiAdam: gradient / parameter mismatch")
-                    gr = gr if gr.is_contiguous() else gr.contiguous()
-                    s = self._slot(o, p)
-                    if not (s["exp_avg"].is_contiguous() and s["exp_avg_sq"].is_contiguous()):
-                        s["exp_avg"], s["exp_avg_sq"] = s["exp_avg"].contiguous(), s["exp_avg_sq"].contiguous()
-                    step = int(s["step"]) + 1  # a host scalar tensor, as torch.optim.Adam keeps it
-                    if torch.is_tensor(s["step"]) and not s["step"].is_cuda:
-                        s["step"].fill_(float(step))
-                    else:
-                        s["step"] = torch.tensor(float(step))
-                    by_hyper.setdefault(key, []).append((p, gr, (s["exp_avg"], s["exp_avg_sq"], step), float(g["lr"])))
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for (b1, b2, eps), items in by_hyper.items():
-            n = len(items)
+                    by_hyper.setdefault(key, []).append((o, g, p))
+        self._sig, self._cached = sig, by_hyper
+        return by_hyper
+
+    @torch.no_grad()
+    def step(self, grads=None):
+        """grads: optional dict id(param) -> gradient tensor overriding param.grad (e.g. views of a reduced bucket)."""
+        L = _lib.lib()
+        stream = None
+        for (b1, b2, eps), entries in self._plan().items():
+            P, G, M, V, N, LR, ST = [], [], [], [], [], [], []
+            for o, g, p in entries:
+                gr = grads.get(id(p)) if grads is not None else p.grad
+                if gr is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise ValueError("MultiAdam: parameters must be contiguous fp32 device tensors")
+                if gr.dtype != torch.float32 or gr.shape != p.shape:
+                    raise ValueError("MultiAdam: gradient / parameter mismatch")
+                gr = gr if gr.is_contiguous() else gr.contiguous()
+                s = self._slot(o, p)
+                if not (s["exp_avg"].is_contiguous() and s["exp_avg_sq"].is_contiguous()):
+                    s["exp_avg"], s["exp_avg_sq"] = s["exp_avg"].contiguous(), s["exp_avg_sq"].contiguous()
+                step = int(s["step"]) + 1  # a host scalar tensor, as torch.optim.Adam keeps it
+                if torch.is_tensor(s["step"]) and not s["step"].is_cuda:
+                    s["step"].fill_(float(step))
+                else:
+                    s["step"] = torch.tensor(float(step))
+                P.append(p.data_ptr()), G.append(gr.data_ptr()), M.append(s["exp_avg"].data_ptr()), V.append(s["exp_avg_sq"].data_ptr())
+                N.append(p.numel()), LR.append(float(g["lr"])), ST.append(step)
+            n = len(P)
+            if n == 0:
+                continue
             VP = ctypes.c_void_p * n
-            rc = L.dgm_adam_step(
-                n, VP(*[it[0].data_ptr() for it in items]), VP(*[it[1].data_ptr() for it in items]),
-                VP(*[it[2][0].data_ptr() for it in items]), VP(*[it[2][1].data_ptr() for it in items]),
-                (ctypes.c_longlong * n)(*[it[0].numel() for it in items]), (ctypes.c_float * n)(*[it[3] for it in items]),
-                (ctypes.c_int * n)(*[it[2][2] for it in items]), b1, b2, eps, stream)
+            if stream is None:
+                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = L.dgm_adam_step(n, VP(*P), VP(*G), VP(*M), VP(*V), (ctypes.c_longlong * n)(*N), (ctypes.c_float * n)(*LR),
+                                 (ctypes.c_int * n)(*ST), b1, b2, eps, stream)
             if rc != 0:
                 raise RuntimeError(L.dgm_last_error().decode())

@@ -72,12 +72,20 @@ class FlatGradBucket:
         return self.flat.numel() * self.flat.element_size()
 
 
+_PERM_CACHE = {}
+
+
 def frame_schedule(n_frames, step, rank, world, seed=0):
     """Index of the camera rank `rank` renders at `step`: a shared-seed shuffle per epoch, strided by rank."""
     per_epoch = max(n_frames // world, 1)
     epoch, k = divmod(step, per_epoch)
-    perm = list(range(n_frames))
-    random.Random(seed * 1000003 + epoch).shuffle(perm)
+    key = (n_frames, seed, epoch)
+    perm = _PERM_CACHE.get(key)
+    if perm is None:  # one shuffle per epoch, not per step
+        perm = list(range(n_frames))
+        random.Random(seed * 1000003 + epoch).shuffle(perm)
+        _PERM_CACHE.clear()
+        _PERM_CACHE[key] = perm
     return perm[(k * world + rank) % n_frames]
 
 

@@ -135,7 +135,9 @@ int dgm_describe_state(int P, int width, int height, int R, dgm_state_layout* ou
  * dgm_set_profiling(2): deferred -- calls only record events (no synchronisation inside a timed region);
  *     after the caller has synchronised, dgm_collect_stage_ms() returns the average duration and the
  *     number of launches of every stage since the mode was set (and resets them);
- * dgm_set_profiling(0): off.  State is process-wide (PyTorch runs backward on its own thread). */
+ * dgm_set_profiling(0): off.  State is process-wide (PyTorch runs backward on its own thread).
+ * dgm_set_profiling_sampling(n): in deferred mode bracket only every n-th launch of a stage (default 1); the averages are
+ *     over the sampled launches, the counts are all launches. */
 enum {
     DGM_STAGE_PREPROCESS = 0,
     DGM_STAGE_BIN_COUNT,
@@ -151,6 +153,7 @@ enum {
     DGM_STAGE_COUNT
 };
 void dgm_set_profiling(int mode);
+void dgm_set_profiling_sampling(int every);
 int dgm_get_stage_ms(float* ms, int capacity);
 int dgm_collect_stage_ms(float* avg_ms, int* counts, int capacity);
 const char* dgm_stage_name(int stage);
