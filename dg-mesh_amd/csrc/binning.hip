@@ -17,7 +17,7 @@
 //                (depth_bits << 32 | gaussian) straight into its tile segment;
 //   4. sort    : one workgroup per tile sorts its segment in LDS (normalised bitonic network on the
 //                64-bit keys => deterministic order independent of the atomic arrival order) and emits
-//                point_list plus the inverse map inv[offs[g]+k] = slot used by the backward gather.
+//                point_list plus upos[slot] = offs[g]+k, the instance's position in the per-Gaussian order (backward rows).
 // Wave-cooperative rectangle expansion: a wave loads 64 Gaussians, then iterates over the lanes that own a
 // non-empty rectangle (scalar bit loop on the ballot mask) and lets all 64 lanes cover that rectangle's
 // tiles, so a Gaussian spanning thousands of tiles costs the same lane-cycles as many small ones.
@@ -230,7 +230,7 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* s, int n) {
 
 __device__ __forceinline__ void emit_sorted(const unsigned long long* s, int n, unsigned r0, int tile, int gridx,
                                             const float* __restrict__ rec, unsigned* __restrict__ point_list,
-                                            unsigned* __restrict__ inv, int threads) {
+                                            unsigned* __restrict__ upos, int threads) {
     const unsigned tx = (unsigned)(tile % gridx), ty = (unsigned)(tile / gridx);
     for (int i = threadIdx.x; i < n; i += threads) {
         const unsigned g = (unsigned)s[i];
@@ -239,7 +239,7 @@ __device__ __forceinline__ void emit_sorted(const unsigned long long* s, int n, 
         unsigned xmin, ymin, w;
         unpack_rect(__float_as_uint(r2.y), xmin, ymin, w);
         const unsigned k = (ty - ymin) * w + (tx - xmin);
-        inv[__float_as_uint(r2.z) + k] = r0 + i;
+        upos[r0 + i] = __float_as_uint(r2.z) + k;
     }
 }
 
@@ -247,7 +247,7 @@ __device__ __forceinline__ void emit_sorted(const unsigned long long* s, int n, 
 __global__ void __launch_bounds__(256)
 tile_sort_small_kernel(int cap, int gridx, const uint2* __restrict__ ranges,
                        const unsigned long long* __restrict__ keys, const float* __restrict__ rec,
-                       unsigned* __restrict__ point_list, unsigned* __restrict__ inv) {
+                       unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const int tile = blockIdx.x;
     const uint2 r = ranges[tile];
@@ -256,7 +256,7 @@ tile_sort_small_kernel(int cap, int gridx, const uint2* __restrict__ ranges,
     for (int i = threadIdx.x; i < n; i += 256) skeys[i] = keys[r.x + i];
     __syncthreads();
     bitonic_sort<256, false>(skeys, n);
-    emit_sorted(skeys, n, r.x, tile, gridx, rec, point_list, inv, 256);
+    emit_sorted(skeys, n, r.x, tile, gridx, rec, point_list, upos, 256);
 }
 
 // big segments come from a device-built worklist (write_ranges_kernel), walked by a FIXED grid so that no
@@ -265,7 +265,7 @@ tile_sort_small_kernel(int cap, int gridx, const uint2* __restrict__ ranges,
 __global__ void __launch_bounds__(1024)
 tile_sort_big_kernel(int cap, int gridx, const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
                      const uint2* __restrict__ ranges, unsigned long long* __restrict__ keys,
-                     const float* __restrict__ rec, unsigned* __restrict__ point_list, unsigned* __restrict__ inv) {
+                     const float* __restrict__ rec, unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const unsigned count = *big_count;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
@@ -276,10 +276,10 @@ tile_sort_big_kernel(int cap, int gridx, const unsigned* __restrict__ big_list, 
             for (int i = threadIdx.x; i < n; i += 1024) skeys[i] = keys[r.x + i];
             __syncthreads();
             bitonic_sort<1024, false>(skeys, n);
-            emit_sorted(skeys, n, r.x, tile, gridx, rec, point_list, inv, 1024);
+            emit_sorted(skeys, n, r.x, tile, gridx, rec, point_list, upos, 1024);
         } else {
             bitonic_sort<1024, true>(keys + r.x, n);
-            emit_sorted(keys + r.x, n, r.x, tile, gridx, rec, point_list, inv, 1024);
+            emit_sorted(keys + r.x, n, r.x, tile, gridx, rec, point_list, upos, 1024);
         }
         __syncthreads();
     }
@@ -333,7 +333,7 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
 }
 
 hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, unsigned long long* keys,
-                            const float* rec, unsigned* point_list, unsigned* inv, const unsigned* big_list,
+                            const float* rec, unsigned* point_list, unsigned* upos, const unsigned* big_list,
                             const unsigned* big_count) {
     static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
     bool& attr_set = attr_set_dev[current_device_slot()];
@@ -344,9 +344,9 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* r
         attr_set = true;
     }
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(tiles), dim3(256), kSmallCap * 8, st, kSmallCap, gridx, ranges, keys,
-                       rec, point_list, inv);
+                       rec, point_list, upos);
     hipLaunchKernelGGL(tile_sort_big_kernel, dim3(256), dim3(1024), kLargeCap * 8, st, kLargeCap, gridx, big_list,
-                       big_count, ranges, keys, rec, point_list, inv);
+                       big_count, ranges, keys, rec, point_list, upos);
     return hipSuccess;
 }
 

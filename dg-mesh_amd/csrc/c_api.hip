@@ -35,7 +35,7 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, unsigned long long* keys);
 hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, unsigned long long* keys,
-                            const float* rec, unsigned* point_list, unsigned* inv, const unsigned* big_list,
+                            const float* rec, unsigned* point_list, unsigned* upos, const unsigned* big_list,
                             const unsigned* big_count);
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
@@ -44,14 +44,14 @@ void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const uns
 // render_bwd3.hip
 void launch_render_bwd3(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
-                        const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc, float* slab);
+                        const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc, const unsigned* upos, float* slab);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
                            const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
-                           const float* rec, const unsigned* tiles_touched, const unsigned* offs, const unsigned* inv,
-                           const float* slab, const uint2* ranges, const unsigned* nproc, float* dL_dmean2D,
+                           const float* rec, const unsigned* tiles_touched, const unsigned* offs, const float* slab,
+                           float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                            float* dL_dsh, float* dL_dscale, float* dL_drot);
 // knn.hip
@@ -370,7 +370,7 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
     bin = align_ptr(bin);
     unsigned long long* keys = (unsigned long long*)(bin + L.keys);
     unsigned* point_list = (unsigned*)(bin + L.point_list);
-    unsigned* inv = (unsigned*)(bin + L.inv);
+    unsigned* upos = (unsigned*)(bin + L.upos);
     float4* ckpt = (float4*)(bin + L.ckpt);
 
     tm.begin(DGM_STAGE_BIN_COUNT);
@@ -391,7 +391,7 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
         tm.end(DGM_STAGE_BIN_SCATTER);
 
         tm.begin(DGM_STAGE_TILE_SORT);
-        DGM_HIP(launch_tile_sort(st, tiles, gridx, ranges, keys, rec, point_list, inv, big_list, counters + 2));
+        DGM_HIP(launch_tile_sort(st, tiles, gridx, ranges, keys, rec, point_list, upos, big_list, counters + 2));
         DGM_CHECK("tile_sort");
         tm.end(DGM_STAGE_TILE_SORT);
     }
@@ -435,7 +435,7 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
     const float* cov3D = (const float*)(geom + L.cov3D);
     const uint8_t* clamped = (const uint8_t*)(geom + L.clamped);
     const unsigned* point_list = (const unsigned*)(bin + L.point_list);
-    const unsigned* inv = (const unsigned*)(bin + L.inv);
+    const unsigned* upos = (const unsigned*)(bin + L.upos);
     float* slab = (float*)(bin + L.slab);
     const unsigned* n_contrib = (const unsigned*)(img + L.n_contrib);
     const uint2* ranges = (const uint2*)(img + L.ranges);
@@ -450,7 +450,7 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
     launch_render_bwd3(st, tiles, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, n_contrib,
-                       dL_dpix, nproc, slab);
+                       dL_dpix, nproc, upos, slab);
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);
 
@@ -459,7 +459,7 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
     // with precomputed colours the SH branch is skipped (backward.cu:390: `if (shs)`)
     launch_preprocess_bwd(st, P, D, M, gridx, means3D, radii, colors_precomp ? nullptr : shs, clamped, scales, rotations,
                           scale_modifier, cov3D_ptr, viewmatrix, projmatrix, campos, focal_x, focal_y, tan_fovx,
-                          tan_fovy, width, height, rec, tiles_touched, offs, inv, slab, ranges, nproc, dL_dmean2D, dL_dconic,
+                          tan_fovy, width, height, rec, tiles_touched, offs, slab, dL_dmean2D, dL_dconic,
                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     DGM_CHECK("preprocess_bwd");
     tm.end(DGM_STAGE_PREPROCESS_BWD);

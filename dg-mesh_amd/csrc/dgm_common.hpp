@@ -60,7 +60,7 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     o = 0;
     L->keys = take(Rz * 8);
     L->point_list = take(Rz * 4);
-    L->inv = take(Rz * 4);
+    L->upos = take(Rz * 4);
     L->slab = take(Rz * DGM_SLAB_STRIDE * 4);
     L->ckpt = take((Rz / 256 + 1) * 256 * 16);  // per (tile, 256-entry round boundary): (T, C) of the tile's 256 pixels
     L->binning_bytes = o + A;

@@ -304,6 +304,74 @@ __global__ void mlp_reduce_dw_kernel(int chunks, int db_chunks, int Kp, int in_f
     }
 }
 
+// The same reduction in ONE pass for the matrix-core paths (256 partial tiles of 256 KB per layer: the read is the cost).
+// Workgroup = a 4 x 32 piece of the (k, j) plane as 32 float4 positions, times 8 groups of chunks: every thread streams its
+// group's chunks with eight 16-byte loads in flight, the eight group sums meet in LDS (fixed order), and the piece is
+// written transposed into the PyTorch (out, in) layout, four consecutive k per thread.  The first 32 workgroups also
+// reduce eight columns each of the bias-gradient rows (db_rows of them).
+__global__ void __launch_bounds__(256)
+mlp_reduce_dw1_kernel(int chunks, int db_rows, int Kp, int in_features, int emb_dim, const float* __restrict__ partial,
+                      const float* __restrict__ partial_db, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float4 red[8][32];
+    __shared__ float redb[32][8];
+    const int tid = threadIdx.x, pos = tid & 31, grp = tid >> 5;
+    const int k0 = (blockIdx.x >> 3) * 4, j0 = (blockIdx.x & 7) * 32;
+    {
+        const int k = k0 + (pos >> 3), j = j0 + (pos & 7) * 4;
+        const int per = (chunks + 7) >> 3;
+        const int c1 = min(chunks, (grp + 1) * per);
+        int c = grp * per;
+        const size_t cs = (size_t)Kp * MLP_W;
+        const float* src = partial + (size_t)k * MLP_W + j;
+        float4 sp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (; c + 8 <= c1; c += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(c + u) * cs);
+#pragma unroll
+            for (int u = 0; u < 8; u++) sp[u].x += v[u].x, sp[u].y += v[u].y, sp[u].z += v[u].z, sp[u].w += v[u].w;
+        }
+        for (; c < c1; c++) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * cs);
+            sp[0].x += v.x, sp[0].y += v.y, sp[0].z += v.z, sp[0].w += v.w;
+        }
+#pragma unroll
+        for (int u = 4; u >= 1; u >>= 1)
+#pragma unroll
+            for (int v = 0; v < u; v++)
+                sp[v].x += sp[v + u].x, sp[v].y += sp[v + u].y, sp[v].z += sp[v + u].z, sp[v].w += sp[v + u].w;
+        red[grp][pos] = sp[0];
+    }
+    const bool do_db = db != nullptr && blockIdx.x < 32;
+    if (do_db) {
+        const int col = blockIdx.x * 8 + (tid & 7), g32 = tid >> 3;
+        float s = 0.f;
+        for (int r = g32; r < db_rows; r += 32) s += partial_db[(size_t)r * MLP_W + col];
+        redb[g32][tid & 7] = s;
+    }
+    __syncthreads();
+    if (tid < 128) {  // thread -> column j0 + tid / 4, row k0 + tid % 4
+        const int jj = tid >> 2, kk = tid & 3;
+        const float* r = reinterpret_cast<const float*>(&red[0][0]) + (kk * 8 + (jj >> 2)) * 4 + (jj & 3);
+        float s = r[0];
+#pragma unroll
+        for (int g = 1; g < 8; g++) s += r[g * 128];
+        const int k = k0 + kk;
+        int dst;
+        if (Kp == MLP_W) dst = k;
+        else if (k < MLP_EMB) dst = k < emb_dim ? k : -1;
+        else dst = k - MLP_EMB + emb_dim;
+        if (dst >= 0) dW[(size_t)(j0 + jj) * in_features + dst] = s;
+    } else if (do_db && tid < 136) {
+        const int c = tid - 128;
+        float s = redb[0][c];
+        for (int g = 1; g < 32; g++) s += redb[g][c];
+        db[blockIdx.x * 8 + c] = s;
+    }
+}
+
 // ---- small dense ops around the trunk ----------------------------------------------------------------------------------
 // out[r][c] (+)= sum_j A[r][j] * B(j, c) + bias[c],  j < 256, c < NC <= 16, B(j,c) = Bp[j*sj + c*sc].
 // Four lanes share a row (each covers 64 of the 256 inputs in 16-byte pieces), so a wave load instruction touches
@@ -578,7 +646,7 @@ int mlp_fail(const char* msg) {
     return 1;
 }
 struct Ws {
-    float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb, *part2, *part2_db;
+    float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb;
     uint4 *Wt6[8], *Wd6[8], *Wh6f, *Wh6b;  // bf16x6 weight planes
     uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
     float *wsc_f[8], *wsc_d[8];            // their inverse column scales
@@ -615,7 +683,6 @@ DwPlan dw6_plan(int N, int Kp) {
     d.chunks = (N + rows - 1) / rows;
     return d;
 }
-constexpr int DW_GROUPS = 8;  // first-level groups of the two-level dW partial reduction
 // 2: f16x3 (default; mlp_f16x3.hpp): power-of-two scaled operands split into 2 binary16, 3 partial products on the f16
 //    matrix cores for the 256-wide layers (layer 0 .. 4, 6, 7 forward, all backward-data, their weight gradients); the
 //    skip layer, the heads and the K = 96 / 352 weight gradients run the bf16x6 kernels
@@ -667,8 +734,6 @@ Ws carve(char* base, int N) {
     }
     w.partial = take(pfl * MLP_W * 4);
     w.partial_db = take(pdb * MLP_W * 4);
-    w.part2 = take((size_t)DW_GROUPS * (MLP_EMB + MLP_W) * MLP_W * 4);
-    w.part2_db = take((size_t)DW_GROUPS * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.Wt6[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 6);
     for (int l = 0; l < 8; l++) w.Wd6[l] = (uint4*)take((size_t)MLP_W * MLP_W * 6);
     w.Wh6f = (uint4*)take((size_t)MLP_W * 32 * 6);
@@ -927,12 +992,8 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             } else
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
                                    K2, G, w.partial, w.partial_db);
-            const int per_group = (d.chunks + DW_GROUPS - 1) / DW_GROUPS;
-            const int groups = (d.chunks + per_group - 1) / per_group;
-            hipLaunchKernelGGL(mlp_reduce_dw_groups_kernel, dim3((Kp * MLP_W + 255) / 256, groups), dim3(256), 0, st, d.chunks,
-                               per_group, Kp * MLP_W, w.partial, w.part2, 2, w.partial_db, w.part2_db);
-            hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, groups, groups, Kp,
-                               layer_in(p, l), p->emb_dim, w.part2, w.part2_db, dW[l], db[l]);
+            hipLaunchKernelGGL(mlp_reduce_dw1_kernel, dim3(Kp / 4 * 8), dim3(256), 0, st, d.chunks, 2 * d.chunks, Kp,
+                               layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
         }
         if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]
             for (int c0 = 0; c0 < p->t_dim; c0 += 16)     // the small kernel handles 16 output columns per pass

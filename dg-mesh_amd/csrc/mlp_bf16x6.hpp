@@ -689,40 +689,4 @@ mlp_dw6b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
         *reinterpret_cast<float2*>(partial_db + ((size_t)chunk * 2 + rg) * 256 + c2 * 2) = colsum;
 }
 
-// first reduction level of the dW partials: part2[grp][k][j] = sum of the chunks of group grp (fixed order); the
-// bias-gradient rows (db_rows per chunk, 256 wide) of the group are summed by the blocks with blockIdx.x == 0.
-__global__ void __launch_bounds__(256)
-mlp_reduce_dw_groups_kernel(int chunks, int per_group, int n, const float* __restrict__ partial, float* __restrict__ part2,
-                            int db_rows, const float* __restrict__ partial_db, float* __restrict__ part2_db) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int grp = blockIdx.y;
-    const int c0 = grp * per_group, c1 = min(chunks, c0 + per_group);
-    if (blockIdx.x == 0 && partial_db != nullptr) {
-        float sp[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) sp[u] = 0.f;
-        const float* src = partial_db + threadIdx.x;
-        int r = c0 * db_rows;
-        const int r1 = c1 * db_rows;
-        for (; r + 8 <= r1; r += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) sp[u] += src[(size_t)(r + u) * 256];
-        }
-        for (; r < r1; r++) sp[0] += src[(size_t)r * 256];
-        part2_db[grp * 256 + threadIdx.x] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
-    }
-    if (idx >= n) return;
-    float sp[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) sp[u] = 0.f;
-    const float* src = partial + idx;
-    int c = c0;
-    for (; c + 8 <= c1; c += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) sp[u] += src[(size_t)(c + u) * n];
-    }
-    for (; c < c1; c++) sp[0] += src[(size_t)c * n];
-    part2[(size_t)grp * n + idx] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
-}
-
 }  // namespace dgm

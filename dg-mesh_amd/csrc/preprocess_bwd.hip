@@ -7,9 +7,9 @@
 // (backward.cu:144-274) with preprocessCUDA<3> backward (backward.cu:347-396; helpers :20-139 SH,
 // :278-341 cov3D, auxiliary.h:107-117 dnormvdv).
 //
-// Gather: Gaussian g owns instances k = 0..tiles_touched-1 (row-major over its tile rectangle); instance k
-// sits at slot inv[offs[g]+k] of the tile list; render_bwd wrote a row for it iff
-// slot - ranges[tile].x < nproc[tile].  Rows are summed in ascending k (fixed order => reproducible grads).
+// Gather: Gaussian g owns instances k = 0..tiles_touched-1 (row-major over its tile rectangle); render_bwd wrote
+// the row of instance k at slab row offs[g] + k (zeros where no pixel reached it), so the rows of a Gaussian -- and of
+// neighbouring Gaussians -- are adjacent.  Rows are summed in ascending k (fixed order => reproducible grads).
 //
 // The SH block (192 B in, 192 B out per Gaussian) goes through LDS both ways so that global traffic is
 // coalesced 16-byte accesses (same scheme as preprocess.hip).
@@ -31,9 +31,7 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
                       const float* __restrict__ cov3Ds, const float* __restrict__ vm, const float* __restrict__ proj,
                       const float* __restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, int W, int H,
                       const float* __restrict__ rec, const unsigned* __restrict__ tiles_touched,
-                      const unsigned* __restrict__ offs, const unsigned* __restrict__ inv,
-                      const float* __restrict__ slab, const uint2* __restrict__ ranges,
-                      const unsigned* __restrict__ nproc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                      const unsigned* __restrict__ offs, const float* __restrict__ slab, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                       float* __restrict__ dL_drot) {
@@ -74,39 +72,22 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
         const bool live = radii[idx] > 0;
         float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (live) {
-            const float4 r2 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[2];
-            unsigned xmin, ymin, w;
-            unpack_rect(__float_as_uint(r2.y), xmin, ymin, w);
-            const unsigned n = tiles_touched[idx], o = offs[idx];
-            // Instances are visited in tile order (fixed summation order), eight at a time so that the three dependent
-            // loads of each (slot -> tile bookkeeping -> 48-byte row) overlap across instances instead of serialising (eight in flight).
-            unsigned x = 0, y = 0;
+            // The rows of this Gaussian's instances are adjacent (render_bwd3 writes row upos[slot] = offs[g] + k, zeros for
+            // instances no pixel reached), and the Gaussians of a wave are adjacent too: the gather is a contiguous
+            // stream.  Rows are summed in ascending k, eight loads in flight.
+            const unsigned n = tiles_touched[idx];
+            const float4* row = reinterpret_cast<const float4*>(slab + (size_t)offs[idx] * DGM_SLAB_STRIDE);
             for (unsigned k0 = 0; k0 < n; k0 += 8) {
-                unsigned slot[8], tile[8];
-                bool use[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const bool in = k0 + j < n;
-                    slot[j] = in ? inv[o + k0 + j] : 0u;
-                    tile[j] = in ? (ymin + y) * (unsigned)gridx + xmin + x : 0u;
-                    use[j] = in;
-                    if (in && ++x == w) {
-                        x = 0;
-                        y++;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) use[j] = use[j] && (slot[j] - ranges[tile[j]].x < nproc[tile[j]]);
                 float4 ra[8], rb[8];
                 float rc[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float4* row = reinterpret_cast<const float4*>(slab + (size_t)(use[j] ? slot[j] : slot[0]) * DGM_SLAB_STRIDE);
-                    ra[j] = row[0], rb[j] = row[1], rc[j] = row[2].x;
+                    const float4* r = row + (size_t)(k0 + j < n ? k0 + j : k0) * (DGM_SLAB_STRIDE / 4);
+                    ra[j] = r[0], rb[j] = r[1], rc[j] = r[2].x;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    if (use[j]) {
+                    if (k0 + j < n) {
                         acc[0] += ra[j].x;
                         acc[1] += ra[j].y;
                         acc[2] += ra[j].z;
@@ -403,15 +384,15 @@ void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const
                            const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
                            const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
-                           const float* rec, const unsigned* tiles_touched, const unsigned* offs, const unsigned* inv,
-                           const float* slab, const uint2* ranges, const unsigned* nproc, float* dL_dmean2D,
+                           const float* rec, const unsigned* tiles_touched, const unsigned* offs, const float* slab,
+                           float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                            float* dL_dsh, float* dL_dscale, float* dL_drot) {
     const size_t lds_bytes = (shs != nullptr && M > 0) ? (size_t)DGM_PRE_BLOCK * ((3 * M) | 1) * sizeof(float) : 16;
     const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, gridx, means3D,
                        radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, viewmatrix, projmatrix, campos,
-                       focal_x, focal_y, tan_fovx, tan_fovy, W, H, rec, tiles_touched, offs, inv, slab, ranges, nproc,
+                       focal_x, focal_y, tan_fovx, tan_fovy, W, H, rec, tiles_touched, offs, slab,
                        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
 }
 

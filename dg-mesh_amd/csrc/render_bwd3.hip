@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(64)
 render_bwd3_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                    const float* __restrict__ bg, const float* __restrict__ rec, const float4* __restrict__ cfin,
                    const float4* __restrict__ ckpt, const unsigned* __restrict__ n_contrib,
-                   const float* __restrict__ dL_dpixels, const unsigned* __restrict__ nproc_in, float* __restrict__ slab) {
+                   const float* __restrict__ dL_dpixels, const unsigned* __restrict__ nproc_in,
+                   const unsigned* __restrict__ upos, float* __restrict__ slab) {
     __shared__ float4 sA[64];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
     __shared__ float4 sB[64];  // conic c * -log2(e)/2, opacity, r, g
     __shared__ float sC[64];   // b
@@ -102,6 +103,14 @@ render_bwd3_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
     const uint2 range = ranges[tile];
     const int nproc = (int)nproc_in[tile];
     const int nseg = (nproc + RB3_SEG - 1) / RB3_SEG;
+    // list entries behind the deepest contributor of the tile are never replayed: their rows are zeros (the per-Gaussian
+    // sum of preprocess_bwd reads every row); the tile's workgroups share them
+    for (int pos = nproc + (int)blockIdx.y * 64 + (int)threadIdx.x; pos < (int)(range.y - range.x); pos += RB3_KSPLIT * 64) {
+        float4* dst = reinterpret_cast<float4*>(slab + (size_t)upos[range.x + pos] * DGM_SLAB_STRIDE);
+        dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if ((int)blockIdx.y >= nseg) return;
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int lane = threadIdx.x;
@@ -169,9 +178,10 @@ render_bwd3_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
         for (int t = 0; t < nb; t++) {
             const int base_pos = seg_end - 1 - t * 64;  // list position staged by lane 0; lane l stages base_pos - l
             const int pos = base_pos - lane;
-            unsigned qm = 0u;
+            unsigned qm = 0u, row = 0u;
             if (pos >= seg_begin) {
                 const unsigned g = point_list[range.x + pos];
+                row = upos[range.x + pos];  // fetched with the splat: the dependent row store below does not wait for it
                 const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * DGM_REC_STRIDE);
                 const float4 r0 = r4[0], r1 = r4[1];
                 const float l2e = 1.4426950408889634f;
@@ -214,7 +224,8 @@ render_bwd3_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
             }
             if (pos >= seg_begin) {
                 const float* o = sOut + lane * RB3_RS;
-                float4* dst = reinterpret_cast<float4*>(slab + (size_t)(range.x + pos) * DGM_SLAB_STRIDE);
+                // row of the instance in the per-Gaussian order: the sum over a Gaussian's instances reads adjacent rows
+                float4* dst = reinterpret_cast<float4*>(slab + (size_t)row * DGM_SLAB_STRIDE);
                 dst[0] = make_float4(o[0], o[1], o[2], o[3]);
                 dst[1] = make_float4(o[4], o[5], o[6], o[7]);
                 dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
@@ -225,9 +236,10 @@ render_bwd3_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
 
 void launch_render_bwd3(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
-                        const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc, float* slab) {
+                        const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc, const unsigned* upos,
+                        float* slab) {
     hipLaunchKernelGGL(render_bwd3_kernel, dim3(tiles, RB3_KSPLIT), dim3(64), 0, st, ranges, point_list, W, H, gridx, bg, rec,
-                       cfin, ckpt, n_contrib, dL_dpix, nproc, slab);
+                       cfin, ckpt, n_contrib, dL_dpix, nproc, upos, slab);
 }
 
 }  // namespace dgm

@@ -111,8 +111,9 @@ typedef struct {
     /* binning buffer */
     size_t keys;       /* u64[R]  (depth_bits << 32 | gaussian), grouped by tile, unsorted within a tile */
     size_t point_list; /* u32[R]  gaussian ids, by tile then depth then id: identical to the reference's */
-    size_t inv;        /* u32[R]  inv[offs[g] + k] = slot of g's k-th tile instance in point_list */
-    size_t slab;       /* float[R][12] per-instance gradient rows written by backward: colour r,g,b | moments of
+    size_t upos;       /* u32[R]  upos[slot] = offs[g] + k for the point_list entry at `slot`: g's k-th tile instance */
+    size_t slab;       /* float[R][12] per-instance gradient rows written by backward AT ROW upos[slot] (grouped by
+                          Gaussian, so the per-Gaussian sum reads them contiguously): colour r,g,b | moments of
                           g = G dL/dalpha about the splat centre: 1, dx, dy, dx^2, dx dy, dy^2 | 3 pad */
     size_t ckpt;       /* float4[R/256 + 1][256]: (T, C.rgb) of a tile's pixels after each 256 list entries (forward ->
                           segment-parallel backward) */

@@ -54,9 +54,9 @@ def hip_forward(a, debug=False):
         n_contrib=view(img, lay.n_contrib, np.uint32, W * H).reshape(H, W),
         ranges=view(img, lay.ranges, np.uint32, tiles * 2).reshape(tiles, 2))
     if n > 0:
-        out.update(point_list=view(binning, lay.point_list, np.uint32, n), inv=view(binning, lay.inv, np.uint32, n))
+        out.update(point_list=view(binning, lay.point_list, np.uint32, n), upos=view(binning, lay.upos, np.uint32, n))
     else:
-        out.update(point_list=np.zeros(0, np.uint32), inv=np.zeros(0, np.uint32))
+        out.update(point_list=np.zeros(0, np.uint32), upos=np.zeros(0, np.uint32))
     return out
 
 

@@ -51,12 +51,12 @@ def check_forward(orc, a, f_hip, exact_geom=True):
     b = f["binning"]
     assert np.array_equal(f_hip["ranges"], b["ranges"])
     assert np.array_equal(f_hip["point_list"], b["point_list"])
-    # inverse map consistency: inv[offs[g]+k] is the slot holding g in the k-th tile of its rectangle
+    # upos[slot] = offs[g] + k: a permutation of the instances that sends every list entry into its Gaussian's own run
     if f["num_rendered"]:
-        inv = f_hip["inv"]
-        assert np.array_equal(np.sort(inv), np.arange(f["num_rendered"], dtype=np.uint32))
+        upos = f_hip["upos"]
+        assert np.array_equal(np.sort(upos), np.arange(f["num_rendered"], dtype=np.uint32))
         owner = np.repeat(np.arange(P, dtype=np.uint32), g["tiles_touched"])
-        assert np.array_equal(f_hip["point_list"][inv], owner)
+        assert np.array_equal(owner[upos], f_hip["point_list"])
     img = f["img"]
     frag = img["fragile"]
     assert frag.mean() < 0.05
