@@ -21,7 +21,7 @@ class StateLayout(_c.Structure):
     _fields_ = [(n, _c.c_size_t) for n in (
         "rec", "depth", "radii", "tiles_touched", "offs", "cov3D", "clamped", "block_sums", "block_offs", "hist",
         "tile_count", "tile_offset", "big_list", "counters", "geometry_bytes",
-        "keys", "point_list", "upos", "slab", "ckpt", "binning_bytes",
+        "inst", "point_list", "upos", "slab", "ckpt", "binning_bytes",
         "final_T", "n_contrib", "ranges", "nproc", "cfin", "image_bytes")] + [
         (n, _c.c_int) for n in ("tiles_x", "tiles_y", "n_chunks", "chunk_size")]
 

@@ -13,17 +13,20 @@
 //                scan over tiles -> tile segment starts, `ranges` (empty tiles stay (0,0) like the
 //                reference's memset) and R;
 //   3. scatter : same chunk workgroups, LDS cursors initialised to (tile start + chunk prefix), each
-//                instance takes a slot with one LDS atomic and writes its 8-byte key
-//                (depth_bits << 32 | gaussian) straight into its tile segment;
-//   4. sort    : one workgroup per tile sorts its segment in LDS (normalised bitonic network on the
-//                64-bit keys => deterministic order independent of the atomic arrival order) and emits
-//                point_list plus upos[slot] = offs[g]+k, the instance's position in the per-Gaussian order (backward rows).
+//                instance takes a slot with one LDS atomic and writes its 16-byte record
+//                (gaussian, depth bits, position in the per-Gaussian order) straight into its tile segment;
+//   4. sort    : one workgroup per tile sorts its segment in LDS -- an LSD radix sort on the depth bits with an index
+//                tie-break for segments up to 4096 entries, a normalised bitonic network on the 64-bit keys beyond that;
+//                both give the same order whatever the atomic arrival order was -- and emits point_list plus
+//                upos[slot] = offs[g]+k, the instance's position in the per-Gaussian order (backward rows).
 // Wave-cooperative rectangle expansion: a wave loads 64 Gaussians, then iterates over the lanes that own a
 // non-empty rectangle (scalar bit loop on the ballot mask) and lets all 64 lanes cover that rectangle's
 // tiles, so a Gaussian spanning thousands of tiles costs the same lane-cycles as many small ones.
 #include "dgm_common.hpp"
 
 namespace dgm {
+
+static constexpr int kRadixCap = 2048;  // longest tile segment the one-workgroup-per-tile radix sort takes (256 threads x 8)
 
 // ---- generic single-workgroup exclusive scan of n u32 (n up to a few 100k) --------------------------------
 __global__ void __launch_bounds__(1024)
@@ -139,18 +142,20 @@ colscan_kernel(int tiles, int nchunks, unsigned* __restrict__ hist, unsigned* __
 __global__ void __launch_bounds__(256)
 write_ranges_kernel(int tiles, int small_cap, const unsigned* __restrict__ tile_count,
                     const unsigned* __restrict__ tile_offset, uint2* __restrict__ ranges,
-                    unsigned* __restrict__ big_list, unsigned* __restrict__ big_count) {
+                    unsigned* __restrict__ big_list, unsigned* __restrict__ big_count) {  // big_count[1] = mid count
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= tiles) return;
     const unsigned c = tile_count[t], o = tile_offset[t];
     ranges[t] = c ? make_uint2(o, o + c) : make_uint2(0u, 0u);
-    if (c > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;  // order irrelevant
+    // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
+    if (c > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
+    else if (c > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
 }
 
 __global__ void __launch_bounds__(DGM_BIN_THREADS)
 scatter_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restrict__ tiles_touched,
                const float* __restrict__ rec, const float* __restrict__ depth, const unsigned* __restrict__ hist,
-               const unsigned* __restrict__ tile_offset, unsigned long long* __restrict__ keys) {
+               const unsigned* __restrict__ tile_offset, uint4* __restrict__ inst) {
     extern __shared__ __attribute__((aligned(16))) unsigned cursor[];
     const unsigned* row = hist + (size_t)blockIdx.x * tiles;
     for (int t = threadIdx.x; t < tiles; t += DGM_BIN_THREADS) cursor[t] = tile_offset[t] + row[t];
@@ -158,10 +163,11 @@ scatter_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restric
     const int g0 = blockIdx.x * chunk, g1 = min(P, g0 + chunk);
     for (int base = g0; base < g1; base += DGM_BIN_THREADS) {
         const int g = base + threadIdx.x;
-        unsigned tt = 0u, rect = 0u, dbits = 0u;
+        unsigned tt = 0u, rect = 0u, dbits = 0u, og = 0u;
         if (g < g1) {
             tt = tiles_touched[g];
             rect = __float_as_uint(rec[(size_t)g * DGM_REC_STRIDE + 9]);
+            og = __float_as_uint(rec[(size_t)g * DGM_REC_STRIDE + 10]);  // offs[g] (count_tiles_kernel)
             dbits = __float_as_uint(depth[g]);
         }
         unsigned long long m = __ballot(tt != 0u);
@@ -172,16 +178,18 @@ scatter_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restric
             const unsigned rect_i = __builtin_amdgcn_readlane(rect, src);
             const unsigned d_i = __builtin_amdgcn_readlane(dbits, src);
             const unsigned g_i = (unsigned)__builtin_amdgcn_readlane(g, src);
+            const unsigned o_i = __builtin_amdgcn_readlane(og, src);
             unsigned xmin, ymin, w;
             unpack_rect(rect_i, xmin, ymin, w);
             const unsigned magic = w > 1 ? (0xFFFFFFFFu / w + 1u) : 0u;
-            const unsigned long long key = ((unsigned long long)d_i << 32) | g_i;
             for (unsigned k = lane_id(); k < tt_i; k += 64) {
                 const unsigned y = w > 1 ? __umulhi(k, magic) : k;
                 const unsigned x = k - y * w;
                 const unsigned tile = (ymin + y) * (unsigned)gridx + xmin + x;
                 const unsigned slot = atomicAdd(&cursor[tile], 1u);
-                keys[slot] = key;
+                // one 16-byte store: Gaussian, depth bits (the sort key: depth, then Gaussian) and the position of this
+                // instance in the per-Gaussian order, which the tile sort carries along to `upos`
+                inst[slot] = make_uint4(g_i, d_i, o_i + k, 0u);
             }
         }
     }
@@ -243,20 +251,187 @@ __device__ __forceinline__ void emit_sorted(const unsigned long long* s, int n, 
     }
 }
 
-// small segments (1..kSmallCap keys): one 256-thread workgroup per tile, 32 KB of LDS
-__global__ void __launch_bounds__(256)
-tile_sort_small_kernel(int cap, int gridx, const uint2* __restrict__ ranges,
-                       const unsigned long long* __restrict__ keys, const float* __restrict__ rec,
-                       unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
-    const int tile = blockIdx.x;
-    const uint2 r = ranges[tile];
+// small segments (1..kSmallCap keys): one 256-thread workgroup per tile.  LSD radix sort on the 32 depth bits, 8 bits per
+// pass, with the entry's position in the unsorted segment (< 4096) as payload:
+//   * every thread keeps up to 16 (depth, position) pairs in registers; wave w owns the w-th quarter of the array, so
+//     "wave, then batch, then lane" is the array order and a stable pass only needs ranks in that order;
+//   * rank inside a 64-key batch: eight ballots give each lane the mask of lanes with its digit (mbcnt = rank, popcount =
+//     group size); the first lane of a group advances the wave's digit counter in LDS and broadcasts the old value;
+//   * one wave turns the WAVES x 256 counters into destinations (digit major, wave minor); pairs move through LDS;
+//   * a pass whose digit is the same for every key of the tile is skipped (the exponent byte almost always is);
+//   * equal depths must end in ascending Gaussian index (what the reference's stable sort of the index-ordered emission
+//     gives): after the last pass entries with an equal neighbour are placed inside their run by counting smaller indices.
+// The Gaussian index and the per-Gaussian position are fetched from the instance records through the payload only once, at
+// the end (one 16-byte gather inside the tile's own segment), and the output is written in order.
+// (WAVES, RS_MAXB pairs per thread) = (4, 8): 256 threads, segments up to 2048 entries, one workgroup per tile at 65 VGPRs
+// (sixteen pairs per thread cost 248); (8, 8): 512 threads, up to 4096 entries, the tiles of the device-built "mid"
+// worklist -- a long segment is spread over more waves instead of more registers.
+template <int WAVES, int RS_MAXB>
+__device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __restrict__ inst, unsigned* __restrict__ point_list,
+                                                unsigned* __restrict__ upos, uint2* sk, unsigned (*cnt)[256],
+                                                unsigned* s_red) {
     const int n = (int)(r.y - r.x);
-    if (n < 1 || n > cap) return;
-    for (int i = threadIdx.x; i < n; i += 256) skeys[i] = keys[r.x + i];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = (n + WAVES * 64 - 1) / (WAVES * 64);  // batches of 64 per wave
+    const int w0 = wv * nb * 64;    // first array index of this wave
+    const uint4* seg = inst + r.x;  // (Gaussian, depth bits, per-Gaussian position, -) in arrival order
+    if (tid == 0) s_red[0] = 0u, s_red[1] = 0xFFFFFFFFu;
     __syncthreads();
-    bitonic_sort<256, false>(skeys, n);
-    emit_sorted(skeys, n, r.x, tile, gridx, rec, point_list, upos, 256);
+    unsigned key[RS_MAXB], pay[RS_MAXB];
+    {
+        unsigned vo = 0u, va = 0xFFFFFFFFu;
+#pragma unroll
+        for (int b = 0; b < RS_MAXB; b++) {
+            key[b] = 0xFFFFFFFFu, pay[b] = 0u;
+            if (b < nb) {
+                const int i = w0 + b * 64 + lane;
+                if (i < n) {
+                    key[b] = seg[i].y;
+                    pay[b] = (unsigned)i;
+                    vo |= key[b], va &= key[b];
+                }
+            }
+        }
+        atomicOr(&s_red[0], vo);
+        atomicAnd(&s_red[1], va);
+    }
+    __syncthreads();
+    const unsigned varying = s_red[0] ^ s_red[1];
+    bool moved = false;
+#pragma unroll 1
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((varying >> shift) & 255u) == 0u) continue;  // workgroup-uniform
+        moved = true;
+        reinterpret_cast<uint4*>(&cnt[0][0])[tid] = make_uint4(0u, 0u, 0u, 0u);  // WAVES * 64 threads x 4 = WAVES x 256 counters
+        __syncthreads();
+        unsigned rank[RS_MAXB];
+#pragma unroll
+        for (int b = 0; b < RS_MAXB; b++) {
+            rank[b] = 0u;
+            if (b < nb) {
+                const bool valid = w0 + b * 64 + lane < n;
+                const unsigned d = (key[b] >> shift) & 255u;
+                unsigned long long m = __ballot(valid);
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool bs = (d >> bit) & 1u;
+                    const unsigned long long bb = __ballot(bs);
+                    m &= bs ? bb : ~bb;
+                }
+                const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                unsigned old = 0u;
+                if (valid && rk == 0u) {  // first lane of its digit group
+                    old = cnt[wv][d];
+                    cnt[wv][d] = old + (unsigned)__popcll(m);
+                }
+                const int leader = valid ? __builtin_ctzll(m) : lane;
+                old = (unsigned)__shfl((int)old, leader, 64);
+                rank[b] = old + rk;
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {  // digit-major, wave-minor exclusive prefix over the WAVES x 256 counters: lane l owns digits 4 l .. 4 l + 3
+            uint4 c[WAVES];
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) {
+                c[w] = reinterpret_cast<const uint4*>(&cnt[w][0])[lane];
+                t.x += c[w].x, t.y += c[w].y, t.z += c[w].z, t.w += c[w].w;
+            }
+            const unsigned tot = t.x + t.y + t.z + t.w;
+            const unsigned base = wave_inclusive_scan_u32(tot) - tot;
+            uint4 run = make_uint4(base, base + t.x, base + t.x + t.y, base + t.x + t.y + t.z);
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) {
+                reinterpret_cast<uint4*>(&cnt[w][0])[lane] = run;
+                run.x += c[w].x, run.y += c[w].y, run.z += c[w].z, run.w += c[w].w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < RS_MAXB; b++) {
+            if (b < nb && w0 + b * 64 + lane < n) {
+                const unsigned d = (key[b] >> shift) & 255u;
+                sk[cnt[wv][d] + rank[b]] = make_uint2(key[b], pay[b]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < RS_MAXB; b++) {
+            if (b < nb) {
+                const int i = w0 + b * 64 + lane;
+                if (i < n) {
+                    const uint2 e = sk[i];
+                    key[b] = e.x, pay[b] = e.y;
+                }
+            }
+        }
+    }
+    if (!moved) {  // every key equal (or a single one): the array order is the unsorted order
+#pragma unroll
+        for (int b = 0; b < RS_MAXB; b++) {
+            if (b < nb && w0 + b * 64 + lane < n) sk[w0 + b * 64 + lane] = make_uint2(key[b], pay[b]);
+        }
+        __syncthreads();
+    }
+    // gather the Gaussian index and the per-Gaussian position through the payload; resolve equal depths
+    unsigned gid[RS_MAXB], up[RS_MAXB], dst[RS_MAXB];
+#pragma unroll
+    for (int b = 0; b < RS_MAXB; b++) {
+        gid[b] = up[b] = dst[b] = 0u;
+        if (b < nb) {
+            const int i = w0 + b * 64 + lane;
+            if (i < n) {
+                const uint4 e = seg[pay[b]];
+                gid[b] = e.x, up[b] = e.z;
+                dst[b] = (unsigned)i;
+                const bool tie = (i > 0 && sk[i - 1].x == key[b]) || (i + 1 < n && sk[i + 1].x == key[b]);
+                if (tie) {
+                    int s0 = i, s1 = i + 1;
+                    while (s0 > 0 && sk[s0 - 1].x == key[b]) s0--;
+                    while (s1 < n && sk[s1].x == key[b]) s1++;
+                    unsigned below = 0u;
+                    for (int j = s0; j < s1; j++) below += seg[sk[j].y].x < gid[b] ? 1u : 0u;
+                    dst[b] = (unsigned)s0 + below;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RS_MAXB; b++) {
+        if (b < nb && w0 + b * 64 + lane < n) {
+            point_list[r.x + dst[b]] = gid[b];
+            upos[r.x + dst[b]] = up[b];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tile_sort_radix_kernel(const uint2* __restrict__ ranges, const uint4* __restrict__ inst, unsigned* __restrict__ point_list,
+                       unsigned* __restrict__ upos) {
+    __shared__ __attribute__((aligned(16))) uint2 sk[kRadixCap];
+    __shared__ __attribute__((aligned(16))) unsigned cnt[4][256];
+    __shared__ unsigned s_red[2];
+    const uint2 r = ranges[blockIdx.x];
+    const int n = (int)(r.y - r.x);
+    if (n < 1 || n > kRadixCap) return;  // longer segments: the worklists
+    radix_sort_tile<4, kRadixCap / 256>(r, inst, point_list, upos, sk, cnt, s_red);
+}
+
+// segments of kRadixCap + 1 .. 4096 entries: the "mid" worklist (filled from the END of big_list by write_ranges_kernel), fixed grid
+__global__ void __launch_bounds__(512)
+tile_sort_radix_mid_kernel(int tiles, const unsigned* __restrict__ big_list, const unsigned* __restrict__ mid_count,
+                           const uint2* __restrict__ ranges, const uint4* __restrict__ inst,
+                           unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
+    __shared__ __attribute__((aligned(16))) uint2 sk[4096];
+    __shared__ __attribute__((aligned(16))) unsigned cnt[8][256];
+    __shared__ unsigned s_red[2];
+    const unsigned count = *mid_count;
+    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
+        const uint2 r = ranges[big_list[tiles - 1 - (int)w]];
+        radix_sort_tile<8, 8>(r, inst, point_list, upos, sk, cnt, s_red);
+        __syncthreads();
+    }
 }
 
 // big segments come from a device-built worklist (write_ranges_kernel), walked by a FIXED grid so that no
@@ -264,7 +439,7 @@ tile_sort_small_kernel(int cap, int gridx, const uint2* __restrict__ ranges,
 // 128 KB of LDS; anything larger falls back to the same network on the global key array.
 __global__ void __launch_bounds__(1024)
 tile_sort_big_kernel(int cap, int gridx, const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
-                     const uint2* __restrict__ ranges, unsigned long long* __restrict__ keys,
+                     const uint2* __restrict__ ranges, uint4* __restrict__ inst,
                      const float* __restrict__ rec, unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const unsigned count = *big_count;
@@ -273,20 +448,35 @@ tile_sort_big_kernel(int cap, int gridx, const unsigned* __restrict__ big_list, 
         const uint2 r = ranges[tile];
         const int n = (int)(r.y - r.x);
         if (n <= cap) {
-            for (int i = threadIdx.x; i < n; i += 1024) skeys[i] = keys[r.x + i];
+            for (int i = threadIdx.x; i < n; i += 1024) {
+                const uint4 e = inst[r.x + i];
+                skeys[i] = ((unsigned long long)e.y << 32) | e.x;
+            }
             __syncthreads();
             bitonic_sort<1024, false>(skeys, n);
             emit_sorted(skeys, n, r.x, tile, gridx, rec, point_list, upos, 1024);
         } else {
-            bitonic_sort<1024, true>(keys + r.x, n);
-            emit_sorted(keys + r.x, n, r.x, tile, gridx, rec, point_list, upos, 1024);
+            // the segment's records are packed in place into 64-bit keys (key i lands on record i / 2, which an earlier
+            // or -- with the barrier -- the same round has already read)
+            unsigned long long* gkeys = reinterpret_cast<unsigned long long*>(inst + r.x);
+            for (int i0 = 0; i0 < n; i0 += 1024) {
+                const int i = i0 + (int)threadIdx.x;
+                uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                if (i < n) e = inst[r.x + i];
+                __syncthreads();
+                if (i < n) gkeys[i] = ((unsigned long long)e.y << 32) | e.x;
+            }
+            __threadfence_block();
+            __syncthreads();
+            bitonic_sort<1024, true>(gkeys, n);
+            emit_sorted(gkeys, n, r.x, tile, gridx, rec, point_list, upos, 1024);
         }
         __syncthreads();
     }
 }
 
 // ---- host launchers -----------------------------------------------------------------------------------------
-static constexpr int kSmallCap = 4096;   // 32 KB of LDS keys, 256 threads (cfg2 centre tiles reach 2-3 k entries on some frames)
+static constexpr int kSmallCap = 4096;   // 32 KB of LDS pairs, 256 threads x 16 (cfg2 centre tiles reach 2-3 k entries on some frames)
 static constexpr int kLargeCap = 16384;  // 128 KB of LDS keys, 1024 threads
 
 int binning_lds_limit_tiles() { return 36 * 1024; }  // 144 KB of u32 counters
@@ -320,7 +510,7 @@ void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, un
 
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
-                          const unsigned* tile_offset, unsigned long long* keys) {
+                          const unsigned* tile_offset, uint4* inst) {
     const size_t lds = (size_t)tiles * 4;
     if (lds > 48 * 1024) {
         hipError_t e =
@@ -328,11 +518,11 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(scatter_kernel, dim3(nchunks), dim3(DGM_BIN_THREADS), lds, st, P, chunk, tiles, gridx,
-                       tiles_touched, rec, depth, hist, tile_offset, keys);
+                       tiles_touched, rec, depth, hist, tile_offset, inst);
     return hipSuccess;
 }
 
-hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, unsigned long long* keys,
+hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, uint4* inst,
                             const float* rec, unsigned* point_list, unsigned* upos, const unsigned* big_list,
                             const unsigned* big_count) {
     static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
@@ -343,10 +533,12 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* r
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(tiles), dim3(256), kSmallCap * 8, st, kSmallCap, gridx, ranges, keys,
-                       rec, point_list, upos);
+    static_assert(kSmallCap == 8 * 64 * 8, "tile_sort_radix_mid_kernel covers segments up to kSmallCap");
+    hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(768), dim3(512), 0, st, tiles, big_list, big_count + 1, ranges, inst,
+                       point_list, upos);
+    hipLaunchKernelGGL(tile_sort_radix_kernel, dim3(tiles), dim3(256), 0, st, ranges, inst, point_list, upos);
     hipLaunchKernelGGL(tile_sort_big_kernel, dim3(256), dim3(1024), kLargeCap * 8, st, kLargeCap, gridx, big_list,
-                       big_count, ranges, keys, rec, point_list, upos);
+                       big_count, ranges, inst, rec, point_list, upos);
     return hipSuccess;
 }
 

@@ -33,8 +33,8 @@ void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, un
                       unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count);
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
-                          const unsigned* tile_offset, unsigned long long* keys);
-hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, unsigned long long* keys,
+                          const unsigned* tile_offset, uint4* inst);
+hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, uint4* inst,
                             const float* rec, unsigned* point_list, unsigned* upos, const unsigned* big_list,
                             const unsigned* big_count);
 // render.hip
@@ -368,7 +368,7 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
     char* bin = binning_alloc(binning_ctx, L.binning_bytes);
     if (!bin) return fail("rasterize_forward: binning allocator returned NULL");
     bin = align_ptr(bin);
-    unsigned long long* keys = (unsigned long long*)(bin + L.keys);
+    uint4* inst = (uint4*)(bin + L.inst);
     unsigned* point_list = (unsigned*)(bin + L.point_list);
     unsigned* upos = (unsigned*)(bin + L.upos);
     float4* ckpt = (float4*)(bin + L.ckpt);
@@ -386,12 +386,12 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
     if (R > 0) {
         tm.begin(DGM_STAGE_BIN_SCATTER);
         DGM_HIP(launch_scatter(st, P, L.chunk_size, L.n_chunks, tiles, gridx, tiles_touched, rec, depth, hist,
-                               tile_offset, keys));
+                               tile_offset, inst));
         DGM_CHECK("scatter");
         tm.end(DGM_STAGE_BIN_SCATTER);
 
         tm.begin(DGM_STAGE_TILE_SORT);
-        DGM_HIP(launch_tile_sort(st, tiles, gridx, ranges, keys, rec, point_list, upos, big_list, counters + 2));
+        DGM_HIP(launch_tile_sort(st, tiles, gridx, ranges, inst, rec, point_list, upos, big_list, counters + 2));
         DGM_CHECK("tile_sort");
         tm.end(DGM_STAGE_TILE_SORT);
     }

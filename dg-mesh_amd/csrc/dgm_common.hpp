@@ -58,7 +58,7 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->counters = take(8 * 4);
     L->geometry_bytes = o + A;
     o = 0;
-    L->keys = take(Rz * 8);
+    L->inst = take(Rz * 16);
     L->point_list = take(Rz * 4);
     L->upos = take(Rz * 4);
     L->slab = take(Rz * DGM_SLAB_STRIDE * 4);

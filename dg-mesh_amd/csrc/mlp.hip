@@ -305,40 +305,40 @@ __global__ void mlp_reduce_dw_kernel(int chunks, int db_chunks, int Kp, int in_f
 }
 
 // The same reduction in ONE pass for the matrix-core paths (256 partial tiles of 256 KB per layer: the read is the cost).
-// Workgroup = a 4 x 32 piece of the (k, j) plane as 32 float4 positions, times 8 groups of chunks: every thread streams its
-// group's chunks with eight 16-byte loads in flight, the eight group sums meet in LDS (fixed order), and the piece is
-// written transposed into the PyTorch (out, in) layout, four consecutive k per thread.  The first 32 workgroups also
-// reduce eight columns each of the bias-gradient rows (db_rows of them).
+// Workgroup = a 2 x 32 piece of the (k, j) plane as 16 float4 positions, times 16 groups of chunks: every thread streams
+// its group's chunks with sixteen 16-byte loads in flight (one round for the usual 256 chunks), the sixteen group sums
+// meet in LDS (fixed order), and the piece is written transposed into the PyTorch (out, in) layout.  The first 32
+// workgroups also reduce eight columns each of the bias-gradient rows (db_rows of them).
 __global__ void __launch_bounds__(256)
 mlp_reduce_dw1_kernel(int chunks, int db_rows, int Kp, int in_features, int emb_dim, const float* __restrict__ partial,
                       const float* __restrict__ partial_db, float* __restrict__ dW, float* __restrict__ db) {
-    __shared__ float4 red[8][32];
+    __shared__ float4 red[16][16];
     __shared__ float redb[32][8];
-    const int tid = threadIdx.x, pos = tid & 31, grp = tid >> 5;
-    const int k0 = (blockIdx.x >> 3) * 4, j0 = (blockIdx.x & 7) * 32;
+    const int tid = threadIdx.x, pos = tid & 15, grp = tid >> 4;
+    const int k0 = (blockIdx.x >> 3) * 2, j0 = (blockIdx.x & 7) * 32;
     {
         const int k = k0 + (pos >> 3), j = j0 + (pos & 7) * 4;
-        const int per = (chunks + 7) >> 3;
+        const int per = (chunks + 15) >> 4;
         const int c1 = min(chunks, (grp + 1) * per);
         int c = grp * per;
         const size_t cs = (size_t)Kp * MLP_W;
         const float* src = partial + (size_t)k * MLP_W + j;
-        float4 sp[8];
+        float4 sp[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) sp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (; c + 8 <= c1; c += 8) {
-            float4 v[8];
+        for (int u = 0; u < 16; u++) sp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (; c + 16 <= c1; c += 16) {
+            float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(c + u) * cs);
+            for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(c + u) * cs);
 #pragma unroll
-            for (int u = 0; u < 8; u++) sp[u].x += v[u].x, sp[u].y += v[u].y, sp[u].z += v[u].z, sp[u].w += v[u].w;
+            for (int u = 0; u < 16; u++) sp[u].x += v[u].x, sp[u].y += v[u].y, sp[u].z += v[u].z, sp[u].w += v[u].w;
         }
         for (; c < c1; c++) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * cs);
             sp[0].x += v.x, sp[0].y += v.y, sp[0].z += v.z, sp[0].w += v.w;
         }
 #pragma unroll
-        for (int u = 4; u >= 1; u >>= 1)
+        for (int u = 8; u >= 1; u >>= 1)
 #pragma unroll
             for (int v = 0; v < u; v++)
                 sp[v].x += sp[v + u].x, sp[v].y += sp[v + u].y, sp[v].z += sp[v + u].z, sp[v].w += sp[v + u].w;
@@ -352,20 +352,20 @@ mlp_reduce_dw1_kernel(int chunks, int db_rows, int Kp, int in_features, int emb_
         redb[g32][tid & 7] = s;
     }
     __syncthreads();
-    if (tid < 128) {  // thread -> column j0 + tid / 4, row k0 + tid % 4
-        const int jj = tid >> 2, kk = tid & 3;
+    if (tid < 64) {  // thread -> column j0 + tid / 2, row k0 + tid % 2
+        const int jj = tid >> 1, kk = tid & 1;
         const float* r = reinterpret_cast<const float*>(&red[0][0]) + (kk * 8 + (jj >> 2)) * 4 + (jj & 3);
         float s = r[0];
 #pragma unroll
-        for (int g = 1; g < 8; g++) s += r[g * 128];
+        for (int g = 1; g < 16; g++) s += r[g * 64];
         const int k = k0 + kk;
         int dst;
         if (Kp == MLP_W) dst = k;
         else if (k < MLP_EMB) dst = k < emb_dim ? k : -1;
         else dst = k - MLP_EMB + emb_dim;
         if (dst >= 0) dW[(size_t)(j0 + jj) * in_features + dst] = s;
-    } else if (do_db && tid < 136) {
-        const int c = tid - 128;
+    } else if (do_db && tid < 72) {
+        const int c = tid - 64;
         float s = redb[0][c];
         for (int g = 1; g < 32; g++) s += redb[g][c];
         db[blockIdx.x * 8 + c] = s;
@@ -992,7 +992,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             } else
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
                                    K2, G, w.partial, w.partial_db);
-            hipLaunchKernelGGL(mlp_reduce_dw1_kernel, dim3(Kp / 4 * 8), dim3(256), 0, st, d.chunks, 2 * d.chunks, Kp,
+            hipLaunchKernelGGL(mlp_reduce_dw1_kernel, dim3(Kp / 2 * 8), dim3(256), 0, st, d.chunks, 2 * d.chunks, Kp,
                                layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
         }
         if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]

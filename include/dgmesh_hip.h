@@ -105,11 +105,13 @@ typedef struct {
     size_t hist;          /* u32[n_chunks][tiles] */
     size_t tile_count;    /* u32[tiles] */
     size_t tile_offset;   /* u32[tiles+1] */
-    size_t big_list;      /* u32[tiles] worklist of tiles with more than 4096 instances */
-    size_t counters;      /* u32[8]: [0] = num_rendered, [1] = error flags, [2] = big_list length */
+    size_t big_list;      /* u32[tiles] worklists: tiles with more than 4096 instances from the front, tiles with 2049 ..
+                             4096 from the end */
+    size_t counters;      /* u32[8]: [0] = num_rendered, [1] = error flags, [2] = big worklist length, [3] = mid worklist length */
     size_t geometry_bytes;
     /* binning buffer */
-    size_t keys;       /* u64[R]  (depth_bits << 32 | gaussian), grouped by tile, unsorted within a tile */
+    size_t inst;       /* uint4[R] instance records (gaussian, depth bits, offs[g] + k, 0), grouped by tile, in arrival
+                          order within a tile (the tile sort's input) */
     size_t point_list; /* u32[R]  gaussian ids, by tile then depth then id: identical to the reference's */
     size_t upos;       /* u32[R]  upos[slot] = offs[g] + k for the point_list entry at `slot`: g's k-th tile instance */
     size_t slab;       /* float[R][12] per-instance gradient rows written by backward AT ROW upos[slot] (grouped by
