@@ -415,85 +415,86 @@ mlp_rows_small_kernel(int N, int NC, const float* __restrict__ A, const float* _
     }
 }
 
-// G7[r][c] = (sum_o dOut[r][o] * Wh[o][c]) * (Y7[r][c] > 0)
+// Everything the heads' backward needs from one pass over Y7 (fp32 FMA on the vector units: K = n_out <= 16 is too thin for
+// the matrix cores, and the pass is HBM-bound either way -- read Y7, write G7):
+//   G7[r][c]                = (sum_o dOut[r][o] * Wh[o][c]) * (Y7[r][c] > 0)        (gradient entering layer 7)
+//   partial_W[chunk][o][c]  = sum_rows dOut[r][o] * Y7[r][c],   partial_b[chunk][o] = sum_rows dOut[r][o]
+// A wave owns whole rows (lane l: columns 4 l .. 4 l + 3, one 16-byte load / store per row; lane o also loads dOut[r][o], which
+// v_readlane turns into the wave-uniform multiplier), keeps its four columns of Wh and its 16 x 4 weight-gradient sums in
+// registers, eight rows in flight; the four waves of the workgroup meet in LDS in a fixed order.
+typedef float hf2 __attribute__((ext_vector_type(2)));
+
 __global__ void __launch_bounds__(256)
 mlp_heads_bwd_kernel(int N, int NC, const float* __restrict__ dOut, const float* __restrict__ Wh,
-                     const float* __restrict__ Y7, float* __restrict__ G7) {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int r = (int)(gid >> 6), c4 = (int)(gid & 63);
-    if (r >= N) return;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                     const float* __restrict__ Y7, float* __restrict__ G7, float* __restrict__ partial_W,
+                     float* __restrict__ partial_b) {
+    __shared__ __attribute__((aligned(16))) float sW[16][MLP_W];
+    __shared__ float sB[4][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, chunk = blockIdx.x;
+    const int r0 = chunk * HD_ROWS, r1 = min(N, r0 + HD_ROWS);
+    hf2 wa[16], wb[16], aa[16], ab[16];
 #pragma unroll
     for (int o = 0; o < 16; o++) {
-        if (o < NC) {
-            const float d = dOut[(size_t)r * NC + o];
-            const float4 w = *reinterpret_cast<const float4*>(Wh + (size_t)o * MLP_W + c4 * 4);
-            s.x += d * w.x;
-            s.y += d * w.y;
-            s.z += d * w.z;
-            s.w += d * w.w;
-        }
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o < NC) w = *reinterpret_cast<const float4*>(Wh + (size_t)o * MLP_W + lane * 4);
+        wa[o] = (hf2){w.x, w.y}, wb[o] = (hf2){w.z, w.w};
+        aa[o] = (hf2){0.f, 0.f}, ab[o] = (hf2){0.f, 0.f};
     }
-    const float4 y = *reinterpret_cast<const float4*>(Y7 + (size_t)r * MLP_W + c4 * 4);
-    s.x = y.x > 0.f ? s.x : 0.f;
-    s.y = y.y > 0.f ? s.y : 0.f;
-    s.z = y.z > 0.f ? s.z : 0.f;
-    s.w = y.w > 0.f ? s.w : 0.f;
-    *reinterpret_cast<float4*>(G7 + (size_t)r * MLP_W + c4 * 4) = s;
-}
-
-// partial_Wh[chunk][o][c] = sum_rows dOut[r][o] * Y7[r][c] ; partial_bh[chunk][o] = sum_rows dOut[r][o]
-// (rows are consumed eight at a time so that eight Y7 loads are in flight per thread)
-__global__ void __launch_bounds__(256)
-mlp_heads_dw_kernel(int N, int NC, const float* __restrict__ dOut, const float* __restrict__ Y7,
-                    float* __restrict__ partial_W, float* __restrict__ partial_b) {
-    __shared__ float sd[64 * 16];
-    const int c = threadIdx.x, chunk = blockIdx.x;
-    const int r0 = chunk * HD_ROWS, r1 = min(N, r0 + HD_ROWS);
-    float acc[16], accb = 0.f;
+    float accb = 0.f;
+    for (int rb = r0 + wv * 8; rb < r1; rb += 32) {
+        float4 y[8];
+        float dv[8];
 #pragma unroll
-    for (int o = 0; o < 16; o++) acc[o] = 0.f;
-    for (int rb = r0; rb < r1; rb += 64) {
-        const int nr = min(64, r1 - rb);
-        __syncthreads();
-        for (int i = c; i < 64 * 16; i += 256) {  // stage dOut rows (zero padded to 16 columns)
-            const int rr = i >> 4, o = i & 15;
-            sd[i] = (rr < nr && o < NC) ? dOut[(size_t)(rb + rr) * NC + o] : 0.f;
-        }
-        __syncthreads();
-        for (int rr = 0; rr < nr; rr += 8) {
-            float y[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) y[u] = (rr + u < nr) ? Y7[(size_t)(rb + rr + u) * MLP_W + c] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const float4* d4 = reinterpret_cast<const float4*>(sd + (rr + u) * 16);
-                const float4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
-                acc[0] += d0.x * y[u];
-                acc[1] += d0.y * y[u];
-                acc[2] += d0.z * y[u];
-                acc[3] += d0.w * y[u];
-                acc[4] += d1.x * y[u];
-                acc[5] += d1.y * y[u];
-                acc[6] += d1.z * y[u];
-                acc[7] += d1.w * y[u];
-                acc[8] += d2.x * y[u];
-                acc[9] += d2.y * y[u];
-                acc[10] += d2.z * y[u];
-                acc[11] += d2.w * y[u];
-                acc[12] += d3.x * y[u];
-                acc[13] += d3.y * y[u];
-                acc[14] += d3.z * y[u];
-                acc[15] += d3.w * y[u];
+        for (int u = 0; u < 8; u++) {
+            const int r = rb + u;
+            y[u] = make_float4(0.f, 0.f, 0.f, 0.f), dv[u] = 0.f;
+            if (r < r1) {
+                y[u] = *reinterpret_cast<const float4*>(Y7 + (size_t)r * MLP_W + lane * 4);
+                if (lane < NC) dv[u] = dOut[(size_t)r * NC + lane];
             }
         }
-        if (c < 16)
-            for (int rr = 0; rr < nr; rr++) accb += sd[rr * 16 + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (rb + u < r1) {  // wave-uniform
+                const hf2 ya = {y[u].x, y[u].y}, yb = {y[u].z, y[u].w};
+                hf2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < 16; o++) {  // (columns o >= NC: dv and Wh are zero)
+                    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv[u]), o));
+                    sa += d * wa[o], sb += d * wb[o];
+                    aa[o] += d * ya, ab[o] += d * yb;
+                }
+                float4 g;
+                g.x = y[u].x > 0.f ? sa.x : 0.f;
+                g.y = y[u].y > 0.f ? sa.y : 0.f;
+                g.z = y[u].z > 0.f ? sb.x : 0.f;
+                g.w = y[u].w > 0.f ? sb.y : 0.f;
+                *reinterpret_cast<float4*>(G7 + (size_t)(rb + u) * MLP_W + lane * 4) = g;
+                accb += dv[u];
+            }
+        }
     }
+    if (lane < 16) sB[wv][lane] = accb;
+    for (int w = 0; w < 4; w++) {  // fixed order: wave 0, 1, 2, 3
+        if (wv == w) {
+#pragma unroll
+            for (int o = 0; o < 16; o++) {
+                float4* p = reinterpret_cast<float4*>(&sW[o][lane * 4]);
+                float4 v = make_float4(aa[o].x, aa[o].y, ab[o].x, ab[o].y);
+                if (w > 0) {
+                    const float4 q = *p;
+                    v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+                }
+                *p = v;
+            }
+        }
+        __syncthreads();
+    }
+    const int c = threadIdx.x;
 #pragma unroll
     for (int o = 0; o < 16; o++)
-        if (o < NC) partial_W[((size_t)chunk * 16 + o) * MLP_W + c] = acc[o];
-    if (c < 16) partial_b[(size_t)chunk * 16 + c] = accb;
+        if (o < NC) partial_W[((size_t)chunk * 16 + o) * MLP_W + c] = sW[o][c];
+    if (c < 16) partial_b[(size_t)chunk * 16 + c] = ((sB[0][c] + sB[1][c]) + sB[2][c]) + sB[3][c];
 }
 
 __global__ void mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W,
@@ -647,7 +648,7 @@ int mlp_fail(const char* msg) {
 }
 struct Ws {
     float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb;
-    uint4 *Wt6[8], *Wd6[8], *Wh6f, *Wh6b;  // bf16x6 weight planes
+    uint4 *Wt6[8], *Wd6[8], *Wh6f;  // bf16x6 weight planes
     uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
     float *wsc_f[8], *wsc_d[8];            // their inverse column scales
     unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
@@ -737,7 +738,6 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.Wt6[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 6);
     for (int l = 0; l < 8; l++) w.Wd6[l] = (uint4*)take((size_t)MLP_W * MLP_W * 6);
     w.Wh6f = (uint4*)take((size_t)MLP_W * 32 * 6);
-    w.Wh6b = (uint4*)take((size_t)16 * MLP_W * 6);
     for (int l = 0; l < 8; l++) w.Wt3[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.Wd3[l] = (uint4*)take((size_t)MLP_W * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.wsc_f[l] = take(MLP_W * 4);
@@ -830,7 +830,6 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             }
         }
         add(0, MLP_W, 32, MLP_W, 0, 0, p->n_out, p->Wh, w.Wh6f);
-        add(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh6b);
         hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
         if (n3 > 0) {
             // cmaxY | cmaxG | cmaxW are adjacent in the workspace: one fill clears the forward's two
@@ -916,22 +915,15 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
     const int grid = (N + GM - 1) / GM;
     const bool f32 = use_f32_mfma();
-    const int grid6 = (N + 127) / 128;
-    // heads
-    if (f32)
-        hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3((unsigned)(((size_t)N * 64 + 255) / 256)), dim3(256), 0, st, N, p->n_out,
-                           dOut, p->Wh, w.Y[7], w.Ga);
-    else  // G7 = (dOut * Wh) masked by layer 7's ReLU bits: a K=16 GEMM
-        hipLaunchKernelGGL((mlp_gemm6_kernel<1, 2, 2, 2, 4, true>), dim3(grid6), dim3(256), 0, st, N, dOut, p->n_out, 16,
-                           (const float*)nullptr, 0, 0, p->n_out, w.Wh6b, (const float*)nullptr, w.mask[7], w.Ga, MLP_W, MLP_W);
+    // heads: G7 (masked by layer 7's ReLU, read off Y7 itself) and the partial sums of dWh / dbh in one pass over Y7
+    const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
+    hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, p->Wh, w.Y[7], w.Ga,
+                       w.partial_h, w.partial_hb);
     const bool x3 = use_f16x3();
     if (x3) {  // column maxima of the G_l for the weight gradients' scales: accumulated by the backward-data GEMMs
         if (hipMemsetAsync(w.cmaxG, 0, 8 * MLP_W * 4, st) != hipSuccess) return mlp_fail("mlp_backward: memset failed");
         if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
     }
-    const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
-    hipLaunchKernelGGL(mlp_heads_dw_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, w.Y[7], w.partial_h,
-                       w.partial_hb);
     hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3((p->n_out * MLP_W + 255) / 256), dim3(256), 0, st, hchunks, p->n_out,
                        w.partial_h, w.partial_hb, dWh, dbh);
     hipLaunchKernelGGL(mlp_reduce_bias16_kernel, dim3(1), dim3(256), 0, st, hchunks, p->n_out, w.partial_hb, dbh);
