@@ -247,7 +247,7 @@ def main():
             "mlp_layer_dw": ("mlp_dw3b_kernel (256x256 weight gradient over N rows)" if f16x3 else "mlp_dw6b_kernel", layer_flops, dw_bytes, "pmc_dw3b.json"),
             "render_bwd": ("render_bwd3_kernel", 0.0, alg_bytes, "pmc_render_bwd3.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
-            "tile_sort": ("tile_sort_small_kernel (+big)", 0.0, 20.0 * n_inst, None),
+            "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
             "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 48.0 * n_inst, None),
             "preprocess_fwd": ("preprocess_fwd_kernel", 0.0, 311.0 * P, None),
         }

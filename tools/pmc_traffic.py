@@ -10,9 +10,11 @@ import os
 import sys
 
 fetch_csv, write_csv, out_dir, workload = sys.argv[1:5]
-KERNELS = {"gemm3r_fwd": "mlp_gemm3p_kernel<0>", "gemm3r_bwd": "mlp_gemm3p_kernel<1>", "dw3b": "mlp_dw3b_kernel",
+KERNELS = {"gemm3r_fwd": "mlp_gemm3p_kernel<0, false>", "gemm3r_bwd": "mlp_gemm3p_kernel<1, false>", "dw3b": "mlp_dw3b_kernel",
            "render_bwd3": "render_bwd3_kernel", "render_fwd": "render_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
-           "tile_sort_small": "tile_sort_small_kernel"}
+           "tile_sort_radix": "tile_sort_radix_kernel", "heads_bwd": "mlp_heads_bwd_kernel", "reduce_dw1": "mlp_reduce_dw1_kernel"}
+# kernels whose reads are gathers of short records: the x2 streaming-read correction of FETCH_SIZE is not calibrated for them
+GATHER = {"render_bwd3", "render_fwd", "preprocess_bwd", "tile_sort_radix"}
 
 
 def per_kernel(path, counter):
@@ -35,9 +37,15 @@ for short, pat in KERNELS.items():
         print("missing", short)
         continue
     fetch_kb, write_kb = f[fk[0]], w[wk[0]]
+    gather = short in GATHER
     rec = {"workload": workload, "kernel": pat, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
-           "fetch_bytes": 2.0 * fetch_kb * 1024.0, "write_bytes": write_kb * 1024.0, "launches_sampled": [fn[fk[0]], wn[wk[0]]],
+           "fetch_bytes": (1.0 if gather else 2.0) * fetch_kb * 1024.0, "write_bytes": write_kb * 1024.0,
+           "launches_sampled": [fn[fk[0]], wn[wk[0]]],
            "method": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only, over bench.py; "
-                     "counters are KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950"}
+                     "counters are KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950",
+           "fetch_bytes_raw": fetch_kb * 1024.0, "fetch_bytes_doubled": 2.0 * fetch_kb * 1024.0,
+           "fetch_correction": ("none (gathers of short records / indexed rows: the x2 streaming-read correction is uncalibrated "
+                                "for this access pattern, so the raw counter is a LOWER bound and x2 an upper bound)") if gather
+           else "x2 (wide coalesced streaming reads)"}
     json.dump(rec, open(os.path.join(out_dir, f"pmc_{short}.json"), "w"), indent=1)
     print(f"{short:16s} fetch {rec['fetch_bytes'] / 1e6:8.1f} MB  write {rec['write_bytes'] / 1e6:8.1f} MB per launch")
