@@ -260,43 +260,37 @@ __device__ __forceinline__ void emit_sorted(const unsigned long long* s, int n, 
 //   * one wave turns the WAVES x 256 counters into destinations (digit major, wave minor); pairs move through LDS;
 //   * a pass whose digit is the same for every key of the tile is skipped (the exponent byte almost always is);
 //   * equal depths must end in ascending Gaussian index (what the reference's stable sort of the index-ordered emission
-//     gives): after the last pass entries with an equal neighbour are placed inside their run by counting smaller indices.
+//     gives): after the last pass entries with an equal neighbour are placed inside their run by counting smaller indices;
+//     a segment with a long run of equal depths is sorted again with index passes in front of the depth passes.
 // The Gaussian index and the per-Gaussian position are fetched from the instance records through the payload only once, at
 // the end (one 16-byte gather inside the tile's own segment), and the output is written in order.
 // (WAVES, RS_MAXB pairs per thread) = (4, 8): 256 threads, segments up to 2048 entries, one workgroup per tile at 65 VGPRs
 // (sixteen pairs per thread cost 248); (8, 8): 512 threads, up to 4096 entries, the tiles of the device-built "mid"
 // worklist -- a long segment is spread over more waves instead of more registers.
-template <int WAVES, int RS_MAXB>
-__device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __restrict__ inst, unsigned* __restrict__ point_list,
-                                                unsigned* __restrict__ upos, uint2* sk, unsigned (*cnt)[256],
-                                                unsigned* s_red) {
-    const int n = (int)(r.y - r.x);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nb = (n + WAVES * 64 - 1) / (WAVES * 64);  // batches of 64 per wave
-    const int w0 = wv * nb * 64;    // first array index of this wave
-    const uint4* seg = inst + r.x;  // (Gaussian, depth bits, per-Gaussian position, -) in arrival order
-    if (tid == 0) s_red[0] = 0u, s_red[1] = 0xFFFFFFFFu;
+// bits in which the keys of the segment differ (workgroup-wide OR / AND through two LDS words)
+template <int RS_MAXB>
+__device__ __forceinline__ unsigned radix_varying_bits(const unsigned (&key)[RS_MAXB], int n, int nb, int w0, unsigned* s_red) {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_red[0] = 0u, s_red[1] = 0xFFFFFFFFu;
     __syncthreads();
-    unsigned key[RS_MAXB], pay[RS_MAXB];
-    {
-        unsigned vo = 0u, va = 0xFFFFFFFFu;
+    unsigned vo = 0u, va = 0xFFFFFFFFu;
 #pragma unroll
-        for (int b = 0; b < RS_MAXB; b++) {
-            key[b] = 0xFFFFFFFFu, pay[b] = 0u;
-            if (b < nb) {
-                const int i = w0 + b * 64 + lane;
-                if (i < n) {
-                    key[b] = seg[i].y;
-                    pay[b] = (unsigned)i;
-                    vo |= key[b], va &= key[b];
-                }
-            }
-        }
-        atomicOr(&s_red[0], vo);
-        atomicAnd(&s_red[1], va);
-    }
+    for (int b = 0; b < RS_MAXB; b++)
+        if (b < nb && w0 + b * 64 + lane < n) vo |= key[b], va &= key[b];
+    atomicOr(&s_red[0], vo);
+    atomicAnd(&s_red[1], va);
     __syncthreads();
-    const unsigned varying = s_red[0] ^ s_red[1];
+    const unsigned v = s_red[0] ^ s_red[1];
+    __syncthreads();  // (s_red is reused)
+    return v;
+}
+
+// stable LSD passes over the bits set in `varying`, 8 bits per pass; on return sk[0 .. n) holds the (key, payload) pairs in
+// order and key[] / pay[] the pairs at this thread's own array positions
+template <int WAVES, int RS_MAXB>
+__device__ __forceinline__ void radix_passes(unsigned (&key)[RS_MAXB], unsigned (&pay)[RS_MAXB], unsigned varying, int n, int nb,
+                                             int w0, uint2* sk, unsigned (*cnt)[256]) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     bool moved = false;
 #pragma unroll 1
     for (int shift = 0; shift < 32; shift += 8) {
@@ -367,14 +361,61 @@ __device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __re
             }
         }
     }
-    if (!moved) {  // every key equal (or a single one): the array order is the unsorted order
+    if (!moved) {  // every key equal (or a single one): the array order stays
 #pragma unroll
         for (int b = 0; b < RS_MAXB; b++) {
             if (b < nb && w0 + b * 64 + lane < n) sk[w0 + b * 64 + lane] = make_uint2(key[b], pay[b]);
         }
         __syncthreads();
     }
-    // gather the Gaussian index and the per-Gaussian position through the payload; resolve equal depths
+}
+
+static constexpr int kTieRun = 32;  // runs of equal depth up to this length are ordered in place, longer ones by index passes
+
+template <int WAVES, int RS_MAXB>
+__device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __restrict__ inst, unsigned* __restrict__ point_list,
+                                                unsigned* __restrict__ upos, uint2* sk, unsigned (*cnt)[256],
+                                                unsigned* s_red) {
+    const int n = (int)(r.y - r.x);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = (n + WAVES * 64 - 1) / (WAVES * 64);  // batches of 64 per wave
+    const int w0 = wv * nb * 64;    // first array index of this wave
+    const uint4* seg = inst + r.x;  // (Gaussian, depth bits, per-Gaussian position, -) in arrival order
+    // Equal depths must come out by ascending Gaussian index.  Short runs (the normal case: none, or a pair) are ordered in
+    // place below; if any run is longer than kTieRun -- a scene whose Gaussians share one view depth -- the segment is sorted
+    // again from scratch with index passes in front of the depth passes (LSD: the later key is the more significant).
+    // phase 0: by depth;  then, only after a long run:  phase 1: by index,  phase 2: by depth again (one copy of the passes).
+    unsigned key[RS_MAXB], pay[RS_MAXB];
+    bool resort = false;
+#pragma unroll 1
+    for (int phase = 0; phase < 3; phase++) {
+#pragma unroll
+        for (int b = 0; b < RS_MAXB; b++) {
+            const int i = w0 + b * 64 + lane;
+            const bool valid = b < nb && i < n;
+            if (phase < 2) pay[b] = valid ? (unsigned)i : 0u;
+            key[b] = 0xFFFFFFFFu;
+            if (valid) {
+                const uint4 e = seg[pay[b]];
+                key[b] = phase == 1 ? e.x : e.y;
+            }
+        }
+        const unsigned varying = radix_varying_bits<RS_MAXB>(key, n, nb, w0, s_red);
+        radix_passes<WAVES, RS_MAXB>(key, pay, varying, n, nb, w0, sk, cnt);
+        if (phase == 0) {
+            bool long_run = false;
+#pragma unroll
+            for (int b = 0; b < RS_MAXB; b++) {
+                const int i = w0 + b * 64 + lane;
+                if (b < nb && i + kTieRun < n && sk[i + kTieRun].x == key[b]) long_run = true;
+            }
+            resort = __syncthreads_or(long_run) != 0;  // (also: every wave is past its reads of sk)
+            if (!resort) break;
+        } else {
+            __syncthreads();
+        }
+    }
+    // gather the Gaussian index and the per-Gaussian position through the payload; place the members of short runs
     unsigned gid[RS_MAXB], up[RS_MAXB], dst[RS_MAXB];
 #pragma unroll
     for (int b = 0; b < RS_MAXB; b++) {
@@ -385,7 +426,7 @@ __device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __re
                 const uint4 e = seg[pay[b]];
                 gid[b] = e.x, up[b] = e.z;
                 dst[b] = (unsigned)i;
-                const bool tie = (i > 0 && sk[i - 1].x == key[b]) || (i + 1 < n && sk[i + 1].x == key[b]);
+                const bool tie = !resort && ((i > 0 && sk[i - 1].x == key[b]) || (i + 1 < n && sk[i + 1].x == key[b]));
                 if (tie) {
                     int s0 = i, s1 = i + 1;
                     while (s0 > 0 && sk[s0 - 1].x == key[b]) s0--;

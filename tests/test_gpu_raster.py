@@ -201,14 +201,40 @@ def test_big_tile_lists(orc, syn):
 
 
 def test_depth_ties_sorted_by_index(orc, syn):
-    """Equal depths: order must be ascending Gaussian index (what the reference's stable sort produces)."""
+    """Equal depths: order must be ascending Gaussian index (what the reference's stable sort produces).  Three shapes of
+    the tile sort's tie handling: one long run per tile in the one-workgroup-per-tile class and in the worklist class (both
+    re-sort with index passes), and many short runs (ordered in place)."""
+    # (a) all 600 on one point -> identical depth bits, one run per tile
     a = raster_args(syn, 600, 96, 96, seed=8)
-    a["means3D"][:, :] = a["means3D"][:1]          # all on one point -> identical depth bits
-    a["means3D"] += 0
+    a["means3D"][:, :] = a["means3D"][:1]
     f_hip = G.hip_forward(a)
     f_or = oracle_forward(orc, a)
     assert f_or["num_rendered"] > 0
     assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+    # (b) 3000 on one point, every Gaussian covering the image: runs of 3000 in the 2049..4096 class
+    a = raster_args(syn, 3000, 48, 48, seed=6, kind="init", extent=0.4)
+    a["scales"] = (a["scales"] * 0 + 0.5).astype(np.float32)
+    a["opacities"] = (a["opacities"] * 0 + 0.004).astype(np.float32)
+    a["means3D"][:, :] = a["means3D"][:1]
+    f_hip = G.hip_forward(a)
+    f_or = oracle_forward(orc, a)
+    n = f_or["binning"]["ranges"][:, 1] - f_or["binning"]["ranges"][:, 0]
+    assert n.max() > 2048
+    assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+    # (c) pairs and triples of equal depth among distinct ones: Gaussian i sits on the point of Gaussian i % 170
+    a = raster_args(syn, 500, 96, 96, seed=11)
+    a["means3D"][:, :] = a["means3D"][np.arange(500) % 170]
+    f_hip = G.hip_forward(a)
+    f_or = oracle_forward(orc, a)
+    assert f_or["num_rendered"] > 0
+    assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+    # (d) two depths only, indices interleaved: two long runs per tile
+    a = raster_args(syn, 900, 64, 64, seed=12)
+    a["means3D"][:, :] = a["means3D"][np.arange(900) % 2]
+    f_hip = G.hip_forward(a)
+    f_or = oracle_forward(orc, a)
+    assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+    assert np.array_equal(f_hip["ranges"], f_or["binning"]["ranges"])
 
 
 @pytest.mark.parametrize("variant", ["colors_precomp", "cov3D_precomp", "deg0", "deg1", "deg2", "black_bg"])
