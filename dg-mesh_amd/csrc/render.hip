@@ -26,8 +26,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
                   float4* __restrict__ cfin, unsigned* __restrict__ nproc_out) {
-    __shared__ float4 sA[256];  // x, y, conic a, conic b
-    __shared__ float4 sB[256];  // conic c, opacity, r, g
+    __shared__ float4 sA[256];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
+    __shared__ float4 sB[256];  // conic c * -log2(e)/2, opacity, r, g
     __shared__ float sC[256];   // b
     __shared__ unsigned long long sMask[4][4];  // [staging wave][quadrant]
     __shared__ unsigned sMaxC[4];               // per-wave maximum of last_contributor
@@ -64,8 +64,11 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * DGM_REC_STRIDE);
             const float4 r0 = r4[0], r1 = r4[1];
             const float cb = r4[2].x;
-            sA[threadIdx.x] = r0;
-            sB[threadIdx.x] = r1;
+            // the conic is staged pre-multiplied so that the exponent below comes out times log2(e), ready for v_exp_f32
+            // (same sign as the reference's `power`; render_bwd3 stages the same way)
+            const float l2e = 1.4426950408889634f;
+            sA[threadIdx.x] = make_float4(r0.x, r0.y, -0.5f * l2e * r0.z, -l2e * r0.w);
+            sB[threadIdx.x] = make_float4(-0.5f * l2e * r1.x, r1.y, r1.z, r1.w);
             sC[threadIdx.x] = cb;
             qm = quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx0, ty0);
         }
@@ -87,8 +90,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                 const float4 A = sA[j];
                 const float4 B = sB[j];
                 const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float alpha = fminf(0.99f, B.y * fast_exp(power));
+                const float power = (A.z * dx + A.w * dy) * dx + (B.x * dy) * dy;  // the reference's exponent times log2(e)
+                const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power));
                 bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 const float test_T = T * (1.0f - alpha);
                 if (valid && test_T < 0.0001f) {
