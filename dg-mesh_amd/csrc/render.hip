@@ -89,23 +89,23 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                 m &= m - 1;
                 const float4 A = sA[j];
                 const float4 B = sB[j];
+                const float cb = sC[j];
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = (A.z * dx + A.w * dy) * dx + (B.x * dy) * dy;  // the reference's exponent times log2(e)
                 const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power));
-                bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 const float test_T = T * (1.0f - alpha);
-                if (valid && test_T < 0.0001f) {
-                    done = true;
-                    valid = false;
-                }
-                if (valid) {
-                    const float w = alpha * T;
-                    C0 += B.z * w;
-                    C1 += B.w * w;
-                    C2 += sC[j] * w;
-                    T = test_T;
-                    last_contributor = base + (unsigned)j + 1u;
-                }
+                const bool stop = pass && test_T < 0.0001f;
+                const bool valid = pass && !stop;
+                done = done || stop;
+                // branch-free: a pixel that skips the splat blends it with weight zero (the three colour reads are issued
+                // with the geometry reads instead of behind a divergent branch)
+                const float w = valid ? alpha * T : 0.f;
+                C0 += B.z * w;
+                C1 += B.w * w;
+                C2 += cb * w;
+                T = valid ? test_T : T;
+                last_contributor = valid ? base + (unsigned)j + 1u : last_contributor;
             }
         }
     }
