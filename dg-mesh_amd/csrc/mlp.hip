@@ -650,7 +650,7 @@ struct Ws {
     float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb;
     uint4 *Wt6[8], *Wd6[8], *Wh6f;  // bf16x6 weight planes
     uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
-    float *wsc_f[8], *wsc_d[8];            // their inverse column scales
+    float *wsc_f[8], *wsc_d[8], *wsc_e;    // their inverse column scales (wsc_e: the embedding half of the skip layer)
     unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
     unsigned *cmaxW;                       // [16][256] column maxima of the weight matrices (prep3 pass 1)
     unsigned* mask[8];
@@ -704,7 +704,7 @@ hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once 
     bool& d = done[current_device_slot()];
     if (d) return hipSuccess;
     hipError_t e = hipSuccess;
-    const void* fns[4] = {(const void*)mlp_gemm3p_kernel<0, false>, (const void*)mlp_gemm3p_kernel<0, true>,
+    const void* fns[4] = {(const void*)mlp_gemm3p_kernel<0, false>, (const void*)mlp_gemm3p_kernel<2, false>,
                           (const void*)mlp_gemm3p_kernel<1, false>, (const void*)mlp_gemm3p_kernel<1, true>};
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
     if (e == hipSuccess) d = true;
@@ -742,6 +742,7 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.Wd3[l] = (uint4*)take((size_t)MLP_W * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.wsc_f[l] = take(MLP_W * 4);
     for (int l = 0; l < 8; l++) w.wsc_d[l] = take(MLP_W * 4);
+    w.wsc_e = take(MLP_W * 4);
     w.cmaxY = (unsigned*)take(8 * MLP_W * 4);
     w.cmaxG = (unsigned*)take(8 * MLP_W * 4);
     w.cmaxW = (unsigned*)take(PREP3_MAX_JOBS * MLP_W * 4);
@@ -821,8 +822,12 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             j.k_valid = MLP_W, j.col_valid = MLP_W, j.W = Wp, j.Bp = Bp, j.inv_scale = inv_scale;
         };
         for (int l = 0; l < 8; l++) {
-            const bool l3 = x3 && l != p->skip_layer;  // the K = 352 planes of the skip layer do not fit the register file
-            if (l3) add3(0, layer_kp(p, l), layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_f[l]);
+            // the K = 352 planes of the skip layer do not fit the register file: its embedding half (K = 96, planes at the
+            // front of Wt3[l]) rides along with layer 0, its trunk half (K = 256, behind them) adds that result in its epilogue
+            if (x3 && l == p->skip_layer) {
+                add3(0, MLP_EMB, layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_e);
+                add3(0, MLP_W, layer_in(p, l), p->emb_dim, p->W[l], w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l]);
+            } else if (x3) add3(0, layer_kp(p, l), layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_f[l]);
             else add(0, layer_kp(p, l), MLP_W, layer_in(p, l), 0, 0, MLP_W, p->W[l], w.Wt6[l]);
             if (l >= 1) {
                 if (x3) add3(1, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, p->W[l], w.Wd3[l], w.wsc_d[l]);
@@ -860,27 +865,29 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         }
         if (!f32) {
             const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
-            if (K1 + K2 == MLP_EMB + MLP_W) {  // skip layer: bf16x6, weights streamed through LDS
+            if (K1 + K2 == MLP_EMB + MLP_W && use_f16x3()) {
+                // skip layer, trunk half: Y5 = relu(Y4 * W5[:, emb:]^T + C_in), C_in = emb * W5[:, :emb]^T + b5 already in Y5
+                dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
+                hipLaunchKernelGGL((mlp_gemm3p_kernel<2, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A2, lda2,
+                                   w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l], (const float*)nullptr, w.mask[l], w.Y[l],
+                                   w.cmaxY + l * MLP_W, (unsigned*)nullptr);
+                dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
+            } else if (K1 + K2 == MLP_EMB + MLP_W) {  // skip layer: bf16x6, weights streamed through LDS
                 hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2,
                                    lda2, K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W);
             } else if (use_f16x3()) {
                 if (K1 + K2 == MLP_W) {
                     dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                    // the skip layer (bf16x6) does not deliver the column maxima of its output, which the next layer's
-                    // weight gradient needs for its scales: the layer that READS that output accumulates them on the way
-                    if (l == p->skip_layer + 1)
-                        hipLaunchKernelGGL((mlp_gemm3p_kernel<0, true>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
-                                           w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
-                                           w.cmaxY + (l - 1) * MLP_W);
-                    else
-                        hipLaunchKernelGGL((mlp_gemm3p_kernel<0, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
-                                           w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
-                                           (unsigned*)nullptr);
+                    hipLaunchKernelGGL((mlp_gemm3p_kernel<0, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
+                                       w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
+                                       (unsigned*)nullptr);
                     dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
-                } else
-                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
+                } else {  // layer 0, with the embedding half of the skip layer as second output (into Y[skip], linear + bias)
+                    const int sk = p->skip_layer;
+                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1, true>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
                                        A1, lda1, K1, A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l],
-                                       w.cmaxY + l * MLP_W);
+                                       w.cmaxY + l * MLP_W, (const uint4*)w.Wt3[sk], (const float*)w.wsc_e, p->b[sk], w.Y[sk]);
+                }
             } else if (K1 + K2 == MLP_W) {
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
                 hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, A1, lda1, K1, A2, lda2,

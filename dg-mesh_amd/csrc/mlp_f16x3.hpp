@@ -82,7 +82,7 @@ struct Prep3Batch {
 
 __device__ __forceinline__ float prep3_src(const Prep3Job& j, int k, int col) {
     if (j.mode == 0) {
-        int src = k;
+        int src = k + j.hoff;  // (hoff: first input feature of a K = 256 slice -- the skip layer's trunk half)
         if (j.Kp == 96) src = k < j.emb_dim ? k : -1;
         else if (j.Kp == 352) src = k < 96 ? (k < j.emb_dim ? k : -1) : k - 96 + j.emb_dim;
         return (src >= 0 && col < j.col_valid) ? j.W[(size_t)col * j.in_features + src] : 0.f;
@@ -230,11 +230,16 @@ __device__ __forceinline__ void gemm3r_store(const f32x16& acc, const unsigned* 
     }
 }
 
-template <int EPI, int KS, int PF>
+// DUAL: a second weight matrix over the same activations -- C2 = A * B2 + bias2, no ReLU (layer 0 and the embedding half of
+// the skip layer both consume the embedding: one read of it, one set of row scales and planes, two outputs; C2 is the C_in
+// of mlp_gemm3p_kernel<2>).  One accumulator chain per output in that case.
+template <int EPI, int KS, int PF, bool DUAL = false>
 __global__ void __launch_bounds__(512)
 mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int K1, const float* __restrict__ A2, int lda2,
                   const uint4* __restrict__ Bp, const float* __restrict__ b_inv_scale, const float* __restrict__ bias,
-                  unsigned* __restrict__ mask, float* __restrict__ C, unsigned* __restrict__ colmax) {
+                  unsigned* __restrict__ mask, float* __restrict__ C, unsigned* __restrict__ colmax,
+                  const uint4* __restrict__ Bp2 = nullptr, const float* __restrict__ b_inv_scale2 = nullptr,
+                  const float* __restrict__ bias2 = nullptr, float* __restrict__ C2 = nullptr) {
     constexpr int K = KS * 16;
     constexpr int NI = (K + 255) / 256;        // row-load instructions per row
     constexpr int RS = 4 * K + 16;             // bytes per LDS row: two planes of K halves + pad (odd multiple of 16 mod 256)
@@ -260,6 +265,16 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
     const float binv = b_inv_scale[col];
     const float bv = (EPI == 0) ? bias[col] : 0.f;
     float cmax = 0.f;
+    f16x8 bh2[DUAL ? KS : 1], bl2[DUAL ? KS : 1];
+    float binv2 = 0.f, bv2 = 0.f;
+    if (DUAL) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const uint4* b = Bp2 + ((size_t)ks * 4 + g) * 256 + col;
+            bh2[DUAL ? ks : 0] = as_f16x8(b[0]), bl2[DUAL ? ks : 0] = as_f16x8(b[512]);
+        }
+        binv2 = b_inv_scale2[col], bv2 = bias2[col];
+    }
 
     float4 R[PF][4][NI];
 #define R3_LOAD(slot_, tile_)                                                                                          \
@@ -315,16 +330,26 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         f16x8 fh_[3], fl_[3];                                                                                          \
         fh_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_));                                                       \
         fl_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE));                                               \
-        fh_[1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (KS > 1 ? 32 : 0)));                                   \
-        fl_[1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (KS > 1 ? 32 : 0)));                           \
+        constexpr int PD_ = DUAL ? 1 : 2; /* DUAL: a step is six MFMAs (192 cycles): one step ahead covers the LDS latency */ \
+        if (PD_ == 2) {                                                                                                \
+            fh_[1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (KS > 1 ? 32 : 0)));                               \
+            fl_[1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (KS > 1 ? 32 : 0)));                       \
+        }                                                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < KS; ks++) {                                                            \
-            if (ks + 2 < KS) {                                                                                         \
-                fh_[(ks + 2) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (ks + 2) * 32));                    \
-                fl_[(ks + 2) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (ks + 2) * 32));            \
+            if (ks + PD_ < KS) {                                                                                       \
+                fh_[(ks + PD_) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (ks + PD_) * 32));                \
+                fl_[(ks + PD_) % 3] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (ks + PD_) * 32));        \
             }                                                                                                          \
             /* two accumulator chains (cross terms | leading term): a dependent MFMA waits for its predecessor's */    \
             /* result, alternating chains keeps the matrix pipe issuing every 32 cycles                           */    \
-            if (ks == 0) {                                                                                             \
+            if (DUAL) { /* acc: first output, acc2: second output, alternated */                                      \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bl[ks], ks == 0 ? zero16 : acc, 0, 0, 0);    \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bl2[DUAL ? ks : 0], ks == 0 ? zero16 : acc2, 0, 0, 0); \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks % 3], bh[ks], acc, 0, 0, 0);                       \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks % 3], bh2[DUAL ? ks : 0], acc2, 0, 0, 0);         \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bh[ks], acc, 0, 0, 0);                       \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % 3], bh2[DUAL ? ks : 0], acc2, 0, 0, 0);         \
+            } else if (ks == 0) {                                                                                      \
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bl[0], zero16, 0, 0, 0);                         \
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bh[0], zero16, 0, 0, 0);                          \
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[0], bh[0], acc2, 0, 0, 0);                           \
@@ -336,7 +361,8 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         }                                                                                                              \
     }
 #define R3_UNSCALE(pb_)                                                                                                \
-    acc += acc2;                                                                                                       \
+    if (DUAL) gemm3r_unscale(acc2, rinv + (pb_) * 32, g, binv2);                                                       \
+    else acc += acc2;                                                                                                  \
     gemm3r_unscale(acc, rinv + (pb_) * 32, g, binv);
 #define R3_MWORD() if (EPI == 1) mlds[wv * 32 + li] = mword; /* both halves write the same 32 words; read back by this wave only */
 #define R3_STORE(tile_)                                                                                                \
@@ -346,6 +372,17 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
         unsigned* mb_ = mask + (size_t)row0_ * 8 + wv;                                                                 \
         if ((tile_) * 32 + 32 <= M) gemm3r_store<EPI, true>(acc, mlds + wv * 32, row0_, M, cb_, mb_, g, li, bv, cmax);   \
         else gemm3r_store<EPI, false>(acc, mlds + wv * 32, row0_, M, cb_, mb_, g, li, bv, cmax);                       \
+        if (DUAL) { /* second output: linear, bias only */                                                             \
+            float* c2_ = C2 + (size_t)row0_ * 256 + col;                                                               \
+            if ((tile_) * 32 + 32 <= M) {                                                                              \
+                _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) c2_[((r_ & 3) + 8 * (r_ >> 2)) * 256] = acc2[r_] + bv2; \
+            } else {                                                                                                   \
+                _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) {                                                    \
+                    const int ro_ = (r_ & 3) + 8 * (r_ >> 2);                                                          \
+                    if (row0_ + ro_ < M) c2_[ro_ * 256] = acc2[r_] + bv2;                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
     }
     // EPI 1: the tile's 32 mask words of this wave's column group, one per lane, requested a phase before their use
 #define R3_MASK(tile_)                                                                                                 \
@@ -455,6 +492,9 @@ mlp_gemm3r_kernel(int M, int ntiles, const float* __restrict__ A1, int lda1, int
 // split lands in an LDS buffer nobody reads), the first step has its own copy without an epilogue, and the globally last --
 // possibly partial -- tile is always some workgroup's final tile and is stored by the predicated path after the loop.
 // CMAX_IN: also accumulate the column maxima of the INPUT rows (for a producer that cannot deliver them) into colmax_in.
+// EPI 2 (the skip layer's 256-wide half): C = relu(acc + C_in), where C already holds the other half of the product plus the
+// bias (written by the K = 96 kernel's second output); the tile's sixteen C_in values per lane are requested at the tile's
+// memory slot (step 8) and consumed half a tile later by the epilogue, in place.
 template <int EPI, bool CMAX_IN>
 __global__ void __launch_bounds__(512)
 mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const uint4* __restrict__ Bp,
@@ -485,6 +525,7 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
     float4 cin = make_float4(0.f, 0.f, 0.f, 0.f);  // CMAX_IN: running maxima of input columns 4 lane .. 4 lane + 3
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc, out;
+    float ev[EPI == 2 ? 16 : 1];  // EPI 2: C_in of the tile whose accumulators are in flight
     float4 R[2][4];     // rows of tile t live in R[t & 1]
     unsigned mw[2] = {0u, 0u};  // EPI 1: mask word (row li of the tile, this wave's column group) of tile t in mw[t & 1]
 
@@ -537,8 +578,8 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
     {                                                                                                                  \
         const int ro_ = ((r_) & 3) + 8 * ((r_) >> 2);                                                                  \
         float v_ = out[r_];                                                                                            \
-        if (EPI == 0) {                                                                                                \
-            v_ = fmaxf(v_ + bv, 0.f);                                                                                  \
+        if (EPI == 0 || EPI == 2) {                                                                                    \
+            v_ = fmaxf(v_ + (EPI == 2 ? ev[EPI == 2 ? (r_) : 0] : bv), 0.f);                                           \
             const unsigned long long bal_ = __ballot(v_ > 0.f);                                                        \
             const unsigned mwd_ = g ? (unsigned)(bal_ >> 32) : (unsigned)bal_;                                         \
             mwsel = (li == (r_)) ? mwd_ : mwsel;                                                                       \
@@ -578,12 +619,20 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
             if (!(FIRST_) && ks < 8) {                                                                                 \
                 P3_STORE_REG(2 * ks)                                                                                   \
                 P3_STORE_REG(2 * ks + 1)                                                                               \
-                if (EPI == 0 && ks == 7 && li < 16) mb[((li & 3) + 8 * (li >> 2)) * 8] = mwsel;                        \
+                if ((EPI == 0 || EPI == 2) && ks == 7 && li < 16) mb[((li & 3) + 8 * (li >> 2)) * 8] = mwsel;          \
             }                                                                                                          \
             if (EPI == 1 && ks == 0) mlds[pb * 256 + wv * 32 + li] = mw[1 - (SN_)]; /* this tile's mask words */        \
             if (ks == 8) {                                                                                             \
                 P3_ROWMAX(SN_) /* first use of tile j+1's rows: the tile's one memory wait */                          \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
+                if (EPI == 2) { /* C_in of THIS tile, ahead of the row loads: the epilogue's wait leaves those in flight */ \
+                    const int t_ = blockIdx.x + (j_) * G;                                                              \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) {                                                \
+                        int er_ = t_ * 32 + 4 * g + (r_ & 3) + 8 * (r_ >> 2);                                          \
+                        er_ = er_ < M ? er_ : M - 1;                                                                   \
+                        ev[EPI == 2 ? r_ : 0] = C[(size_t)er_ * 256 + col];                                            \
+                    }                                                                                                  \
+                }                                                                                                      \
                 P3_LOAD(1 - (SN_), P3_TILE((j_) + 2))                                                                  \
             }                                                                                                          \
             if (ks == 9) wave_max4_stage_a(m_[0], m_[1], m_[2], m_[3]);                                                \
@@ -626,8 +675,13 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
         float* cb = C + (size_t)row0 * 256 + col;
         unsigned* mb = mask + (size_t)row0 * 8 + wv;
         const unsigned* ml = mlds + ((my_tiles - 1) & 1) * 256 + wv * 32;
-        if (tile * 32 + 32 <= M) gemm3r_store<EPI, true>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
-        else gemm3r_store<EPI, false>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
+        if (EPI == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) out[r] += ev[EPI == 2 ? r : 0];  // (rows beyond M: clamped loads, never stored)
+        }
+        constexpr int SE = EPI == 2 ? 0 : EPI;  // bias already inside C_in: plain ReLU / mask epilogue with bias 0
+        if (tile * 32 + 32 <= M) gemm3r_store<SE, true>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
+        else gemm3r_store<SE, false>(out, ml, row0, M, cb, mb, g, li, bv, cmax);
     }
     if (CMAX_IN && colmax_in != nullptr) {
         // the clamped tail re-reads the last tile (same values: harmless for a maximum); fold the eight waves through LDS
