@@ -79,6 +79,41 @@ __global__ void mlp_embed_kernel(int N, const float* __restrict__ x, const float
     emb[idx] = v;
 }
 
+// Column maxima of |emb| (float bits) -- the scales of the f16x3 weight gradients of the two layers that consume the
+// embedding -- without a pass over it: the sin / cos columns are bounded by 1, the x and time columns are reduced from their
+// sources (thread = one of the 3 + T source columns, sixteen rows per batch; one atomic per column and workgroup; cmax zeroed by the
+// caller).
+__global__ void __launch_bounds__(256)
+mlp_embed_cmax_kernel(int N, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
+                      unsigned* __restrict__ cmax) {
+    __shared__ float smax[4][64];
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int nrows_t = temb_stride != 0 ? N : 1;  // a broadcast time embedding is a single row
+    float mx = 0.f;
+    if (j < 3 + T) {
+        const int nr = j < 3 ? N : nrows_t;
+        // sixteen rows per batch, all loads in flight at once; 128 workgroups stride over the rows
+        for (int rb = (blockIdx.x * 4 + slice) * 16; rb < nr; rb += gridDim.x * 64) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = rb + i;
+                v[i] = 0.f;
+                if (r < nr) v[i] = j < 3 ? x[3 * r + j] : temb[(size_t)r * temb_stride + (j - 3)];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) mx = fmaxf(mx, fabsf(v[i]));
+        }
+    }
+    smax[slice][j] = mx;
+    __syncthreads();
+    if (slice == 0 && j < 3 + T) {
+        mx = fmaxf(fmaxf(smax[0][j], smax[1][j]), fmaxf(smax[2][j], smax[3][j]));
+        atomicMax(cmax + (j < 3 ? j : MLP_XE + (j - 3)), __float_as_uint(mx));
+    }
+    if (blockIdx.x == 0 && threadIdx.x >= 3 && threadIdx.x < MLP_XE) cmax[threadIdx.x] = __float_as_uint(1.0f);
+}
+
 // ---- the 256-wide GEMM: C[M x 256] = [A1 | A2][M x (K1+K2)] * Bt[(K1+K2) x 256] ------------------------------------
 // EPI 0: C = relu(acc + bias), and the ReLU mask is saved as bits: mask[row][col / 32] bit (col % 32)
 // EPI 1: C = acc where the saved mask bit of the layer below is set, else 0  (backward data: the product is
@@ -652,6 +687,7 @@ struct Ws {
     uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
     float *wsc_f[8], *wsc_d[8], *wsc_e;    // their inverse column scales (wsc_e: the embedding half of the skip layer)
     unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
+    unsigned* cmaxE;                       // [256] column maxima of the embedding (right behind cmaxY: one memset clears both)
     unsigned *cmaxW;                       // [16][256] column maxima of the weight matrices (prep3 pass 1)
     unsigned* mask[8];
     size_t bytes;
@@ -672,11 +708,12 @@ int num_cus() {
 struct DwPlan {
     int rows, chunks, slabs;
 };
-DwPlan dw6_plan(int N, int Kp) {
+DwPlan dw6_plan(int N, int Kp, bool x3) {
     DwPlan d;
     d.slabs = (Kp + DW6_SLAB - 1) / DW6_SLAB;
-    if (Kp == MLP_W) d.slabs = 1;  // mlp_dw6b_kernel: one 8-wave workgroup per chunk covers all 256 columns
-    const int target = (Kp == MLP_W) ? num_cus() : 512 / d.slabs;
+    // mlp_dw6b / dw3b / dw3e kernels: one 8-wave workgroup per chunk covers all columns
+    if (Kp == MLP_W || x3) d.slabs = 1;
+    const int target = d.slabs == 1 ? num_cus() : 512 / d.slabs;
     int rows = (N + target - 1) / target;
     rows = (rows + 15) & ~15;
     if (rows < 16) rows = 16;
@@ -699,6 +736,7 @@ int g_gemm_mode = [] {
 bool use_f32_mfma() { return g_gemm_mode == 1; }
 bool use_f16x3() { return g_gemm_mode == 2; }
 #define G3R_LDS(K_) (2 * 32 * (4 * (K_) + 16) + 256 + 2 * 8 * 32 * 4)  // A planes (double buffered) + row scales + mask words
+#define DW3E_LDS(MT_) (2 * (4 * (MT_) * 32 + DW3_U) * 16)  // X and G stages, two planes each, double buffered
 hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once per device
     static bool done[DGM_MAX_DEVICES] = {false};
     bool& d = done[current_device_slot()];
@@ -707,6 +745,8 @@ hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once 
     const void* fns[4] = {(const void*)mlp_gemm3p_kernel<0, false>, (const void*)mlp_gemm3p_kernel<2, false>,
                           (const void*)mlp_gemm3p_kernel<1, false>, (const void*)mlp_gemm3p_kernel<1, true>};
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)mlp_dw3e_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, DW3E_LDS(11));
     if (e == hipSuccess) d = true;
     return e;
 }
@@ -729,9 +769,11 @@ Ws carve(char* base, int N) {
     w.Gb = take(n * MLP_W * 4);
     size_t pfl = (size_t)chunks * (MLP_EMB + MLP_W), pdb = (size_t)chunks;
     for (int Kp : {MLP_EMB, MLP_W, MLP_EMB + MLP_W}) {
-        const DwPlan d = dw6_plan(N > 0 ? N : 1, Kp);
-        if ((size_t)d.chunks * Kp > pfl) pfl = (size_t)d.chunks * Kp;
-        if ((size_t)d.chunks * 2 > pdb) pdb = (size_t)d.chunks * 2;
+        for (int x3 = 0; x3 < 2; x3++) {  // the workspace does not depend on the arithmetic selected later
+            const DwPlan d = dw6_plan(N > 0 ? N : 1, Kp, x3 != 0);
+            if ((size_t)d.chunks * Kp > pfl) pfl = (size_t)d.chunks * Kp;
+            if ((size_t)d.chunks * 2 > pdb) pdb = (size_t)d.chunks * 2;
+        }
     }
     w.partial = take(pfl * MLP_W * 4);
     w.partial_db = take(pdb * MLP_W * 4);
@@ -743,7 +785,8 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.wsc_f[l] = take(MLP_W * 4);
     for (int l = 0; l < 8; l++) w.wsc_d[l] = take(MLP_W * 4);
     w.wsc_e = take(MLP_W * 4);
-    w.cmaxY = (unsigned*)take(8 * MLP_W * 4);
+    w.cmaxY = (unsigned*)take(9 * MLP_W * 4);
+    w.cmaxE = w.cmaxY + 8 * MLP_W;
     w.cmaxG = (unsigned*)take(8 * MLP_W * 4);
     w.cmaxW = (unsigned*)take(PREP3_MAX_JOBS * MLP_W * 4);
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
@@ -838,7 +881,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
         if (n3 > 0) {
             // cmaxY | cmaxG | cmaxW are adjacent in the workspace: one fill clears the forward's two
-            if (hipMemsetAsync(w.cmaxY, 0, 8 * MLP_W * 4, st) != hipSuccess || hipMemsetAsync(w.cmaxW, 0, PREP3_MAX_JOBS * MLP_W * 4, st) != hipSuccess)
+            if (hipMemsetAsync(w.cmaxY, 0, 9 * MLP_W * 4, st) != hipSuccess || hipMemsetAsync(w.cmaxW, 0, PREP3_MAX_JOBS * MLP_W * 4, st) != hipSuccess)
                 return mlp_fail("mlp_forward: memset failed");
             const int pthreads = (MLP_EMB + MLP_W) / 8 * MLP_W;
             hipLaunchKernelGGL(mlp_prep3_max_kernel, dim3((pthreads + 255) / 256, n3), dim3(256), 0, st, p3, w.cmaxW);
@@ -850,6 +893,8 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         const size_t tot = (size_t)N * MLP_EMB;
         hipLaunchKernelGGL(mlp_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, x, temb, temb_stride,
                            p->t_dim, w.emb);
+        if (use_f16x3())
+            hipLaunchKernelGGL(mlp_embed_cmax_kernel, dim3(128), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.cmaxE);
     }
     const int grid = (N + GM - 1) / GM;
     const int grid6 = (N + 127) / 128;
@@ -978,7 +1023,8 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, chunks, chunks, Kp,
                                layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
         } else {
-            const DwPlan d = dw6_plan(N, Kp);
+            const DwPlan d = dw6_plan(N, Kp, x3);
+            int db_rows = 2 * d.chunks;  // bias-gradient partial rows the kernel leaves
             if (Kp == MLP_W) {
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
                 if (x3)
@@ -988,10 +1034,19 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                     hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial,
                                        w.partial_db);
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
+            } else if (x3) {  // the layers that consume the embedding: K = 96 (layer 0) / 352 (skip layer), f16x3
+                db_rows = d.chunks;
+                if (Kp == MLP_EMB)
+                    hipLaunchKernelGGL(mlp_dw3e_kernel<3>, dim3(d.chunks), dim3(512), DW3E_LDS(3), st, N, d.rows, X1, ldx1, K1, X2,
+                                       ldx2, G, w.cmaxE, (const unsigned*)nullptr, w.cmaxG + l * MLP_W, w.partial, w.partial_db);
+                else
+                    hipLaunchKernelGGL(mlp_dw3e_kernel<11>, dim3(d.chunks), dim3(512), DW3E_LDS(11), st, N, d.rows, X1, ldx1, K1,
+                                       X2, ldx2, G, w.cmaxE, w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial,
+                                       w.partial_db);
             } else
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
                                    K2, G, w.partial, w.partial_db);
-            hipLaunchKernelGGL(mlp_reduce_dw1_kernel, dim3(Kp / 2 * 8), dim3(256), 0, st, d.chunks, 2 * d.chunks, Kp,
+            hipLaunchKernelGGL(mlp_reduce_dw1_kernel, dim3(Kp / 2 * 8), dim3(256), 0, st, d.chunks, db_rows, Kp,
                                layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
         }
         if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]

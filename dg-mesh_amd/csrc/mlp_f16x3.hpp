@@ -834,4 +834,134 @@ mlp_dw3b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
         *reinterpret_cast<float2*>(partial_db + ((size_t)chunk * 2 + rg) * 256 + c2 * 2) = colsum;
 }
 
+// ---- weight gradient of the layers that consume the embedding (K = 96: layer 0; K = 352 = 96 | 256: the skip layer) --------
+// partial[chunk][k][j] = sum_{rows of chunk} [X1 | X2][row][k] * G[row][j]; same arithmetic and staging granules as
+// mlp_dw3b_kernel.  One 8-wave workgroup per chunk covers all MT * 32 x 256 outputs: wave w owns the 32 gradient columns
+// [32 w, 32 w + 32) against ALL MT * 32 input columns (one G fragment pair feeds 3 MT MFMAs; MT * 16 accumulator registers).
+// Stagers: thread t < MT * 16 carries two input columns, threads 256 .. 383 two gradient columns, sixteen rows each per stage.
+template <int MT>
+__global__ void __launch_bounds__(512)
+mlp_dw3e_kernel(int M, int rows_per_chunk, const float* __restrict__ X1, int ldx1, int K1, const float* __restrict__ X2, int ldx2,
+                const float* __restrict__ G, const unsigned* __restrict__ xmax1, const unsigned* __restrict__ xmax2,
+                const unsigned* __restrict__ gmax, float* __restrict__ partial, float* __restrict__ partial_db) {
+    constexpr int NX = MT * 32;   // input columns
+    constexpr int XU = 4 * NX;    // uint4 per X stage: [plane][row half][column]
+    extern __shared__ __attribute__((aligned(16))) uint4 dw3e_lds[];
+    uint4* Xs = dw3e_lds;                 // [2][XU]
+    uint4* Gs = dw3e_lds + 2 * XU;        // [2][DW3_U]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const int nst = (r1 - r0 + 15) >> 4;
+    const bool isX = tid < NX / 2, isG = tid >= 256 && tid < 384;
+    const bool stager = isX || isG;
+    const int c2 = isG ? tid - 256 : tid;  // column pair
+    const float* sp = G;
+    int sld = 256;
+    float sc0 = 0.f, sc1 = 0.f;
+    uint4* sdst0 = Gs;
+    if (stager) {
+        float unused;
+        const int col = 2 * c2;
+        if (isG) {
+            sp = G + col;
+            scale_from_max_bits(gmax[col], sc0, unused);
+            scale_from_max_bits(gmax[col + 1], sc1, unused);
+            sdst0 = Gs + col;
+        } else {
+            const bool first = col < K1;
+            sp = first ? X1 + col : X2 + (col - K1);
+            sld = first ? ldx1 : ldx2;
+            const unsigned* mx = first ? xmax1 + col : xmax2 + (col - K1);
+            scale_from_max_bits(mx[0], sc0, unused);
+            scale_from_max_bits(mx[1], sc1, unused);
+            sdst0 = Xs + col;
+        }
+    }
+    const int snc = isG ? 256 : NX;           // columns of the staged operand
+    const int sbuf = isG ? DW3_U : XU;        // uint4 per stage buffer
+    float2 v[16];
+    float2 colsum = make_float2(0.f, 0.f);
+
+#define DW3E_LOAD(st_)                                                                                \
+    if (stager) {                                                                                     \
+        const int rb_ = r0 + (st_) * 16;                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) {                                           \
+            v[i_] = make_float2(0.f, 0.f);                                                            \
+            if (rb_ + i_ < r1) v[i_] = *reinterpret_cast<const float2*>(sp + (size_t)(rb_ + i_) * sld); \
+        }                                                                                             \
+    }
+#define DW3E_STORE(buf_)                                                                              \
+    if (stager) {                                                                                     \
+        uint4* d_ = sdst0 + (buf_) * sbuf;                                                            \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                            \
+            uint4 H_, L_;                                                                             \
+            split2h(v[8 * h_ + 0].x * sc0, v[8 * h_ + 1].x * sc0, H_.x, L_.x);                        \
+            split2h(v[8 * h_ + 2].x * sc0, v[8 * h_ + 3].x * sc0, H_.y, L_.y);                        \
+            split2h(v[8 * h_ + 4].x * sc0, v[8 * h_ + 5].x * sc0, H_.z, L_.z);                        \
+            split2h(v[8 * h_ + 6].x * sc0, v[8 * h_ + 7].x * sc0, H_.w, L_.w);                        \
+            d_[h_ * snc] = H_, d_[2 * snc + h_ * snc] = L_;                                           \
+            split2h(v[8 * h_ + 0].y * sc1, v[8 * h_ + 1].y * sc1, H_.x, L_.x);                        \
+            split2h(v[8 * h_ + 2].y * sc1, v[8 * h_ + 3].y * sc1, H_.y, L_.y);                        \
+            split2h(v[8 * h_ + 4].y * sc1, v[8 * h_ + 5].y * sc1, H_.z, L_.z);                        \
+            split2h(v[8 * h_ + 6].y * sc1, v[8 * h_ + 7].y * sc1, H_.w, L_.w);                        \
+            d_[h_ * snc + 1] = H_, d_[2 * snc + h_ * snc + 1] = L_;                                   \
+        }                                                                                             \
+        if (isG) {                                                                                    \
+            _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) colsum.x += v[i_].x, colsum.y += v[i_].y; \
+        }                                                                                             \
+    }
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+
+    DW3E_LOAD(0)
+    DW3E_STORE(0)
+    if (nst > 1) DW3E_LOAD(1)
+    __syncthreads();
+    for (int st = 0; st < nst; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nst) {
+            DW3E_STORE(buf ^ 1)
+            if (st + 2 < nst) DW3E_LOAD(st + 2)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4* xs = Xs + buf * XU;
+        const uint4* gs = Gs + buf * DW3_U;
+        const int bi = g * 256 + wv * 32 + li;
+        const f16x8 gh = as_f16x8(gs[bi]), gl = as_f16x8(gs[512 + bi]);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int ai = g * NX + mt * 32 + li;
+            const f16x8 ah = as_f16x8(xs[ai]), al = as_f16x8(xs[2 * NX + ai]);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc[mt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef DW3E_LOAD
+#undef DW3E_STORE
+
+    float* out = partial + (size_t)chunk * NX * 256;
+    const int col = wv * 32 + li;
+    float sg, ig;
+    scale_from_max_bits(gmax[col], sg, ig);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int k = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            float sx, ix;
+            scale_from_max_bits(k < K1 ? xmax1[k] : xmax2[k - K1], sx, ix);
+            out[(size_t)k * 256 + col] = acc[mt][r] * (ix * ig);
+        }
+    }
+    if (isG && partial_db != nullptr) *reinterpret_cast<float2*>(partial_db + (size_t)chunk * 256 + c2 * 2) = colsum;
+}
+
 }  // namespace dgm
