@@ -81,37 +81,65 @@ __global__ void mlp_embed_kernel(int N, const float* __restrict__ x, const float
 
 // Column maxima of |emb| (float bits) -- the scales of the f16x3 weight gradients of the two layers that consume the
 // embedding -- without a pass over it: the sin / cos columns are bounded by 1, the x and time columns are reduced from their
-// sources (thread = one of the 3 + T source columns, sixteen rows per batch; one atomic per column and workgroup; cmax zeroed by the
-// caller).
+// sources.  Blocks [0, nbx): x read as a flat array, twelve floats (four rows) per thread in three coalesced 16-byte loads,
+// so a thread's float k is column k % 3; blocks [nbx, ..): the time embedding, thread = one of its T columns, sixteen rows
+// per batch (a broadcast time embedding is a single row).  One atomic per column and workgroup; cmax zeroed by the caller.
 __global__ void __launch_bounds__(256)
-mlp_embed_cmax_kernel(int N, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
+mlp_embed_cmax_kernel(int N, int nbx, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
                       unsigned* __restrict__ cmax) {
     __shared__ float smax[4][64];
-    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int nrows_t = temb_stride != 0 ? N : 1;  // a broadcast time embedding is a single row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if ((int)blockIdx.x < nbx) {
+        const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 12, tot = (size_t)N * 3;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        if (e0 + 12 <= tot && (((uintptr_t)x) & 15) == 0) {
+            const float4* p = reinterpret_cast<const float4*>(x + e0);
+            const float4 a = p[0], b = p[1], c = p[2];  // columns 0 1 2 0 | 1 2 0 1 | 2 0 1 2
+            m0 = fmaxf(fmaxf(fabsf(a.x), fabsf(a.w)), fmaxf(fabsf(b.z), fabsf(c.y)));
+            m1 = fmaxf(fmaxf(fabsf(a.y), fabsf(b.x)), fmaxf(fabsf(b.w), fabsf(c.z)));
+            m2 = fmaxf(fmaxf(fabsf(a.z), fabsf(b.y)), fmaxf(fabsf(c.x), fabsf(c.w)));
+        } else {
+            for (int i = 0; i < 12; i++) {
+                if (e0 + i < tot) {
+                    const float v = fabsf(x[e0 + i]);
+                    if (i % 3 == 0) m0 = fmaxf(m0, v);
+                    else if (i % 3 == 1) m1 = fmaxf(m1, v);
+                    else m2 = fmaxf(m2, v);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            m0 = fmaxf(m0, __shfl_xor(m0, d, 64)), m1 = fmaxf(m1, __shfl_xor(m1, d, 64)), m2 = fmaxf(m2, __shfl_xor(m2, d, 64));
+        }
+        if (lane == 0) smax[wv][0] = m0, smax[wv][1] = m1, smax[wv][2] = m2;
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int j = threadIdx.x;
+            atomicMax(cmax + j, __float_as_uint(fmaxf(fmaxf(smax[0][j], smax[1][j]), fmaxf(smax[2][j], smax[3][j]))));
+        }
+        if (blockIdx.x == 0 && threadIdx.x >= 3 && threadIdx.x < MLP_XE) cmax[threadIdx.x] = __float_as_uint(1.0f);
+        return;
+    }
+    const int nr = temb_stride != 0 ? N : 1;
+    const int tb = (int)blockIdx.x - nbx, ntb = (int)gridDim.x - nbx;
     float mx = 0.f;
-    if (j < 3 + T) {
-        const int nr = j < 3 ? N : nrows_t;
-        // sixteen rows per batch, all loads in flight at once; 128 workgroups stride over the rows
-        for (int rb = (blockIdx.x * 4 + slice) * 16; rb < nr; rb += gridDim.x * 64) {
+    if (lane < T) {
+        for (int rb = (tb * 4 + wv) * 16; rb < nr; rb += ntb * 64) {
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int r = rb + i;
                 v[i] = 0.f;
-                if (r < nr) v[i] = j < 3 ? x[3 * r + j] : temb[(size_t)r * temb_stride + (j - 3)];
+                if (rb + i < nr) v[i] = temb[(size_t)(rb + i) * temb_stride + lane];
             }
 #pragma unroll
             for (int i = 0; i < 16; i++) mx = fmaxf(mx, fabsf(v[i]));
         }
     }
-    smax[slice][j] = mx;
+    smax[wv][lane] = mx;
     __syncthreads();
-    if (slice == 0 && j < 3 + T) {
-        mx = fmaxf(fmaxf(smax[0][j], smax[1][j]), fmaxf(smax[2][j], smax[3][j]));
-        atomicMax(cmax + (j < 3 ? j : MLP_XE + (j - 3)), __float_as_uint(mx));
-    }
-    if (blockIdx.x == 0 && threadIdx.x >= 3 && threadIdx.x < MLP_XE) cmax[threadIdx.x] = __float_as_uint(1.0f);
+    if (wv == 0 && lane < T)
+        atomicMax(cmax + MLP_XE + lane, __float_as_uint(fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]))));
 }
 
 // ---- the 256-wide GEMM: C[M x 256] = [A1 | A2][M x (K1+K2)] * Bt[(K1+K2) x 256] ------------------------------------
@@ -893,8 +921,11 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         const size_t tot = (size_t)N * MLP_EMB;
         hipLaunchKernelGGL(mlp_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, x, temb, temb_stride,
                            p->t_dim, w.emb);
-        if (use_f16x3())
-            hipLaunchKernelGGL(mlp_embed_cmax_kernel, dim3(128), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.cmaxE);
+        if (use_f16x3()) {
+            const int nbx = (int)(((size_t)N * 3 + 3071) / 3072), nbt = temb_stride != 0 ? 256 : 1;
+            hipLaunchKernelGGL(mlp_embed_cmax_kernel, dim3(nbx + nbt), dim3(256), 0, st, N, nbx, x, temb, temb_stride, p->t_dim,
+                               w.cmaxE);
+        }
     }
     const int grid = (N + GM - 1) / GM;
     const int grid6 = (N + 127) / 128;
