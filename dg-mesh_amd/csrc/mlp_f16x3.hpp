@@ -746,9 +746,9 @@ mlp_dw3b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
 #define DW3_LOAD(st_)                                                                                 \
     {                                                                                                 \
         const int rb_ = r0 + (st_) * 16 + rg * 8;                                                     \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                            \
-            v[i_] = make_float2(0.f, 0.f);                                                            \
-            if (rb_ + i_ < r1) v[i_] = *reinterpret_cast<const float2*>(sp + (size_t)(rb_ + i_) * sld); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) { /* branch-free: rows past the chunk load its last row, then zero */ \
+            const float2 t_ = *reinterpret_cast<const float2*>(sp + (size_t)min(rb_ + i_, r1 - 1) * sld); \
+            v[i_] = rb_ + i_ < r1 ? t_ : make_float2(0.f, 0.f);                                       \
         }                                                                                             \
     }
 #define DW3_STORE(buf_)                                                                               \
@@ -808,7 +808,7 @@ mlp_dw3b_kernel(int M, int rows_per_chunk, const float* __restrict__ X, int ldx,
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], gh, acc[mt][nt], 0, 0, 0);
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the rows just prefetched
     }
 #undef DW3_LOAD
 #undef DW3_STORE
@@ -887,9 +887,9 @@ mlp_dw3e_kernel(int M, int rows_per_chunk, const float* __restrict__ X1, int ldx
 #define DW3E_LOAD(st_)                                                                                \
     if (stager) {                                                                                     \
         const int rb_ = r0 + (st_) * 16;                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) {                                           \
-            v[i_] = make_float2(0.f, 0.f);                                                            \
-            if (rb_ + i_ < r1) v[i_] = *reinterpret_cast<const float2*>(sp + (size_t)(rb_ + i_) * sld); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) { /* branch-free: rows past the chunk load its last row, then zero */ \
+            const float2 t_ = *reinterpret_cast<const float2*>(sp + (size_t)min(rb_ + i_, r1 - 1) * sld); \
+            v[i_] = rb_ + i_ < r1 ? t_ : make_float2(0.f, 0.f);                                       \
         }                                                                                             \
     }
 #define DW3E_STORE(buf_)                                                                              \
@@ -942,7 +942,7 @@ mlp_dw3e_kernel(int M, int rows_per_chunk, const float* __restrict__ X1, int ldx
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc[mt], 0, 0, 0);
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc[mt], 0, 0, 0);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the rows just prefetched
     }
 #undef DW3E_LOAD
 #undef DW3E_STORE
