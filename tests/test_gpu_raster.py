@@ -200,6 +200,23 @@ def test_big_tile_lists(orc, syn):
         assert np.array_equal(f_hip["ranges"], f_or["binning"]["ranges"])
 
 
+@pytest.mark.parametrize("P", [1024, 1025, 2048, 2049, 4096, 4097])
+def test_tile_list_class_boundaries(orc, syn, P):
+    """Segments of exactly the sizes at which the per-tile sort changes path (one workgroup per tile up to 2048 entries, the
+    512-thread worklist up to 4096, the bitonic network beyond): every Gaussian covers the whole 32 x 32 image."""
+    a = raster_args(syn, P, 32, 32, seed=13, kind="init", extent=0.4)
+    a["scales"] = (a["scales"] * 0 + 0.5).astype(np.float32)
+    a["opacities"] = (a["opacities"] * 0 + 0.004).astype(np.float32)
+    f_hip = G.hip_forward(a)
+    f_or = oracle_forward(orc, a)
+    n = f_or["binning"]["ranges"][:, 1] - f_or["binning"]["ranges"][:, 0]
+    assert n.max() >= P * 0.95
+    assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+    assert np.array_equal(f_hip["ranges"], f_or["binning"]["ranges"])
+    upos = f_hip["upos"]
+    assert np.array_equal(np.sort(upos), np.arange(f_or["num_rendered"], dtype=np.uint32))
+
+
 def test_depth_ties_sorted_by_index(orc, syn):
     """Equal depths: order must be ascending Gaussian index (what the reference's stable sort produces).  Three shapes of
     the tile sort's tie handling: one long run per tile in the one-workgroup-per-tile class and in the worklist class (both
