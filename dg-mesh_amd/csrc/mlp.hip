@@ -943,11 +943,10 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
             if (K1 + K2 == MLP_EMB + MLP_W && use_f16x3()) {
                 // skip layer, trunk half: Y5 = relu(Y4 * W5[:, emb:]^T + C_in), C_in = emb * W5[:, :emb]^T + b5 already in Y5
-                dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
+                // (not under the mlp_layer_fwd stage timer: it also reads C_in, 1.5x the bytes of a plain 256 -> 256 layer)
                 hipLaunchKernelGGL((mlp_gemm3p_kernel<2, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A2, lda2,
                                    w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l], (const float*)nullptr, w.mask[l], w.Y[l],
                                    w.cmaxY + l * MLP_W, (unsigned*)nullptr);
-                dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
             } else if (K1 + K2 == MLP_EMB + MLP_W) {  // skip layer: bf16x6, weights streamed through LDS
                 hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2,
                                    lda2, K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W);
