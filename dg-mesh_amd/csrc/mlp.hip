@@ -61,22 +61,36 @@ __global__ void mlp_prep_kernel(int in_features, int Kp, int emb_dim, int is_ski
 
 // ---- positional encoding -------------------------------------------------------------------------------------------
 // emb[r] = [x, sin(x 2^0), cos(x 2^0), ..., sin(x 2^9), cos(x 2^9) | t_emb[r] | 0...]   (time_utils.py:24-55)
-__global__ void mlp_embed_kernel(int N, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride,
-                                 int T, float* __restrict__ emb) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)N * MLP_EMB) return;
-    const int r = (int)(idx / MLP_EMB), c = (int)(idx % MLP_EMB);
-    float v = 0.f;
-    if (c < 3) {
-        v = x[3 * r + c];
-    } else if (c < MLP_XE) {
-        const int q = (c - 3) / 6, w = (c - 3) % 6;
-        const float arg = x[3 * r + (w % 3)] * (float)(1 << q);
-        v = w < 3 ? sinf(arg) : cosf(arg);
-    } else if (c < MLP_XE + T) {
-        v = temb[(size_t)r * temb_stride + (c - MLP_XE)];
+// One wave per TWO rows: lanes 0..59 evaluate sin AND cos of one (row, frequency, axis) triple with a single argument
+// reduction (sincosf; the kernel is VALU-bound -- 60 transcendentals per row); then the 64 lanes copy x, the time embedding and
+// the zero padding of both rows (36 columns each).
+__global__ void __launch_bounds__(256)
+mlp_embed_kernel(int N, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
+                 float* __restrict__ emb) {
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2, lane = threadIdx.x & 63;
+    if (r0 >= N) return;
+    if (lane < 60) {
+        const int sub = lane / 30, p = lane - 30 * sub, r = r0 + sub;
+        if (r < N) {
+            const int q = p / 3, a = p - 3 * q;
+            float sn, cs;
+            sincosf(x[3 * r + a] * (float)(1 << q), &sn, &cs);
+            float* e = emb + (size_t)r * MLP_EMB + 3 + 6 * q + a;
+            e[0] = sn;
+            e[3] = cs;
+        }
     }
-    emb[idx] = v;
+    constexpr int REST = 3 + (MLP_EMB - MLP_XE);  // x and everything behind the positional encoding
+    for (int i = lane; i < 2 * REST; i += 64) {
+        const int sub = i / REST, j = i - REST * sub, r = r0 + sub;
+        if (r >= N) continue;
+        float* e = emb + (size_t)r * MLP_EMB;
+        if (j < 3) e[j] = x[3 * r + j];
+        else {
+            const int t = j - 3;
+            e[MLP_XE + t] = t < T ? temb[(size_t)r * temb_stride + t] : 0.f;
+        }
+    }
 }
 
 // Column maxima of |emb| (float bits) -- the scales of the f16x3 weight gradients of the two layers that consume the
@@ -918,9 +932,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         }
     }
     {
-        const size_t tot = (size_t)N * MLP_EMB;
-        hipLaunchKernelGGL(mlp_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, x, temb, temb_stride,
-                           p->t_dim, w.emb);
+        hipLaunchKernelGGL(mlp_embed_kernel, dim3((N + 7) / 8), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.emb);
         if (use_f16x3()) {
             const int nbx = (int)(((size_t)N * 3 + 3071) / 3072), nbt = temb_stride != 0 ? 256 : 1;
             hipLaunchKernelGGL(mlp_embed_cmax_kernel, dim3(nbx + nbt), dim3(256), 0, st, N, nbx, x, temb, temb_stride, p->t_dim,
