@@ -126,25 +126,6 @@ __global__ void __launch_bounds__(256) mlp_prep3_batch_kernel(const Prep3Batch b
     dst[2 * j.ncols] = L;
 }
 
-// column maxima of |X| (N x ncols <= 256, row stride ld) for producers that do not deliver them:
-// out[col] = max(out[col], ..) as float bits (non-negative floats order like unsigned integers).  Thread = column,
-// eight rows in flight per thread, one atomic per column and workgroup.
-__global__ void __launch_bounds__(256) mlp_colmax_kernel(int N, int ncols, const float* __restrict__ X, int ld,
-                                                         unsigned* __restrict__ out) {
-    const int col = threadIdx.x;
-    if (col >= ncols) return;
-    float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int G = gridDim.x;
-    int r = blockIdx.x;
-    for (; r + 7 * G < N; r += 8 * G) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) m[u] = fmaxf(m[u], fabsf(X[(size_t)(r + u * G) * ld + col]));
-    }
-    for (; r < N; r += G) m[0] = fmaxf(m[0], fabsf(X[(size_t)r * ld + col]));
-    const float mm = fmaxf(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])), fmaxf(fmaxf(m[4], m[5]), fmaxf(m[6], m[7])));
-    atomicMax(out + col, __float_as_uint(mm));
-}
-
 // ---- the trunk-layer GEMM, weights stationary in registers -------------------------------------------------------------
 // C[M x 256] = [A1 | A2] * B with K = KS * 16 (A1: first K1 columns, A2 the rest).
 //   EPI 0: C = relu(acc + bias), ReLU mask bits saved (mask[row][col / 32] bit col % 32)
