@@ -510,7 +510,7 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
     float4 R[2][4];     // rows of tile t live in R[t & 1]
     unsigned mw[2] = {0u, 0u};  // EPI 1: mask word (row li of the tile, this wave's column group) of tile t in mw[t & 1]
 
-#define P3_TILE(j_) min(blockIdx.x + (j_) * G, last_tile)
+#define P3_TILE(j_) min((int)blockIdx.x + (j_) * G, last_tile)  /* int on both sides: a mixed unsigned / int min() resolves to the double overload */
 #define P3_LOAD(slot_, tile_)                                                                                          \
     {                                                                                                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                             \
