@@ -482,6 +482,7 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
                   const float* __restrict__ b_inv_scale, const float* __restrict__ bias, unsigned* __restrict__ mask,
                   float* __restrict__ C, unsigned* __restrict__ colmax, unsigned* __restrict__ colmax_in) {
     constexpr int KS = 16, K = 256, RS = 4 * K + 16, PLANE = 2 * K;
+    constexpr int G3P_PD = 1;  // fragment prefetch distance in K steps (2 measured: no gain, 14 more registers)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ps = smem;                                          // [2][32][RS]
     float* rinv = reinterpret_cast<float*>(smem + 2 * 32 * RS);        // [2][32] inverse row scales
@@ -583,20 +584,24 @@ mlp_gemm3p_kernel(int M, int ntiles, const float* __restrict__ A, int lda, const
         unsigned mwsel = 0u;                                                                                           \
         const unsigned* mlp_ = mlds + (1 - pb) * 256 + wv * 32 + 4 * g; /* previous tile's mask words */               \
         float m_[4], sc_[4];                                                                                           \
-        f16x8 fh_[2], fl_[2]; /* fragments one K step ahead (the slices between the MFMAs cover the LDS latency) */      \
-        fh_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_));                                                       \
-        fl_[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE));                                               \
+        /* fragments PD_ K steps ahead (the slices between the MFMAs cover the LDS latency)                               */ \
+        constexpr int PD_ = G3P_PD;                                                                                    \
+        f16x8 fh_[PD_ + 1], fl_[PD_ + 1];                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < PD_; i_++) {                                                           \
+            fh_[i_] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + i_ * 32));                                        \
+            fl_[i_] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + i_ * 32));                                \
+        }                                                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < KS; ks++) {                                                            \
-            if (ks + 1 < KS) {                                                                                         \
-                fh_[(ks + 1) & 1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (ks + 1) * 32));                    \
-                fl_[(ks + 1) & 1] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (ks + 1) * 32));            \
+            if (ks + PD_ < KS) {                                                                                       \
+                fh_[(ks + PD_) % (PD_ + 1)] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + (ks + PD_) * 32));        \
+                fl_[(ks + PD_) % (PD_ + 1)] = as_f16x8(*reinterpret_cast<const uint4*>(ps_ + PLANE + (ks + PD_) * 32)); \
             }                                                                                                          \
             /* one accumulator chain: the VALU slices between the MFMAs cover the dependent-issue latency, and the */   \
             /* second chain's 16 registers are what keeps this kernel out of scratch                                */   \
             if (ks == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[0], bl[0], zero16, 0, 0, 0);                 \
-            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks & 1], bl[ks], acc, 0, 0, 0);                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks & 1], bh[ks], acc, 0, 0, 0);                           \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks & 1], bh[ks], acc, 0, 0, 0);                           \
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % (PD_ + 1)], bl[ks], acc, 0, 0, 0);              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl_[ks % (PD_ + 1)], bh[ks], acc, 0, 0, 0);                   \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh_[ks % (PD_ + 1)], bh[ks], acc, 0, 0, 0);                   \
             if (!(FIRST_) && ks < 8) {                                                                                 \
                 P3_STORE_REG(2 * ks)                                                                                   \
                 P3_STORE_REG(2 * ks + 1)                                                                               \
