@@ -574,53 +574,48 @@ mlp_heads_bwd_kernel(int N, int NC, const float* __restrict__ dOut, const float*
     if (c < 16) partial_b[(size_t)chunk * 16 + c] = ((sB[0][c] + sB[1][c]) + sB[2][c]) + sB[3][c];
 }
 
-__global__ void mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W,
-                                        const float* __restrict__ partial_b, float* __restrict__ dWh,
-                                        float* __restrict__ dbh) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < NC * MLP_W) {
-        const int o = idx / MLP_W, c = idx % MLP_W;
-        float sp[16];  // sixteen loads in flight per thread; fixed summation order
-#pragma unroll
-        for (int u = 0; u < 16; u++) sp[u] = 0.f;
-        int k = 0;
-        for (; k + 16 <= chunks; k += 16) {
-#pragma unroll
-            for (int u = 0; u < 16; u++) sp[u] += partial_W[((size_t)(k + u) * 16 + o) * MLP_W + c];
-        }
-        for (; k < chunks; k++) sp[0] += partial_W[((size_t)k * 16 + o) * MLP_W + c];
-#pragma unroll
-        for (int u = 8; u >= 1; u >>= 1)
-#pragma unroll
-            for (int v = 0; v < u; v++) sp[v] += sp[v + u];
-        const float s = sp[0];
-        dWh[idx] = s;
-    }
-}
-
-// dbh[o] = sum_chunks partial_b[chunk][o]   (one workgroup: strided partial sums, then an LDS tree)
+// dWh[o][c] = sum_chunks partial_W[chunk][o][c], dbh[o] = sum_chunks partial_b[chunk][o].  Grid (8 column blocks, n_out):
+// a workgroup owns 32 columns of one output row as 8 float4 positions x 32 chunk groups (a wave instruction reads 128 contiguous
+// bytes of eight chunks), group sums meet in LDS in a fixed order; the first column block of each row also reduces its bias.
 __global__ void __launch_bounds__(256)
-mlp_reduce_bias16_kernel(int chunks, int NC, const float* __restrict__ partial_b, float* __restrict__ dbh) {
-    __shared__ float red[256][17];
-    float a[16];
-#pragma unroll
-    for (int o = 0; o < 16; o++) a[o] = 0.f;
-    for (int k = threadIdx.x; k < chunks; k += 256) {
-        const float4* p4 = reinterpret_cast<const float4*>(partial_b + (size_t)k * 16);
-        const float4 v0 = p4[0], v1 = p4[1], v2 = p4[2], v3 = p4[3];
-        a[0] += v0.x, a[1] += v0.y, a[2] += v0.z, a[3] += v0.w, a[4] += v1.x, a[5] += v1.y, a[6] += v1.z, a[7] += v1.w;
-        a[8] += v2.x, a[9] += v2.y, a[10] += v2.z, a[11] += v2.w, a[12] += v3.x, a[13] += v3.y, a[14] += v3.z, a[15] += v3.w;
+mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W, const float* __restrict__ partial_b,
+                        float* __restrict__ dWh, float* __restrict__ dbh) {
+    __shared__ float4 red[32][8];
+    __shared__ float redb[256];
+    const int tid = threadIdx.x, pos = tid & 7, grp = tid >> 3;
+    const int o = blockIdx.y, c0 = blockIdx.x * 32 + pos * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = partial_W + (size_t)o * MLP_W + c0;
+    int k = grp;
+    for (; k + 96 < chunks; k += 128) {  // four loads in flight
+        const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)k * 16 * MLP_W);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(k + 32) * 16 * MLP_W);
+        const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(k + 64) * 16 * MLP_W);
+        const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(k + 96) * 16 * MLP_W);
+        s.x += (v0.x + v1.x) + (v2.x + v3.x), s.y += (v0.y + v1.y) + (v2.y + v3.y);
+        s.z += (v0.z + v1.z) + (v2.z + v3.z), s.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-#pragma unroll
-    for (int o = 0; o < 16; o++) red[threadIdx.x][o] = a[o];
+    for (; k < chunks; k += 32) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * 16 * MLP_W);
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    red[grp][pos] = s;
+    float sb = 0.f;
+    if (blockIdx.x == 0)
+        for (int c = tid; c < chunks; c += 256) sb += partial_b[(size_t)c * 16 + o];
+    redb[tid] = sb;
     __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off)
-#pragma unroll
-            for (int o = 0; o < 16; o++) red[threadIdx.x][o] += red[threadIdx.x + off][o];
-        __syncthreads();
+    if (tid < 8) {
+        float4 t = red[0][tid];
+        for (int g = 1; g < 32; g++) t.x += red[g][tid].x, t.y += red[g][tid].y, t.z += red[g][tid].z, t.w += red[g][tid].w;
+        *reinterpret_cast<float4*>(dWh + (size_t)o * MLP_W + blockIdx.x * 32 + tid * 4) = t;
     }
-    if ((int)threadIdx.x < NC) dbh[threadIdx.x] = red[0][threadIdx.x];
+    if (blockIdx.x == 0 && tid == 8) {
+        float t = 0.f;
+        for (int i = 0; i < 256; i++) t += redb[i];
+        dbh[o] = t;
+    }
+    (void)NC;
 }
 
 // broadcast t: dtemb[c] = sum_j db0[j] W0[j][63+c] + db5[j] W5[j][63+c]   (one 256-thread block per column c)
@@ -827,10 +822,12 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.wsc_f[l] = take(MLP_W * 4);
     for (int l = 0; l < 8; l++) w.wsc_d[l] = take(MLP_W * 4);
     w.wsc_e = take(MLP_W * 4);
-    w.cmaxY = (unsigned*)take(9 * MLP_W * 4);
+    // one block, cleared by ONE fill at the start of the forward pass (the backward pass of a network always follows its own
+    // forward pass on the same workspace): cmaxY [8] | cmaxE [1] | cmaxG [8] | cmaxW [PREP3_MAX_JOBS], 256 words each
+    w.cmaxY = (unsigned*)take((9 + 8 + PREP3_MAX_JOBS) * MLP_W * 4);
     w.cmaxE = w.cmaxY + 8 * MLP_W;
-    w.cmaxG = (unsigned*)take(8 * MLP_W * 4);
-    w.cmaxW = (unsigned*)take(PREP3_MAX_JOBS * MLP_W * 4);
+    w.cmaxG = w.cmaxY + 9 * MLP_W;
+    w.cmaxW = w.cmaxY + 17 * MLP_W;
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     w.partial_h = take((size_t)hchunks * 16 * MLP_W * 4);
     w.partial_hb = take((size_t)hchunks * 16 * 4);
@@ -922,8 +919,9 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         add(0, MLP_W, 32, MLP_W, 0, 0, p->n_out, p->Wh, w.Wh6f);
         hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
         if (n3 > 0) {
-            // cmaxY | cmaxG | cmaxW are adjacent in the workspace: one fill clears the forward's two
-            if (hipMemsetAsync(w.cmaxY, 0, 9 * MLP_W * 4, st) != hipSuccess || hipMemsetAsync(w.cmaxW, 0, PREP3_MAX_JOBS * MLP_W * 4, st) != hipSuccess)
+            // cmaxY | cmaxE | cmaxG | cmaxW are one block: one fill clears the maxima of this forward AND its backward pass
+            // (a repeated backward pass finds maxima that are at least as large: still valid scales)
+            if (hipMemsetAsync(w.cmaxY, 0, (9 + 8 + PREP3_MAX_JOBS) * MLP_W * 4, st) != hipSuccess)
                 return mlp_fail("mlp_forward: memset failed");
             const int pthreads = (MLP_EMB + MLP_W) / 8 * MLP_W;
             hipLaunchKernelGGL(mlp_prep3_max_kernel, dim3((pthreads + 255) / 256, n3), dim3(256), 0, st, p3, w.cmaxW);
@@ -1014,13 +1012,12 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, p->Wh, w.Y[7], w.Ga,
                        w.partial_h, w.partial_hb);
     const bool x3 = use_f16x3();
-    if (x3) {  // column maxima of the G_l for the weight gradients' scales: accumulated by the backward-data GEMMs
-        if (hipMemsetAsync(w.cmaxG, 0, 8 * MLP_W * 4, st) != hipSuccess) return mlp_fail("mlp_backward: memset failed");
+    if (x3) {  // (the column maxima of the G_l for the weight gradients' scales, accumulated by the backward-data GEMMs, were
+               // cleared by the forward pass)
         if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
     }
-    hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3((p->n_out * MLP_W + 255) / 256), dim3(256), 0, st, hchunks, p->n_out,
-                       w.partial_h, w.partial_hb, dWh, dbh);
-    hipLaunchKernelGGL(mlp_reduce_bias16_kernel, dim3(1), dim3(256), 0, st, hchunks, p->n_out, w.partial_hb, dbh);
+    hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3(8, p->n_out), dim3(256), 0, st, hchunks, p->n_out, w.partial_h, w.partial_hb,
+                       dWh, dbh);
     float* G = w.Ga;
     float* Gn = w.Gb;
     const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
