@@ -19,15 +19,20 @@ namespace dgm {
 static constexpr int LT = 16, LH = 5, LR = LT + 2 * LH;  // tile, halo, haloed tile edge (26)
 static constexpr int LP = LR + 1;                        // LDS row pitch
 
-__device__ __forceinline__ void gauss11(float* w) {  // R/utils/loss_utils.py:32-34
+// the 11-tap window (R/utils/loss_utils.py:32-34), evaluated once on the host and passed BY VALUE: the taps sit in scalar
+// registers for the whole kernel instead of being recomputed (11 expf and the normalisation) by every thread
+struct Gauss11 {
+    float w[11];
+};
+static Gauss11 gauss11_host() {
+    Gauss11 g;
     float s = 0.f;
-#pragma unroll
     for (int k = 0; k < 11; k++) {
-        w[k] = expf(-(float)((k - 5) * (k - 5)) / (2.0f * 1.5f * 1.5f));
-        s += w[k];
+        g.w[k] = expf(-(float)((k - 5) * (k - 5)) / (2.0f * 1.5f * 1.5f));
+        s += g.w[k];
     }
-#pragma unroll
-    for (int k = 0; k < 11; k++) w[k] /= s;
+    for (int k = 0; k < 11; k++) g.w[k] /= s;
+    return g;
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
@@ -40,13 +45,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 __global__ void __launch_bounds__(256)
-loss_fwd_kernel(const float* __restrict__ I, const float* __restrict__ G, int H, int W, float* __restrict__ a1,
+loss_fwd_kernel(const Gauss11 gw, const float* __restrict__ I, const float* __restrict__ G, int H, int W, float* __restrict__ a1,
                 float* __restrict__ a11, float* __restrict__ a12, float* __restrict__ partial) {
     __shared__ float sI[LR * LP], sG[LR * LP];
     __shared__ float hq[5][LR * LT];
     __shared__ float red[4];
-    float w[11];
-    gauss11(w);
+    const float* w = gw.w;
     const int ch = blockIdx.z;
     const size_t plane = (size_t)H * W;
     const float* Ic = I + ch * plane;
@@ -136,13 +140,12 @@ loss_reduce_kernel(int nblocks, const float* __restrict__ partial, float inv_n, 
 }
 
 __global__ void __launch_bounds__(256)
-loss_bwd_kernel(const float* __restrict__ I, const float* __restrict__ G, const float* __restrict__ a1,
+loss_bwd_kernel(const Gauss11 gw, const float* __restrict__ I, const float* __restrict__ G, const float* __restrict__ a1,
                 const float* __restrict__ a11, const float* __restrict__ a12, int H, int W, float inv_n, float lambda,
                 const float* __restrict__ gout, float* __restrict__ dI) {
     __shared__ float sA[3][LR * LP];
     __shared__ float hq[3][LR * LT];
-    float w[11];
-    gauss11(w);
+    const float* w = gw.w;
     const int ch = blockIdx.z;
     const size_t plane = (size_t)H * W;
     const int x0 = blockIdx.x * LT - LH, y0 = blockIdx.y * LT - LH;
@@ -219,7 +222,7 @@ int dgm_image_loss_forward(const float* image, const float* gt, int channels, in
     float* a12 = (float*)(p + 2 * align_up(n * 4, 256));
     float* partial = (float*)(p + 3 * align_up(n * 4, 256));
     dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, channels);
-    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, st, image, gt, H, W, a1, a11, a12, partial);
+    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, st, gauss11_host(), image, gt, H, W, a1, a11, a12, partial);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (int)(grid.x * grid.y * grid.z), partial,
                        1.0f / (float)n, lambda_dssim, out);
     hipError_t e = hipGetLastError();
@@ -244,7 +247,7 @@ int dgm_image_loss_backward(const float* image, const float* gt, int channels, i
     const float* a11 = (const float*)(p + align_up(n * 4, 256));
     const float* a12 = (const float*)(p + 2 * align_up(n * 4, 256));
     dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, channels);
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, st, image, gt, a1, a11, a12, H, W, 1.0f / (float)n, lambda_dssim,
+    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, st, gauss11_host(), image, gt, a1, a11, a12, H, W, 1.0f / (float)n, lambda_dssim,
                        grad_out, d_image);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
