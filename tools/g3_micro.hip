@@ -8,6 +8,7 @@
 #include "mlp_f16x3.hpp"
 namespace dgm {
 #include "exp/g3_kernel.inc"
+#include "exp/g3p_kernel.inc"
 }
 using namespace dgm;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -50,6 +51,25 @@ float run_p(int M, int ncu, const float* A, const uint4* Bp, const float* binv, 
     return ms / 20 * 1000.f;
 }
 
+template <int EPI, int VAR>
+float run_pv(int M, int ncu, const float* A, const uint4* Bp, const float* binv, const float* bias, unsigned* mask, float* C, unsigned* cmax) {
+    const int nt = (M + 31) / 32, gx = nt < ncu ? nt : ncu;
+    const int lds = 2 * 32 * (4 * 256 + 16) + 256 + 2048;
+    hipFuncSetAttribute((const void*)g3p_kernel<EPI, false, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    for (int i = 0; i < 3; i++)
+        hipLaunchKernelGGL((g3p_kernel<EPI, false, VAR>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax, (unsigned*)nullptr);
+    hipEventRecord(a);
+    for (int i = 0; i < 20; i++)
+        hipLaunchKernelGGL((g3p_kernel<EPI, false, VAR>), dim3(gx), dim3(512), lds, 0, M, nt, A, 256, Bp, binv, bias, mask, C, cmax, (unsigned*)nullptr);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / 20 * 1000.f;
+}
+
 int main() {
     const int M = 100000;
     int ncu = 256;
@@ -76,6 +96,30 @@ int main() {
 #define RUN(E, V, what) printf("EPI %d VAR %2d %-40s %8.1f\n", E, V, what, run<E, V>(M, ncu, A, Bp, binv, bias, mask, C, cmax));
     printf("product mlp_gemm3p_kernel<0> (software-pipelined)   %8.1f\n", run_p<0>(M, ncu, A, Bp, binv, bias, mask, C, cmax));
     printf("product mlp_gemm3p_kernel<1>                         %8.1f\n", run_p<1>(M, ncu, A, Bp, binv, bias, mask, C, cmax));
+#define RUNP(E, V, what) printf("gemm3p EPI %d VAR %2d %-40s %8.1f\n", E, V, what, run_pv<E, V>(M, ncu, A, Bp, binv, bias, mask, C, cmax));
+    RUNP(0, 0, "full (instrumented copy)")
+    RUNP(0, 1, "no MFMA")
+    RUNP(0, 2, "no stores")
+    RUNP(0, 8, "no loads")
+    RUNP(0, 3, "no MFMA, no stores")
+    RUNP(0, 9, "no MFMA, no loads")
+    RUNP(0, 10, "no stores, no loads")
+    RUNP(0, 11, "no MFMA / stores / loads (VALU + LDS skeleton)")
+    RUNP(0, 32, "no epilogue / maxima / split (MFMA + frag reads)")
+    RUNP(0, 33, "no epilogue/split, no MFMA (frag reads + barrier)")
+    RUNP(0, 96, "no epilogue/split, no frag reads (MFMA only)")
+    RUNP(0, 64, "no frag reads")
+    RUNP(0, 65, "no frag reads, no MFMA (VALU skeleton w/o LDS reads)")
+    RUNP(1, 0, "bwd full")
+    RUNP(1, 1, "bwd no MFMA")
+    {
+        run_pv<0, 16>(M, ncu, A, Bp, binv, bias, mask, C, cmax);
+        unsigned long long hd[16];
+        CK(hipMemcpy(hd, cmax + 256, 128, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 2; w++)
+            printf("gemm3p timing wave %d (%llu tiles): steps 0-7 (epilogue) %llu  step 8 (wait+loads+rowmax) %llu  steps 9-15 (scales+split) %llu  unscale+barrier %llu  cycles per tile\n",
+                   w * 4, hd[w * 8 + 5], hd[w * 8 + 0] / hd[w * 8 + 5], hd[w * 8 + 1] / hd[w * 8 + 5], hd[w * 8 + 2] / hd[w * 8 + 5], hd[w * 8 + 3] / hd[w * 8 + 5]);
+    }
     if (getenv("G3_ONLY_P")) return 0;
     RUN(0, 0, "full")
     RUN(0, 1, "no MFMA")
