@@ -22,9 +22,11 @@ def rep(text, a, b, n=1):
 
 
 kern = rep(kern, "template <int EPI, bool CMAX_IN>\n__global__", "template <int EPI, bool CMAX_IN, int VAR>\n__global__")
+kern = ("#define ACC2_ZERO acc2 = zero16;\n" if "acc2" in kern else "#define ACC2_ZERO\n") + kern
 kern = rep(kern, "mlp_gemm3p_kernel(", "g3p_kernel(")
-kern = rep(kern, "    f32x16 acc, out;\n",
-           "    f32x16 acc, out;\n    unsigned long long tm_[4] = {0, 0, 0, 0}, t0_ = 0;\n"
+decl = "    f32x16 acc, acc2, out;\n" if "f32x16 acc, acc2, out;" in kern else "    f32x16 acc, out;\n"
+kern = rep(kern, decl,
+           decl + "    unsigned long long tm_[4] = {0, 0, 0, 0}, t0_ = 0;\n"
            "#define TT(i_) if (VAR & 16) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = "
            "__builtin_amdgcn_s_memtime(); tm_[i_] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); }\n")
 # loads
@@ -35,13 +37,13 @@ kern = rep(kern, line("            R[slot_][r_] = *reinterpret_cast<const float4
 kern = rep(kern, line("        cb[ro_ * 256] = v_;"), line("        if (!(VAR & 2) || v_ == 1234.5f) cb[ro_ * 256] = v_;"))
 # MFMA
 mf = [l for l in kern.split("\n") if "__builtin_amdgcn_mfma_f32_32x32x16_f16" in l]
-assert len(mf) == 4, len(mf)
+assert len(mf) in (3, 4), len(mf)
 lines_ = kern.split("\n")
 i0 = lines_.index(mf[0])
 i1 = lines_.index(mf[-1])
 block = "\n".join(lines_[i0:i1 + 1]) + "\n"
 kern = rep(kern, block, line("            if (!(VAR & 1)) {") + block +
-           line('            } else { if (ks == 0) acc = zero16; asm volatile("" ::"v"(fh_[ks % (PD_ + 1)]), "v"(fl_[ks % (PD_ + 1)])); }'))
+           line('            } else { if (ks == 0) { acc = zero16; ACC2_ZERO } asm volatile("" ::"v"(fh_[ks % (PD_ + 1)]), "v"(fl_[ks % (PD_ + 1)])); }'))
 # stamps
 kern = rep(kern, line("            if (ks + PD_ < KS) {"), line("            if (ks == 8) TT(0)") + line("            if (ks + PD_ < KS) {"))
 kern = rep(kern, line("            if (ks == 9) wave_max4_stage_a(m_[0], m_[1], m_[2], m_[3]);"),
