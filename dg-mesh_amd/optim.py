@@ -38,8 +38,9 @@ class MultiAdam:
         return s
 
     def _plan(self):
-        """Everything that only changes when the parameter set does (pointers of parameters and moments, sizes, grouping by
-        hyper-parameters) is gathered once and reused; only gradients, learning rates and step counts are per call."""
+        """Everything that only changes when the parameter set does is gathered once per parameter set and reused: the grouping
+        by hyper-parameters, the state slots, the ctypes argument arrays with the pointers of parameters and moments and the
+        sizes already filled in.  Per call only gradients, learning rates and step counts are written."""
         sig = tuple(id(p) for o in self.optimizers for g in o.param_groups for p in g["params"])
         if getattr(self, "_sig", None) == sig:
             return self._cached
@@ -49,42 +50,68 @@ class MultiAdam:
                 key = (float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
                 for p in g["params"]:
                     by_hyper.setdefault(key, []).append((o, g, p))
-        self._sig, self._cached = sig, by_hyper
-        return by_hyper
+        plans = []
+        for key, entries in by_hyper.items():
+            n = len(entries)
+            VP = ctypes.c_void_p * n
+            plans.append(dict(key=key, entries=entries, n=n, slots=[None] * n, mom=[None] * n, P=VP(), G=VP(), M=VP(), V=VP(),
+                              N=(ctypes.c_longlong * n)(), LR=(ctypes.c_float * n)(), ST=(ctypes.c_int * n)(), dense=False))
+        self._sig, self._cached = sig, plans
+        return plans
+
+    def _bind(self, pl, i):
+        """(Re)binds entry i of a plan to its parameter's current state tensors; returns the state slot."""
+        o, g, p = pl["entries"][i]
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+            raise ValueError("MultiAdam: parameters must be contiguous fp32 device tensors")
+        s = self._slot(o, p)
+        if not (s["exp_avg"].is_contiguous() and s["exp_avg_sq"].is_contiguous()):
+            s["exp_avg"], s["exp_avg_sq"] = s["exp_avg"].contiguous(), s["exp_avg_sq"].contiguous()
+        if not (torch.is_tensor(s["step"]) and not s["step"].is_cuda):
+            s["step"] = torch.tensor(float(s["step"]))  # a host scalar tensor, as torch.optim.Adam keeps it
+        pl["slots"][i], pl["mom"][i] = s, (s["exp_avg"], s["exp_avg_sq"], s["step"])
+        return s
 
     @torch.no_grad()
     def step(self, grads=None):
         """grads: optional dict id(param) -> gradient tensor overriding param.grad (e.g. views of a reduced bucket)."""
         L = _lib.lib()
         stream = None
-        for (b1, b2, eps), entries in self._plan().items():
-            P, G, M, V, N, LR, ST = [], [], [], [], [], [], []
-            for o, g, p in entries:
+        for pl in self._plan():
+            entries, slots, mom = pl["entries"], pl["slots"], pl["mom"]
+            P, G, M, V, N, LR, ST = pl["P"], pl["G"], pl["M"], pl["V"], pl["N"], pl["LR"], pl["ST"]
+            k = 0
+            keep = []  # gradient tensors made contiguous for this call
+            steps = []
+            for i, (o, g, p) in enumerate(entries):
                 gr = grads.get(id(p)) if grads is not None else p.grad
                 if gr is None:
                     continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                    raise ValueError("MultiAdam: parameters must be contiguous fp32 device tensors")
                 if gr.dtype != torch.float32 or gr.shape != p.shape:
                     raise ValueError("MultiAdam: gradient / parameter mismatch")
-                gr = gr if gr.is_contiguous() else gr.contiguous()
-                s = self._slot(o, p)
-                if not (s["exp_avg"].is_contiguous() and s["exp_avg_sq"].is_contiguous()):
-                    s["exp_avg"], s["exp_avg_sq"] = s["exp_avg"].contiguous(), s["exp_avg_sq"].contiguous()
-                step = int(s["step"]) + 1  # a host scalar tensor, as torch.optim.Adam keeps it
-                if torch.is_tensor(s["step"]) and not s["step"].is_cuda:
-                    s["step"].fill_(float(step))
-                else:
-                    s["step"] = torch.tensor(float(step))
-                P.append(p.data_ptr()), G.append(gr.data_ptr()), M.append(s["exp_avg"].data_ptr()), V.append(s["exp_avg_sq"].data_ptr())
-                N.append(p.numel()), LR.append(float(g["lr"])), ST.append(step)
-            n = len(P)
-            if n == 0:
+                if not gr.is_contiguous():
+                    gr = gr.contiguous()
+                    keep.append(gr)
+                s = slots[i]
+                st = o.state.get(p)
+                # the state dict entry, its moment tensors and its step tensor must still be the ones bound last time
+                # (optimizer surgery on an unchanged Parameter, load_state_dict ...): otherwise bind again
+                if s is None or st is not s or s.get("exp_avg") is not mom[i][0] or s.get("exp_avg_sq") is not mom[i][1] \
+                        or s.get("step") is not mom[i][2] or k != i or not pl["dense"]:
+                    s = self._bind(pl, i)
+                    P[k], M[k], V[k], N[k] = p.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel()
+                G[k], LR[k] = gr.data_ptr(), float(g["lr"])
+                stp = mom[i][2]
+                ST[k] = int(stp) + 1
+                steps.append(stp)
+                k += 1
+            pl["dense"] = k == pl["n"]  # the cached pointer arrays are valid as long as every entry takes part
+            if k == 0:
                 continue
-            VP = ctypes.c_void_p * n
+            torch._foreach_add_(steps, 1.0)
             if stream is None:
                 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            rc = L.dgm_adam_step(n, VP(*P), VP(*G), VP(*M), VP(*V), (ctypes.c_longlong * n)(*N), (ctypes.c_float * n)(*LR),
-                                 (ctypes.c_int * n)(*ST), b1, b2, eps, stream)
+            b1, b2, eps = pl["key"]
+            rc = L.dgm_adam_step(k, P, G, M, V, N, LR, ST, b1, b2, eps, stream)
             if rc != 0:
                 raise RuntimeError(L.dgm_last_error().decode())
