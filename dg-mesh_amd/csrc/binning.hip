@@ -15,9 +15,9 @@
 //   3. scatter : same chunk workgroups, LDS cursors initialised to (tile start + chunk prefix), each
 //                instance takes a slot with one LDS atomic and writes its 16-byte record
 //                (gaussian, depth bits, position in the per-Gaussian order) straight into its tile segment;
-//   4. sort    : one workgroup per tile sorts its segment in LDS -- an LSD radix sort on the depth bits with an index
-//                tie-break for segments up to 4096 entries, a normalised bitonic network on the 64-bit keys beyond that;
-//                both give the same order whatever the atomic arrival order was -- and emits point_list plus
+//   4. sort    : one workgroup per tile sorts its segment -- an LSD radix sort on the depth bits with an index tie-break, pairs in
+//                registers / LDS for segments up to 4096 entries, in global memory (L2) beyond that; the result does not
+//                depend on the atomic arrival order -- and emits point_list plus
 //                upos[slot] = offs[g]+k, the instance's position in the per-Gaussian order (backward rows).
 // Wave-cooperative rectangle expansion: a wave loads 64 Gaussians, then iterates over the lanes that own a
 // non-empty rectangle (scalar bit loop on the ballot mask) and lets all 64 lanes cover that rectangle's
@@ -27,6 +27,7 @@
 namespace dgm {
 
 static constexpr int kRadixCap = 2048;  // longest tile segment the one-workgroup-per-tile radix sort takes (256 threads x 8)
+static constexpr int kBigLds = 8192;    // longest segment whose (key, payload) pairs ping-pong in LDS (2 x 64 KB) in the big path
 
 // ---- generic single-workgroup exclusive scan of n u32 (n up to a few 100k) --------------------------------
 __global__ void __launch_bounds__(1024)
@@ -196,61 +197,6 @@ scatter_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restric
 }
 
 // ---- per-tile sort ------------------------------------------------------------------------------------------
-// Normalised bitonic network (every compare-exchange moves the minimum to the lower index), so elements
-// beyond n behave as +inf without being stored.  Pair p of a stage with half-block h: j = p mod h,
-// lo = 2(p - j) + j ; flip stage partner = lo's block end mirrored, disperse stage partner = lo + h.
-#define DGM_CEX(lo_, hi_)                                  \
-    if ((hi_) < n) {                                       \
-        const unsigned long long a_ = s[lo_], c_ = s[hi_]; \
-        if (a_ > c_) {                                     \
-            s[lo_] = c_;                                   \
-            s[hi_] = a_;                                   \
-        }                                                  \
-    }
-
-template <int THREADS, bool GLOBAL>
-__device__ __forceinline__ void bitonic_sort(unsigned long long* s, int n) {
-    int N = 1;
-    while (N < n) N <<= 1;
-    const int half = N >> 1;
-    for (int k = 2; k <= N; k <<= 1) {
-        const int hk = k >> 1;
-        for (int p = threadIdx.x; p < half; p += THREADS) {
-            const int j = p & (hk - 1);
-            const int blk = (p - j) << 1;
-            const int lo = blk + j, hi = blk + k - 1 - j;
-            DGM_CEX(lo, hi)
-        }
-        if (GLOBAL) __threadfence_block();
-        __syncthreads();
-        for (int h = k >> 2; h >= 1; h >>= 1) {
-            for (int p = threadIdx.x; p < half; p += THREADS) {
-                const int j = p & (h - 1);
-                const int lo = ((p - j) << 1) + j, hi = lo + h;
-                DGM_CEX(lo, hi)
-            }
-            if (GLOBAL) __threadfence_block();
-            __syncthreads();
-        }
-    }
-}
-#undef DGM_CEX
-
-__device__ __forceinline__ void emit_sorted(const unsigned long long* s, int n, unsigned r0, int tile, int gridx,
-                                            const float* __restrict__ rec, unsigned* __restrict__ point_list,
-                                            unsigned* __restrict__ upos, int threads) {
-    const unsigned tx = (unsigned)(tile % gridx), ty = (unsigned)(tile / gridx);
-    for (int i = threadIdx.x; i < n; i += threads) {
-        const unsigned g = (unsigned)s[i];
-        point_list[r0 + i] = g;
-        const float4 r2 = reinterpret_cast<const float4*>(rec + (size_t)g * DGM_REC_STRIDE)[2];
-        unsigned xmin, ymin, w;
-        unpack_rect(__float_as_uint(r2.y), xmin, ymin, w);
-        const unsigned k = (ty - ymin) * w + (tx - xmin);
-        upos[r0 + i] = __float_as_uint(r2.z) + k;
-    }
-}
-
 // small segments (1..kSmallCap keys): one 256-thread workgroup per tile.  LSD radix sort on the 32 depth bits, 8 bits per
 // pass, with the entry's position in the unsorted segment (< 4096) as payload:
 //   * every thread keeps up to 16 (depth, position) pairs in registers; wave w owns the w-th quarter of the array, so
@@ -475,42 +421,178 @@ tile_sort_radix_mid_kernel(int tiles, const unsigned* __restrict__ big_list, con
     }
 }
 
-// big segments come from a device-built worklist (write_ranges_kernel), walked by a FIXED grid so that no
-// host read-back is needed and an empty list costs one trivial launch.  Up to `cap` keys are sorted in
-// 128 KB of LDS; anything larger falls back to the same network on the global key array.
+// Segments of more than kSmallCap entries (any length; the device-built "big" worklist, walked by a FIXED grid so that no host
+// read-back is needed and an empty list costs one trivial launch): the same LSD radix sort with the pairs in GLOBAL memory.
+// A pass reads the segment twice -- count (per-wave digit histogram from the ballot groups), one-wave scan, scatter (the
+// ballots again give the rank inside a batch, the wave's LDS counter the running destination) -- so nothing is kept per key
+// and the length is unbounded; (key, payload) pairs ping-pong between two buffers: in LDS for segments up to kBigLds entries,
+// else carved from the backward's row slab, which is idle during the forward pass (16 bytes per entry of its 48; all traffic
+// stays inside the tile's own segment, i.e. in L2).
+// Equal depths: as in the small kernel, an index sort in front of a second depth sort when (and only when) the depth-sorted
+// segment has equal neighbours.
+template <int WAVES>
+__device__ __forceinline__ void radix_pass_global(const uint2* __restrict__ src, uint2* __restrict__ dst, int n, int shift,
+                                                  unsigned (*cnt)[256]) {
+    constexpr int GB = 8;  // batches whose loads are in flight together (the passes are latency-bound: L2 round trips)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nbw = (n + WAVES * 64 - 1) / (WAVES * 64);  // batches of 64 per wave
+    const int w0 = wv * nbw * 64;
+    reinterpret_cast<uint4*>(&cnt[0][0])[tid] = make_uint4(0u, 0u, 0u, 0u);  // WAVES * 64 threads x 4 = WAVES x 256 counters
+    __syncthreads();
+    for (int b0 = 0; b0 < nbw; b0 += GB) {  // count
+        unsigned key[GB];
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const int i = w0 + (b0 + u) * 64 + lane;
+            key[u] = (b0 + u < nbw && i < n) ? src[i].x : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const bool valid = b0 + u < nbw && w0 + (b0 + u) * 64 + lane < n;
+            const unsigned d = (key[u] >> shift) & 255u;
+            unsigned long long m = __ballot(valid);
+            if (m != 0ull) {
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool bs = (d >> bit) & 1u;
+                    const unsigned long long bb = __ballot(bs);
+                    m &= bs ? bb : ~bb;
+                }
+                const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (valid && rk == 0u) cnt[wv][d] += (unsigned)__popcll(m);
+            }
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {  // digit-major, wave-minor exclusive prefix: lane l owns digits 4 l .. 4 l + 3
+        uint4 c[WAVES];
+        uint4 t = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) {
+            c[w] = reinterpret_cast<const uint4*>(&cnt[w][0])[lane];
+            t.x += c[w].x, t.y += c[w].y, t.z += c[w].z, t.w += c[w].w;
+        }
+        const unsigned tot = t.x + t.y + t.z + t.w;
+        const unsigned base = wave_inclusive_scan_u32(tot) - tot;
+        uint4 run = make_uint4(base, base + t.x, base + t.x + t.y, base + t.x + t.y + t.z);
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) {
+            reinterpret_cast<uint4*>(&cnt[w][0])[lane] = run;
+            run.x += c[w].x, run.y += c[w].y, run.z += c[w].z, run.w += c[w].w;
+        }
+    }
+    __syncthreads();
+    for (int b0 = 0; b0 < nbw; b0 += GB) {  // scatter: cnt[wv][d] is now the wave's running destination for digit d
+        uint2 e[GB];
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const int i = w0 + (b0 + u) * 64 + lane;
+            e[u] = make_uint2(0u, 0u);
+            if (b0 + u < nbw && i < n) e[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const bool valid = b0 + u < nbw && w0 + (b0 + u) * 64 + lane < n;
+            const unsigned d = (e[u].x >> shift) & 255u;
+            unsigned long long m = __ballot(valid);
+            if (m != 0ull) {
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool bs = (d >> bit) & 1u;
+                    const unsigned long long bb = __ballot(bs);
+                    m &= bs ? bb : ~bb;
+                }
+                const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                unsigned old = 0u;
+                if (valid && rk == 0u) {
+                    old = cnt[wv][d];
+                    cnt[wv][d] = old + (unsigned)__popcll(m);
+                }
+                const int leader = valid ? __builtin_ctzll(m) : lane;
+                old = (unsigned)__shfl((int)old, leader, 64);
+                if (valid) dst[old + rk] = e[u];
+            }
+        }
+    }
+    __threadfence_block();  // the pairs cross waves through memory (one CU, one L1)
+    __syncthreads();
+}
+
+// OR / AND over .x of n pairs -> bits that differ
+template <int WAVES>
+__device__ __forceinline__ unsigned varying_bits_global(const uint2* __restrict__ src, int n, unsigned* s_red) {
+    if (threadIdx.x == 0) s_red[0] = 0u, s_red[1] = 0xFFFFFFFFu;
+    __syncthreads();
+    unsigned vo = 0u, va = 0xFFFFFFFFu;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += WAVES * 64) vo |= src[i].x, va &= src[i].x;
+    atomicOr(&s_red[0], vo);
+    atomicAnd(&s_red[1], va);
+    __syncthreads();
+    const unsigned v = s_red[0] ^ s_red[1];
+    __syncthreads();
+    return v;
+}
+
 __global__ void __launch_bounds__(1024)
-tile_sort_big_kernel(int cap, int gridx, const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
-                     const uint2* __restrict__ ranges, uint4* __restrict__ inst,
-                     const float* __restrict__ rec, unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
+                           const uint2* __restrict__ ranges, const uint4* __restrict__ inst, uint2* __restrict__ pairs, size_t R,
+                           unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
+    constexpr int WAVES = 16;
+    extern __shared__ __attribute__((aligned(16))) uint2 lds_pairs[];  // 2 x kBigLds pairs: segments up to kBigLds entries
+    __shared__ __attribute__((aligned(16))) unsigned cnt[WAVES][256];  // ping-pong in LDS, longer ones in global memory
+    __shared__ unsigned s_red[2];
     const unsigned count = *big_count;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
-        const int tile = (int)big_list[w];
-        const uint2 r = ranges[tile];
+        const uint2 r = ranges[big_list[w]];
         const int n = (int)(r.y - r.x);
-        if (n <= cap) {
-            for (int i = threadIdx.x; i < n; i += 1024) {
-                const uint4 e = inst[r.x + i];
-                skeys[i] = ((unsigned long long)e.y << 32) | e.x;
-            }
-            __syncthreads();
-            bitonic_sort<1024, false>(skeys, n);
-            emit_sorted(skeys, n, r.x, tile, gridx, rec, point_list, upos, 1024);
-        } else {
-            // the segment's records are packed in place into 64-bit keys (key i lands on record i / 2, which an earlier
-            // or -- with the barrier -- the same round has already read)
-            unsigned long long* gkeys = reinterpret_cast<unsigned long long*>(inst + r.x);
-            for (int i0 = 0; i0 < n; i0 += 1024) {
-                const int i = i0 + (int)threadIdx.x;
-                uint4 e = make_uint4(0u, 0u, 0u, 0u);
-                if (i < n) e = inst[r.x + i];
-                __syncthreads();
-                if (i < n) gkeys[i] = ((unsigned long long)e.y << 32) | e.x;
+        const uint4* seg = inst + r.x;
+        uint2* bufA = n <= kBigLds ? lds_pairs : pairs + r.x;  // two pair buffers of this segment
+        uint2* bufB = n <= kBigLds ? lds_pairs + kBigLds : pairs + R + r.x;
+        bool resort = false;
+        for (int phase = 0; phase < 3; phase++) {  // 0: by depth; after a tie only: 1: by index, 2: by depth again
+            uint2* cur = bufA;
+            uint2* oth = bufB;
+            if (phase == 2) {  // keys = depths of the index-sorted order (payloads kept); result of phase 1 is in `last`
+                // (handled below: phase 1 leaves its result in bufA)
+#pragma unroll 4
+                for (int i = threadIdx.x; i < n; i += WAVES * 64) bufA[i].x = seg[bufA[i].y].y;
+            } else {
+#pragma unroll 4
+                for (int i = threadIdx.x; i < n; i += WAVES * 64) {
+                    const uint4 e = seg[i];
+                    bufA[i] = make_uint2(phase == 1 ? e.x : e.y, (unsigned)i);
+                }
             }
             __threadfence_block();
             __syncthreads();
-            bitonic_sort<1024, true>(gkeys, n);
-            emit_sorted(gkeys, n, r.x, tile, gridx, rec, point_list, upos, 1024);
+            const unsigned varying = varying_bits_global<WAVES>(bufA, n, s_red);
+            for (int shift = 0; shift < 32; shift += 8) {
+                if (((varying >> shift) & 255u) == 0u) continue;  // workgroup-uniform
+                radix_pass_global<WAVES>(cur, oth, n, shift, cnt);
+                uint2* t = cur;
+                cur = oth;
+                oth = t;
+            }
+            if (cur != bufA) {  // keep the result in bufA (one copy at most per phase)
+#pragma unroll 4
+                for (int i = threadIdx.x; i < n; i += WAVES * 64) bufA[i] = bufB[i];
+                __threadfence_block();
+                __syncthreads();
+            }
+            if (phase == 0) {
+                bool tie = false;
+#pragma unroll 4
+                for (int i = threadIdx.x; i + 1 < n; i += WAVES * 64) tie = tie | (bufA[i].x == bufA[i + 1].x);
+                resort = __syncthreads_or(tie) != 0;
+                if (!resort) break;
+            }
+        }
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n; i += WAVES * 64) {
+            const uint4 e = seg[bufA[i].y];
+            point_list[r.x + i] = e.x;
+            upos[r.x + i] = e.z;
         }
         __syncthreads();
     }
@@ -518,7 +600,6 @@ tile_sort_big_kernel(int cap, int gridx, const unsigned* __restrict__ big_list, 
 
 // ---- host launchers -----------------------------------------------------------------------------------------
 static constexpr int kSmallCap = 4096;   // 32 KB of LDS pairs, 256 threads x 16 (cfg2 centre tiles reach 2-3 k entries on some frames)
-static constexpr int kLargeCap = 16384;  // 128 KB of LDS keys, 1024 threads
 
 int binning_lds_limit_tiles() { return 36 * 1024; }  // 144 KB of u32 counters
 
@@ -563,23 +644,22 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
     return hipSuccess;
 }
 
-hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, uint4* inst,
-                            const float* rec, unsigned* point_list, unsigned* upos, const unsigned* big_list,
-                            const unsigned* big_count) {
-    static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
-    bool& attr_set = attr_set_dev[current_device_slot()];
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tile_sort_big_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLargeCap * 8);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint4* inst, uint2* pairs, size_t R,
+                            unsigned* point_list, unsigned* upos, const unsigned* big_list, const unsigned* big_count) {
     static_assert(kSmallCap == 8 * 64 * 8, "tile_sort_radix_mid_kernel covers segments up to kSmallCap");
     hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(768), dim3(512), 0, st, tiles, big_list, big_count + 1, ranges, inst,
                        point_list, upos);
     hipLaunchKernelGGL(tile_sort_radix_kernel, dim3(tiles), dim3(256), 0, st, ranges, inst, point_list, upos);
-    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(256), dim3(1024), kLargeCap * 8, st, kLargeCap, gridx, big_list,
-                       big_count, ranges, inst, rec, point_list, upos);
+    static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
+    bool& attr_set = attr_set_dev[current_device_slot()];
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)tile_sort_radix_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * kBigLds * 8);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(tile_sort_radix_big_kernel, dim3(256), dim3(1024), 2 * kBigLds * 8, st, big_list, big_count, ranges, inst,
+                       pairs, R, point_list, upos);
     return hipSuccess;
 }
 

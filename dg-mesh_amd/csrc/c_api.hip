@@ -34,9 +34,8 @@ void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, un
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, uint4* inst);
-hipError_t launch_tile_sort(hipStream_t st, int tiles, int gridx, const uint2* ranges, uint4* inst,
-                            const float* rec, unsigned* point_list, unsigned* upos, const unsigned* big_list,
-                            const unsigned* big_count);
+hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint4* inst, uint2* pairs, size_t R,
+                            unsigned* point_list, unsigned* upos, const unsigned* big_list, const unsigned* big_count);
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
@@ -391,7 +390,10 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
         tm.end(DGM_STAGE_BIN_SCATTER);
 
         tm.begin(DGM_STAGE_TILE_SORT);
-        DGM_HIP(launch_tile_sort(st, tiles, gridx, ranges, inst, rec, point_list, upos, big_list, counters + 2));
+        // (segments beyond 4096 entries sort in global memory: their pair buffers are carved from the backward's row slab,
+        // 48 bytes per entry and idle during the forward pass)
+        DGM_HIP(launch_tile_sort(st, tiles, ranges, inst, (uint2*)(bin + L.slab), (size_t)R, point_list, upos, big_list,
+                                 counters + 2));
         DGM_CHECK("tile_sort");
         tm.end(DGM_STAGE_TILE_SORT);
     }
