@@ -55,7 +55,7 @@ class MultiAdam:
             n = len(entries)
             VP = ctypes.c_void_p * n
             plans.append(dict(key=key, entries=entries, n=n, slots=[None] * n, mom=[None] * n, P=VP(), G=VP(), M=VP(), V=VP(),
-                              N=(ctypes.c_longlong * n)(), LR=(ctypes.c_float * n)(), ST=(ctypes.c_int * n)(), dense=False))
+                              N=(ctypes.c_longlong * n)(), LR=(ctypes.c_float * n)(), ST=(ctypes.c_int * n)(), pos=[-1] * n))
         self._sig, self._cached = sig, plans
         return plans
 
@@ -81,11 +81,13 @@ class MultiAdam:
             entries, slots, mom = pl["entries"], pl["slots"], pl["mom"]
             P, G, M, V, N, LR, ST = pl["P"], pl["G"], pl["M"], pl["V"], pl["N"], pl["LR"], pl["ST"]
             k = 0
-            keep = []  # gradient tensors made contiguous for this call
+            keep = []   # gradient tensors made contiguous for this call
             steps = []
-            for i, (o, g, p) in enumerate(entries):
+            pos = pl["pos"]  # array position each entry had in the previous call (-1: took no part): the cached pointers at a
+            for i, (o, g, p) in enumerate(entries):  # position are valid as long as the same entry lands there again
                 gr = grads.get(id(p)) if grads is not None else p.grad
                 if gr is None:
+                    pos[i] = -1
                     continue
                 if gr.dtype != torch.float32 or gr.shape != p.shape:
                     raise ValueError("MultiAdam: gradient / parameter mismatch")
@@ -93,19 +95,18 @@ class MultiAdam:
                     gr = gr.contiguous()
                     keep.append(gr)
                 s = slots[i]
-                st = o.state.get(p)
                 # the state dict entry, its moment tensors and its step tensor must still be the ones bound last time
                 # (optimizer surgery on an unchanged Parameter, load_state_dict ...): otherwise bind again
-                if s is None or st is not s or s.get("exp_avg") is not mom[i][0] or s.get("exp_avg_sq") is not mom[i][1] \
-                        or s.get("step") is not mom[i][2] or k != i or not pl["dense"]:
+                if s is None or pos[i] != k or o.state.get(p) is not s or s.get("exp_avg") is not mom[i][0] \
+                        or s.get("exp_avg_sq") is not mom[i][1] or s.get("step") is not mom[i][2]:
                     s = self._bind(pl, i)
                     P[k], M[k], V[k], N[k] = p.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel()
+                    pos[i] = k
                 G[k], LR[k] = gr.data_ptr(), float(g["lr"])
                 stp = mom[i][2]
                 ST[k] = int(stp) + 1
                 steps.append(stp)
                 k += 1
-            pl["dense"] = k == pl["n"]  # the cached pointer arrays are valid as long as every entry takes part
             if k == 0:
                 continue
             torch._foreach_add_(steps, 1.0)

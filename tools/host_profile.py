@@ -14,6 +14,7 @@ import bench  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
+bench.WORKLOAD = os.environ.get("DGM_BENCH_WORKLOAD", "cfg2")
 tr, _ = bench.build_scene(dev, 0, 1, "hip")
 it0 = tr.opt.warm_up + 2000
 for i in range(15):
