@@ -185,11 +185,11 @@ typedef struct {
     const float* bh;
 } dgm_mlp_params;
 
-/* Arithmetic of the 256-wide GEMMs.  0 (default): "bf16x6" -- every fp32 operand is split exactly into three bf16
- * numbers and the six partial products above 2^-24 are accumulated in fp32 on the bf16 matrix cores (fp32 accuracy
- * at 2.7x the rate of the fp32 MFMA instruction); 1: native fp32 MFMA.  Returns the previous mode; any other value
- * only queries.  Process-wide; the initial value comes from the environment variable DGM_MLP_GEMM=bf16x6|f32.
- * A forward and its backward must run in the same mode. */
+/* Arithmetic of the trunk GEMMs.  2 (default): "f16x3" -- fp32 operands scaled by a power of two and split into two binary16
+ * numbers, three partial products accumulated in fp32 on the f16 matrix cores; 0: "bf16x6" -- operands split exactly into
+ * three bf16 numbers, six partial products; 1: native fp32 MFMA.  All three are fp32 GEMMs to rounding.  Returns the previous
+ * mode; any other value only queries.  Process-wide; the initial value comes from the environment variable
+ * DGM_MLP_GEMM=f16x3|bf16x6|f32.  A forward and its backward must run in the same mode. */
 int dgm_mlp_set_gemm(int mode);
 
 /* Bytes of the workspace that forward fills (embedding, the 8 post-ReLU activations, re-laid-out
