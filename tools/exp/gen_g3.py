@@ -5,10 +5,10 @@ import os
 
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = open(os.path.join(root, "dg-mesh_amd/csrc/mlp_f16x3.hpp")).read()
-k0 = src.index("template <int EPI, int KS, int PF>\n__global__")
-k1 = src.index("// ---- weight gradient of the K = 256 layers")
+k0 = src.index("template <int EPI, int KS, int PF, bool DUAL = false>\n__global__")
+k1 = src.index("// ---- the K = 256 layer GEMM, software-pipelined")
 kern = src[k0:k1]
-kern = kern.replace("template <int EPI, int KS, int PF>\n__global__", "template <int EPI, int KS, int PF, int VAR>\n__global__")
+kern = kern.replace("template <int EPI, int KS, int PF, bool DUAL = false>\n__global__", "template <int EPI, int KS, int PF, int VAR, bool DUAL = false>\n__global__")
 kern = kern.replace("mlp_gemm3r_kernel(", "g3_kernel(")
 PAD = 119
 
@@ -23,7 +23,7 @@ def rep(text, a, b):
 
 
 mf = [l for l in kern.split("\n") if "__builtin_amdgcn_mfma_f32_32x32x16_f16" in l]
-assert len(mf) == 6
+assert len(mf) == 12  # six of the DUAL branch, six of the two-chain branch
 lines_ = kern.split("\n")
 i0_ = lines_.index(mf[0]) - 1
 i1_ = lines_.index(mf[-1]) + 1
