@@ -770,6 +770,27 @@ int g_gemm_mode = [] {
     if (e[0] == 'f' && e[1] == '3') return 1;
     return 2;
 }();
+// arithmetic the last forward pass on a workspace ran in: the backward pass must match (its scales and masks were produced by
+// that forward pass).  A small host-side table keyed by the workspace pointer; an unknown workspace is not checked.
+struct WsMode {
+    const void* ws;
+    int mode;
+};
+WsMode g_ws_mode[64] = {};
+unsigned g_ws_next = 0;
+void remember_ws_mode(const void* ws, int mode) {
+    for (auto& e : g_ws_mode)
+        if (e.ws == ws) {
+            e.mode = mode;
+            return;
+        }
+    g_ws_mode[g_ws_next++ % 64] = WsMode{ws, mode};
+}
+int recall_ws_mode(const void* ws) {
+    for (auto& e : g_ws_mode)
+        if (e.ws == ws) return e.mode;
+    return -1;
+}
 bool use_f32_mfma() { return g_gemm_mode == 1; }
 bool use_f16x3() { return g_gemm_mode == 2; }
 #define G3R_LDS(K_) (2 * 32 * (4 * (K_) + 16) + 256 + 2 * 8 * 32 * 4)  // A planes (double buffered) + row scales + mask words
@@ -877,6 +898,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     if (!x || !temb || !workspace || !out) return mlp_fail("mlp_forward: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
+    remember_ws_mode(workspace, g_gemm_mode);
     const bool f32 = use_f32_mfma();
     if (f32) {
         for (int l = 0; l < 8; l++) {
@@ -1002,6 +1024,11 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     if (check_params(p)) return 1;
     if (N <= 0) return 0;
     if (!dOut || !workspace || !dW || !db || !dWh || !dbh) return mlp_fail("mlp_backward: NULL pointer");
+    {
+        const int fm = recall_ws_mode(workspace);
+        if (fm >= 0 && fm != g_gemm_mode)
+            return mlp_fail("mlp_backward: the arithmetic mode changed since the forward pass on this workspace (dgm_mlp_set_gemm)");
+    }
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
