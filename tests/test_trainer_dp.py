@@ -70,6 +70,13 @@ def test_frame_schedule_partitions_epoch():
     assert sorted(seen) == list(range(n))                      # one epoch covers every frame exactly once
     assert [T.frame_schedule(n, s, 1, W, seed=3) for s in range(3)] == seen[1::W]
     assert T.frame_schedule(n, 0, 0, W, seed=3) == T.frame_schedule(n, 0, 0, W, seed=3)
+    # the per-epoch permutation is cached (one entry): alternating epochs / seeds / frame counts must give the same answers
+    # as asking for them in order
+    want = {(e, sd, m): T.frame_schedule(m, e * (m // W), 0, W, seed=sd) for e in (0, 1, 2) for sd in (3, 4) for m in (n, n + 8)}
+    for _ in range(2):
+        for key in reversed(sorted(want)):
+            e, sd, m = key
+            assert T.frame_schedule(m, e * (m // W), 0, W, seed=sd) == want[key]
 
 
 def test_flat_bucket_views():
