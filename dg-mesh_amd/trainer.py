@@ -224,10 +224,21 @@ class Trainer:
                 d_xyz, d_rotation, d_scaling = self.deform.step(g.get_xyz.detach(), time_input)[:3]
         losses = {}
         if delta is not None:
-            pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta)
-            back = self.deform_back.step_raw(pkg["means3D"].detach(), self.time_input(cam, N, iteration))
             from .glue import cycle_loss
-            losses["cycle_loss"] = cycle_loss(delta, back)
+            if self.world > 1 and self._early is not None:
+                # Data parallel with the early Gaussian-bucket all-reduce: build the cycle branch BEFORE the render branch.
+                # Autograd runs later-built branches first, so the rasterizer's backward -- after which the Gaussian
+                # gradients are final and their all-reduce starts -- then precedes BOTH MLP backward passes instead of only
+                # the deformation network's: twice the window to hide the exchange in.  Same values (the deformed means are
+                # the same fp32 sum the glue kernel forms; the two gradients of `delta` commute).
+                means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
+                back = self.deform_back.step_raw(means, self.time_input(cam, N, iteration))
+                losses["cycle_loss"] = cycle_loss(delta, back)
+                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta)
+            else:
+                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta)
+                back = self.deform_back.step_raw(pkg["means3D"].detach(), self.time_input(cam, N, iteration))
+                losses["cycle_loss"] = cycle_loss(delta, back)
         else:
             pkg = self.render_fn(cam, g, self.pipe, self.bg, d_xyz, d_rotation, d_scaling, self.is_6dof)
             if iteration >= opt.warm_up:
