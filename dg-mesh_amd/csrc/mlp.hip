@@ -664,13 +664,19 @@ mlp_timenet_fwd_kernel(const float* __restrict__ t, int n_freq, const float* __r
         save[n_pe + j] = a;
     }
     __syncthreads();
-    // one wave per output: 64 lanes stride over the hidden units, butterfly sum
-    for (int o = tid >> 6; o < n_out; o += 4) {
+    // eight lanes per output, 32 outputs per round (one round for the reference's 30): every thread streams its slice of the
+    // row with all loads in flight, three shuffles finish the sum -- the kernel is pure latency, so rounds are what costs
+    for (int o0 = 0; o0 < n_out; o0 += 32) {
+        const int o = o0 + (tid >> 3), l8 = tid & 7;
         float a = 0.f;
-        for (int j = tid & 63; j < hidden; j += 64) a += W2[o * hidden + j] * h[j];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-        if ((tid & 63) == 0) out[o] = a + b2[o];
+        if (o < n_out) {
+#pragma unroll 8
+            for (int j = l8; j < hidden; j += 8) a += W2[o * hidden + j] * h[j];
+        }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        if (l8 == 0 && o < n_out) out[o] = a + b2[o];
     }
 }
 
