@@ -130,24 +130,20 @@ cycle_finish_kernel(int N, int blocks, const float* __restrict__ partial, float*
 __global__ void __launch_bounds__(256)
 cycle_bwd_kernel(int N, const float* __restrict__ a, const float* __restrict__ b, int ld, const float* __restrict__ grad,
                  float* __restrict__ d_a, float* __restrict__ d_b) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    // one thread per ELEMENT of the (N, ld) row-major arrays: consecutive lanes touch consecutive floats (a thread per row
+    // walked the rows at a 52-byte pitch, thirteen partial-line passes over the same memory)
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)N * ld) return;
+    const int c = (int)(idx % (size_t)ld);
     const float g = grad[0] / 3.f;
-    const float w3 = g / (3.f * N), w4 = g / (4.f * N);
-    const float* pa = a + (size_t)r * ld;
-    const float* pb = b + (size_t)r * ld;
-    float* da = d_a + (size_t)r * ld;
-    float* db = d_b + (size_t)r * ld;
-    for (int c = 0; c < ld; c++) {
-        float v = 0.f;
-        if (c < 10) {
-            const float x = -pb[c] - pa[c];
-            const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
-            v = -sg * ((c >= 3 && c < 7) ? w4 : w3);
-        }
-        da[c] = v;
-        db[c] = v;
+    float v = 0.f;
+    if (c < 10) {
+        const float x = -b[idx] - a[idx];
+        const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+        v = -sg * ((c >= 3 && c < 7) ? g / (4.f * N) : g / (3.f * N));
     }
+    d_a[idx] = v;
+    d_b[idx] = v;
 }
 
 }  // namespace dgm
@@ -211,7 +207,8 @@ int dgm_cycle_loss_backward(int N, const float* a, const float* b, int ld, const
                             void* stream) {
     if (N <= 0) return 0;
     if (!a || !b || !grad_out || !d_a || !d_b) return glue_fail("cycle_loss_backward: NULL pointer");
-    hipLaunchKernelGGL(cycle_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, a, b, ld, grad_out, d_a, d_b);
+    hipLaunchKernelGGL(cycle_bwd_kernel, dim3((unsigned)(((size_t)N * ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, a, b, ld,
+                       grad_out, d_a, d_b);
     return glue_done();
 }
 
