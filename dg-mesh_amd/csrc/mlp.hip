@@ -386,11 +386,30 @@ __global__ void mlp_reduce_dw_kernel(int chunks, int db_chunks, int Kp, int in_f
 // its group's chunks with sixteen 16-byte loads in flight (one round for the usual 256 chunks), the sixteen group sums
 // meet in LDS (fixed order), and the piece is written transposed into the PyTorch (out, in) layout.  The first 32
 // workgroups also reduce eight columns each of the bias-gradient rows (db_rows of them).
+struct ReduceDwJob {
+    int chunks, db_rows, Kp, in_features, nblocks;
+    const float* partial;
+    const float* partial_db;
+    float* dW;
+    float* db;
+};
+struct ReduceDwBatch {
+    int emb_dim;
+    ReduceDwJob job[8];
+};
+// All eight layers of a network in ONE launch at the end of its backward pass (blockIdx.y = layer; every layer keeps its own
+// partial tiles until then): seven launches and their ramps fewer per pass, and the bias-gradient rows ride along.
 __global__ void __launch_bounds__(256)
-mlp_reduce_dw1_kernel(int chunks, int db_rows, int Kp, int in_features, int emb_dim, const float* __restrict__ partial,
-                      const float* __restrict__ partial_db, float* __restrict__ dW, float* __restrict__ db) {
+mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
     __shared__ float4 red[16][16];
     __shared__ float redb[32][8];
+    const ReduceDwJob& jb = rb.job[blockIdx.y];
+    if ((int)blockIdx.x >= jb.nblocks) return;
+    const int chunks = jb.chunks, db_rows = jb.db_rows, Kp = jb.Kp, in_features = jb.in_features, emb_dim = rb.emb_dim;
+    const float* __restrict__ partial = jb.partial;
+    const float* __restrict__ partial_db = jb.partial_db;
+    float* __restrict__ dW = jb.dW;
+    float* __restrict__ db = jb.db;
     const int tid = threadIdx.x, pos = tid & 15, grp = tid >> 4;
     const int k0 = (blockIdx.x >> 3) * 2, j0 = (blockIdx.x & 7) * 32;
     {
@@ -726,6 +745,7 @@ int mlp_fail(const char* msg) {
 }
 struct Ws {
     float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb;
+    float *partial_l[8], *partial_db_l[8];  // per layer: the weight-gradient partial tiles wait for the pass's one reduction
     uint4 *Wt6[8], *Wd6[8], *Wh6f;  // bf16x6 weight planes
     uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
     float *wsc_f[8], *wsc_d[8], *wsc_e;    // their inverse column scales (wsc_e: the embedding half of the skip layer)
@@ -839,8 +859,21 @@ Ws carve(char* base, int N) {
             if ((size_t)d.chunks * 2 > pdb) pdb = (size_t)d.chunks * 2;
         }
     }
-    w.partial = take(pfl * MLP_W * 4);
-    w.partial_db = take(pdb * MLP_W * 4);
+    for (int l = 0; l < 8; l++) {  // (geometry is fixed: layer 0 consumes the embedding, layer 5 embedding | trunk)
+        const int Kp = l == 0 ? MLP_EMB : (l == 5 ? MLP_EMB + MLP_W : MLP_W);
+        size_t rows = 0, dbr = 0;
+        for (int x3 = 0; x3 < 2; x3++) {
+            const DwPlan d = dw6_plan(N > 0 ? N : 1, Kp, x3 != 0);
+            if ((size_t)d.chunks * Kp > rows) rows = (size_t)d.chunks * Kp;
+            if ((size_t)d.chunks * 2 > dbr) dbr = (size_t)d.chunks * 2;
+        }
+        if (l == 5 && pfl > rows) rows = pfl;  // the fp32-MFMA path reduces layer by layer through this one
+        if (l == 5 && pdb > dbr) dbr = pdb;
+        w.partial_l[l] = take(rows * MLP_W * 4);
+        w.partial_db_l[l] = take(dbr * MLP_W * 4);
+    }
+    w.partial = w.partial_l[5];
+    w.partial_db = w.partial_db_l[5];
     for (int l = 0; l < 8; l++) w.Wt6[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 6);
     for (int l = 0; l < 8; l++) w.Wd6[l] = (uint4*)take((size_t)MLP_W * MLP_W * 6);
     w.Wh6f = (uint4*)take((size_t)MLP_W * 32 * 6);
@@ -1054,6 +1087,9 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     float* G = w.Ga;
     float* Gn = w.Gb;
     const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
+    ReduceDwBatch rb;
+    rb.emb_dim = p->emb_dim;
+    int rb_blocks = 0;
     for (int l = 7; l >= 0; l--) {
         const float *X1, *X2 = nullptr;
         int ldx1, K1, ldx2 = 0, K2 = 0;
@@ -1101,25 +1137,27 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
                 if (x3)
                     hipLaunchKernelGGL(mlp_dw3b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G,
-                                       w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial, w.partial_db);
+                                       w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial_l[l], w.partial_db_l[l]);
                 else
-                    hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial,
-                                       w.partial_db);
+                    hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial_l[l],
+                                       w.partial_db_l[l]);
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
             } else if (x3) {  // the layers that consume the embedding: K = 96 (layer 0) / 352 (skip layer), f16x3
                 db_rows = d.chunks;
                 if (Kp == MLP_EMB)
                     hipLaunchKernelGGL(mlp_dw3e_kernel<3>, dim3(d.chunks), dim3(512), DW3E_LDS(3), st, N, d.rows, X1, ldx1, K1, X2,
-                                       ldx2, G, w.cmaxE, (const unsigned*)nullptr, w.cmaxG + l * MLP_W, w.partial, w.partial_db);
+                                       ldx2, G, w.cmaxE, (const unsigned*)nullptr, w.cmaxG + l * MLP_W, w.partial_l[l], w.partial_db_l[l]);
                 else
                     hipLaunchKernelGGL(mlp_dw3e_kernel<11>, dim3(d.chunks), dim3(512), DW3E_LDS(11), st, N, d.rows, X1, ldx1, K1,
-                                       X2, ldx2, G, w.cmaxE, w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial,
-                                       w.partial_db);
+                                       X2, ldx2, G, w.cmaxE, w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial_l[l],
+                                       w.partial_db_l[l]);
             } else
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
-                                   K2, G, w.partial, w.partial_db);
-            hipLaunchKernelGGL(mlp_reduce_dw1_kernel, dim3(Kp / 2 * 8), dim3(256), 0, st, d.chunks, db_rows, Kp,
-                               layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
+                                   K2, G, w.partial_l[l], w.partial_db_l[l]);
+            ReduceDwJob& jb = rb.job[l];
+            jb.chunks = d.chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = Kp / 2 * 8;
+            jb.partial = w.partial_l[l], jb.partial_db = w.partial_db_l[l], jb.dW = dW[l], jb.db = db[l];
+            if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;
         }
         if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]
             for (int c0 = 0; c0 < p->t_dim; c0 += 16)     // the small kernel handles 16 output columns per pass
@@ -1132,6 +1170,8 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             Gn = t;
         }
     }
+    if (!f32)  // the weight gradients of all eight layers: one reduction of their partial tiles
+        hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, 8), dim3(256), 0, st, rb);
     if (!per_row_t && dtemb != nullptr)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
                            db[p->skip_layer], p->W[p->skip_layer], layer_in(p, p->skip_layer), dtemb);
