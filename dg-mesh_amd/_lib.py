@@ -42,6 +42,12 @@ SYMBOLS = {
                                    _c.POINTER(_i)]),
     "dgm_rasterize_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dgm_rasterize_forward_split_sh": (_i, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp,
+                                            _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp,
+                                            _c.POINTER(_i)]),
+    "dgm_rasterize_backward_split_sh": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp,
+                                             _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                             _vp, _vp, _i, _vp]),
     "dgm_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "dgm_geometry_bytes": (_c.c_size_t, [_i, _i, _i]),
     "dgm_binning_bytes": (_c.c_size_t, [_i]),
@@ -62,6 +68,7 @@ SYMBOLS = {
     "dgm_cycle_loss_forward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_cycle_loss_backward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dgm_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp]),
+    "dgm_densify_stats": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgm_densify_scratch_bytes": (_c.c_size_t, [_i]),
     "dgm_densify_totals_offset": (_c.c_size_t, [_i]),
     "dgm_densify_decide": (_i, [_i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),

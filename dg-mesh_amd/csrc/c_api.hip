@@ -17,7 +17,8 @@ namespace dgm {
 // preprocess.hip
 void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations, const float* opacities, const float* shs,
-                           const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
+                           const float* shs_rest, const float* cov3D_precomp, const float* colors_precomp,
+                           const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                            int gridx, int gridy, int prefiltered, int* radii_out, float* rec, float* depth,
                            int* radii_int, unsigned* tiles_touched, float* cov3Ds, uint8_t* clamped,
@@ -46,13 +47,14 @@ void launch_render_bwd3(hipStream_t st, int tiles, const uint2* ranges, const un
                         const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc, const unsigned* upos, float* slab);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
-                           const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
+                           const float* shs, const float* shs_rest, const uint8_t* clamped, const float* scales,
+                           const float* rotations,
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
                            const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
                            const float* rec, const unsigned* tiles_touched, const unsigned* offs, const float* slab,
                            float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
-                           float* dL_dsh, float* dL_dscale, float* dL_drot);
+                           float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot);
 // knn.hip
 size_t knn_scratch_bytes(int P);
 void launch_knn(hipStream_t st, int P, const float* pts, float* dists, char* scratch);
@@ -282,8 +284,23 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                           const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                           int* radii, int debug, void* stream, int* num_rendered) {
+    return dgm_rasterize_forward_split_sh(geom_alloc, geom_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+                                          background, width, height, means3D, shs, nullptr, colors_precomp, opacities, scales,
+                                          scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                                          tan_fovy, prefiltered, out_color, radii, debug, stream, num_rendered);
+}
+
+int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                                   dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                                   int width, int height, const float* means3D, const float* shs, const float* shs_rest,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                                   int* num_rendered) {
     hipStream_t st = (hipStream_t)stream;
     if (num_rendered) *num_rendered = 0;
+    if (shs_rest && (!shs || M < 2)) return fail("rasterize_forward: shs_rest needs the DC rows in shs and M >= 2");
     if (P < 0 || width <= 0 || height <= 0) return fail("rasterize_forward: bad sizes P=%d W=%d H=%d", P, width, height);
     if (!geom_alloc || !binning_alloc || !image_alloc) return fail("rasterize_forward: allocator callback is NULL");
     if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color)
@@ -341,7 +358,7 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
     DGM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), st));
 
     tm.begin(DGM_STAGE_PREPROCESS);
-    launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+    launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                           colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, gridx,
                           gridy, prefiltered, radii, rec, depth, radii_int, tiles_touched, cov3D, clamped, block_sums,
                           counters);
@@ -415,8 +432,26 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
                            char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                            float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                            float* dL_dscale, float* dL_drot, int debug, void* stream) {
+    return dgm_rasterize_backward_split_sh(P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales,
+                                           scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx,
+                                           tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D,
+                                           dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, nullptr, dL_dscale,
+                                           dL_drot, debug, stream);
+}
+
+int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* background, int width, int height,
+                                    const float* means3D, const float* shs, const float* shs_rest,
+                                    const float* colors_precomp, const float* scales, float scale_modifier,
+                                    const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                    const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                    const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                                    const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                    float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
+                                    float* dL_dscale, float* dL_drot, int debug, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (P <= 0) return 0;  // rasterize_points.cu:161
+    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (shs_rest && (!shs || !dL_dsh || M < 2)))
+        return fail("rasterize_backward: shs_rest and dL_dsh_rest come together (with shs, dL_dsh and M >= 2)");
     if (width <= 0 || height <= 0 || R < 0) return fail("rasterize_backward: bad sizes");
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("rasterize_backward: NULL state buffer");
     if (!dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale ||
@@ -459,10 +494,12 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
     tm.begin(DGM_STAGE_PREPROCESS_BWD);
     const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : cov3D;  // rasterizer_impl.cu:411
     // with precomputed colours the SH branch is skipped (backward.cu:390: `if (shs)`)
-    launch_preprocess_bwd(st, P, D, M, gridx, means3D, radii, colors_precomp ? nullptr : shs, clamped, scales, rotations,
+    launch_preprocess_bwd(st, P, D, M, gridx, means3D, radii, colors_precomp ? nullptr : shs,
+                          colors_precomp ? nullptr : shs_rest, clamped, scales, rotations,
                           scale_modifier, cov3D_ptr, viewmatrix, projmatrix, campos, focal_x, focal_y, tan_fovx,
                           tan_fovy, width, height, rec, tiles_touched, offs, slab, dL_dmean2D, dL_dconic,
-                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, colors_precomp ? nullptr : dL_dsh_rest, dL_dscale,
+                          dL_drot);
     DGM_CHECK("preprocess_bwd");
     tm.end(DGM_STAGE_PREPROCESS_BWD);
     tm.finish();

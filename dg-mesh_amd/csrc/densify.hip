@@ -155,6 +155,24 @@ densify_split_kernel(int P, unsigned first, unsigned count, const unsigned* __re
     scaling_out[3 * j + 2] = logf(s2 / 1.6f);
 }
 
+// per-iteration statistics (R/train.py:489-496 + add_densification_stats, gaussian_model_dpsr_dynamic_anchor.py:679-682):
+// for the Gaussians with radii > 0: max_radii2D = max(max_radii2D, radii), xyz_gradient_accum += |dL/dmeans2D[:2]|,
+// denom += 1.  One thread per Gaussian, in place.
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int P, const float* __restrict__ grad2d, const int* __restrict__ radii, float* __restrict__ max_radii2D,
+                     float* __restrict__ grad_accum, float* __restrict__ denom) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    if (grad2d != nullptr) {
+        const float gx = grad2d[3 * (size_t)i], gy = grad2d[3 * (size_t)i + 1];
+        grad_accum[i] += sqrtf(gx * gx + gy * gy);
+        denom[i] += 1.0f;
+    }
+}
+
 }  // namespace dgm
 
 using namespace dgm;
@@ -167,6 +185,17 @@ int dfail(const char* m) {
 }  // namespace
 
 extern "C" {
+
+int dgm_densify_stats(int P, const float* grad2d, const int* radii, float* max_radii2D, float* grad_accum, float* denom,
+                      void* stream) {
+    if (P <= 0) return 0;
+    if (!radii || !max_radii2D || (grad2d && (!grad_accum || !denom))) return dfail("densify_stats: NULL pointer");
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, grad2d, radii,
+                       max_radii2D, grad_accum, denom);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dfail(hipGetErrorString(e));
+    return 0;
+}
 
 // Decision + scans.  scratch: (P + 3 P * 4 + 16) bytes = flags | off_keep | off_clone | off_split | totals[3] (u32);
 // after the stream has reached this point, totals (at dgm_densify_totals_offset(P)) hold K, C, S.

@@ -54,9 +54,39 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 
 // Cooperative, coalesced copy of the first 3*n floats of each SH row of this workgroup's Gaussians
 // into LDS with an odd row stride.  Must be called by all threads of the block.
-__device__ __forceinline__ void stage_sh(const float* __restrict__ shs, int base, int cnt, int M, int n, int stride,
-                                         float* lds) {
+// shs_rest != nullptr: the rows come in two pieces, as the model stores them -- shs = the DC term (P,1,3), shs_rest = the
+// other M-1 coefficients (P,M-1,3) -- which saves the caller the concatenation (get_features).
+__device__ __forceinline__ void stage_sh(const float* __restrict__ shs, const float* __restrict__ shs_rest, int base, int cnt,
+                                         int M, int n, int stride, float* lds) {
     const int L = 3 * n;
+    if (shs_rest != nullptr) {
+        for (int i = threadIdx.x; i < cnt * 3; i += blockDim.x) {
+            const int g = i / 3, k = i - g * 3;
+            lds[g * stride + k] = shs[(size_t)base * 3 + i];
+        }
+        const int Lr = L - 3, Mr = 3 * (M - 1);
+        const float* src = shs_rest + (size_t)base * Mr;
+        if (n == M && ((cnt * Mr) & 3) == 0 && (((uintptr_t)src) & 15) == 0) {  // whole rows: 16-byte loads
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            const int total4 = (cnt * Mr) >> 2;
+            for (int i = threadIdx.x; i < total4; i += blockDim.x) {
+                const float4 v = s4[i];
+                const float e4[4] = {v.x, v.y, v.z, v.w};
+                const int e = i << 2;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {  // Mr = 45: the four floats may straddle two rows
+                    const int g = (e + c) / Mr, k = (e + c) - g * Mr;
+                    lds[g * stride + 3 + k] = e4[c];
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < cnt * Lr; i += blockDim.x) {
+                const int g = i / Lr, k = i - g * Lr;
+                lds[g * stride + 3 + k] = src[(size_t)g * Mr + k];
+            }
+        }
+        return;
+    }
     if (n == M && (L & 3) == 0) {
         const float4* src = reinterpret_cast<const float4*>(shs + (size_t)base * 3 * M);
         const int total4 = cnt * (L >> 2);
@@ -82,7 +112,8 @@ __device__ __forceinline__ void stage_sh(const float* __restrict__ shs, int base
 __global__ void __launch_bounds__(DGM_PRE_BLOCK)
 preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                       float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
-                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ shs, const float* __restrict__ shs_rest,
+                      const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ colors_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, int W, int H,
                       float tan_fovx, float tan_fovy, float focal_x, float focal_y, int gridx, int gridy,
@@ -97,7 +128,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int n_sh = (D + 1) * (D + 1);
     const int stride = (3 * n_sh) | 1;
     const bool use_sh = (colors_precomp == nullptr) && shs != nullptr && M > 0;
-    if (use_sh) stage_sh(shs, base, cnt, M, n_sh, stride, lds);
+    if (use_sh) stage_sh(shs, shs_rest, base, cnt, M, n_sh, stride, lds);
     __syncthreads();
 
     unsigned my_tiles = 0;
@@ -282,7 +313,8 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations, const float* opacities, const float* shs,
-                           const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
+                           const float* shs_rest, const float* cov3D_precomp, const float* colors_precomp,
+                           const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                            int gridx, int gridy, int prefiltered, int* radii_out, float* rec, float* depth,
                            int* radii_int, unsigned* tiles_touched, float* cov3Ds, uint8_t* clamped,
@@ -295,7 +327,7 @@ void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* mea
                                  : 16;
     const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, means3D, scales,
-                       scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix,
+                       scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp, colors_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gridx, gridy, prefiltered, radii_out, rec,
                        depth, radii_int, tiles_touched, cov3Ds, clamped, block_sums, counters);
 }

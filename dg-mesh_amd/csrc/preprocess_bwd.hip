@@ -26,15 +26,15 @@ __constant__ float kbSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.45
 
 __global__ void __launch_bounds__(DGM_PRE_BLOCK)
 preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ means3D, const int* __restrict__ radii,
-                      const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
+                      const float* __restrict__ shs, const float* __restrict__ shs_rest, const uint8_t* __restrict__ clamped,
                       const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
                       const float* __restrict__ cov3Ds, const float* __restrict__ vm, const float* __restrict__ proj,
                       const float* __restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, int W, int H,
                       const float* __restrict__ rec, const unsigned* __restrict__ tiles_touched,
                       const unsigned* __restrict__ offs, const float* __restrict__ slab, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-                      float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-                      float* __restrict__ dL_drot) {
+                      float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
+                      float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int base = blockIdx.x * DGM_PRE_BLOCK;
     const int cnt = min(DGM_PRE_BLOCK, P - base);
@@ -47,7 +47,32 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
         // stage the whole (cnt, M, 3) block, coalesced
         const int total = cnt * L;
         const float* src = shs + (size_t)base * L;
-        if ((L & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+        if (shs_rest != nullptr) {  // rows in two pieces (DC | rest), see preprocess.hip: stage_sh
+            for (int i = threadIdx.x; i < cnt * 3; i += DGM_PRE_BLOCK) {
+                const int g = i / 3, k = i - g * 3;
+                lds[g * stride + k] = shs[(size_t)base * 3 + i];
+            }
+            const int Mr = L - 3;
+            const float* sr = shs_rest + (size_t)base * Mr;
+            if (((cnt * Mr) & 3) == 0 && (((uintptr_t)sr) & 15) == 0) {
+                const float4* s4 = reinterpret_cast<const float4*>(sr);
+                for (int i = threadIdx.x; i < ((cnt * Mr) >> 2); i += DGM_PRE_BLOCK) {
+                    const float4 v = s4[i];
+                    const float e4[4] = {v.x, v.y, v.z, v.w};
+                    const int e = i << 2;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int g = (e + c) / Mr, k = (e + c) - g * Mr;
+                        lds[g * stride + 3 + k] = e4[c];
+                    }
+                }
+            } else {
+                for (int i = threadIdx.x; i < cnt * Mr; i += DGM_PRE_BLOCK) {
+                    const int g = i / Mr, k = i - g * Mr;
+                    lds[g * stride + 3 + k] = sr[i];
+                }
+            }
+        } else if ((L & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
             const float4* s4 = reinterpret_cast<const float4*>(src);
             for (int i = threadIdx.x; i < (total >> 2); i += DGM_PRE_BLOCK) {
                 const float4 v = s4[i];
@@ -363,7 +388,32 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
         __syncthreads();
         const int total = cnt * L;
         float* dst = dL_dsh + (size_t)base * L;
-        if ((L & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        if (dL_dsh_rest != nullptr) {  // two outputs: dL_dsh = the DC rows (P,1,3), dL_dsh_rest = the rest (P,M-1,3)
+            for (int i = threadIdx.x; i < cnt * 3; i += DGM_PRE_BLOCK) {
+                const int g = i / 3, k = i - g * 3;
+                dL_dsh[(size_t)base * 3 + i] = lds[g * stride + k];
+            }
+            const int Mr = L - 3;
+            float* dr = dL_dsh_rest + (size_t)base * Mr;
+            if (((cnt * Mr) & 3) == 0 && (((uintptr_t)dr) & 15) == 0) {
+                float4* d4 = reinterpret_cast<float4*>(dr);
+                for (int i = threadIdx.x; i < ((cnt * Mr) >> 2); i += DGM_PRE_BLOCK) {
+                    float e4[4];
+                    const int e = i << 2;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int g = (e + c) / Mr, k = (e + c) - g * Mr;
+                        e4[c] = lds[g * stride + 3 + k];
+                    }
+                    d4[i] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                }
+            } else {
+                for (int i = threadIdx.x; i < cnt * Mr; i += DGM_PRE_BLOCK) {
+                    const int g = i / Mr, k = i - g * Mr;
+                    dr[i] = lds[g * stride + 3 + k];
+                }
+            }
+        } else if ((L & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
             float4* d4 = reinterpret_cast<float4*>(dst);
             for (int i = threadIdx.x; i < (total >> 2); i += DGM_PRE_BLOCK) {
                 const int e = i << 2;
@@ -381,19 +431,20 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
 }
 
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
-                           const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
+                           const float* shs, const float* shs_rest, const uint8_t* clamped, const float* scales,
+                           const float* rotations,
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
                            const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
                            const float* rec, const unsigned* tiles_touched, const unsigned* offs, const float* slab,
                            float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
-                           float* dL_dsh, float* dL_dscale, float* dL_drot) {
+                           float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot) {
     const size_t lds_bytes = (shs != nullptr && M > 0) ? (size_t)DGM_PRE_BLOCK * ((3 * M) | 1) * sizeof(float) : 16;
     const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, gridx, means3D,
-                       radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, viewmatrix, projmatrix, campos,
+                       radii, shs, shs_rest, clamped, scales, rotations, scale_modifier, cov3Ds, viewmatrix, projmatrix, campos,
                        focal_x, focal_y, tan_fovx, tan_fovy, W, H, rec, tiles_touched, offs, slab,
-                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot);
 }
 
 }  // namespace dgm

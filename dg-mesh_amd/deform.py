@@ -237,6 +237,9 @@ class _ModelWrapper:
 
     def __init__(self, net, lr_scale, model_name, final_lr_scale=1.0):
         setattr(self, self.net_attr, net)
+        if getattr(net, "trunk_impl", None) == "hip":  # head weights back to back: read in place by the fused kernels
+            from . import mlp_hip
+            mlp_hip.pack_heads(net.head_modules())
         self.optimizer = None
         self.spatial_lr_scale = lr_scale
         self.final_lr_scale = final_lr_scale

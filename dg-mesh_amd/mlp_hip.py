@@ -16,14 +16,51 @@ def _params(net, W, b, Wh, bh, t_dim):
     return p
 
 
+def _adjacent(ts):
+    """True when the tensors lie back to back in memory, in order (fp32, contiguous)."""
+    at = ts[0].data_ptr()
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() != at:
+            return False
+        at += 4 * t.numel()
+    return True
+
+
+def _stacked(ts, shape):
+    """The head tensors as ONE (n_out, ...) tensor: a view of their common buffer when pack_heads() laid them out back to
+    back (no launch), else a concatenation."""
+    if _adjacent(ts):
+        stride = (shape[1], 1) if len(shape) == 2 else (1,)
+        return torch.as_strided(ts[0].detach(), shape, stride, ts[0].storage_offset())
+    return torch.cat([t.detach() for t in ts], 0).contiguous()
+
+
+def pack_heads(heads):
+    """Re-home the weights (and the biases) of the head modules in one buffer each, in output order.  The Parameters keep
+    their identity, names and shapes (state_dict / optimizers are unaffected); the fused kernels then read [Wh | bh] in
+    place instead of through two torch.cat launches per forward.  Moving the module to another device afterwards undoes
+    the layout (harmless: _stacked() falls back to concatenating)."""
+    with torch.no_grad():
+        for ts in ([m.weight for m in heads], [m.bias for m in heads]):
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            at = 0
+            for t in ts:
+                t.data = flat[at:at + t.numel()].view(t.shape)
+                at += t.numel()
+
+
 class _MLPFunction(torch.autograd.Function):
-    """inputs: x (N,3) [no grad], t_emb ((1,T) when broadcast else (N,T)), Wh, bh, W0..W7, b0..b7."""
+    """inputs: x (N,3) [no grad], t_emb ((1,T) when broadcast else (N,T)), the number of heads n, then the n head weights,
+    the n head biases, W0..W7, b0..b7."""
 
     @staticmethod
-    def forward(ctx, x, t_emb, bcast, Wh, bh, *wb):
+    def forward(ctx, x, t_emb, bcast, n_heads, *tensors):
         L = _lib.lib()
+        hw, hb, wb = tensors[:n_heads], tensors[n_heads:2 * n_heads], tensors[2 * n_heads:]
+        n_out = sum(w.shape[0] for w in hw)
+        Wh, bh = _stacked(hw, (n_out, hw[0].shape[1])), _stacked(hb, (n_out,))
         W, b = [w.contiguous() for w in wb[:8]], [v.contiguous() for v in wb[8:]]
-        x, t_emb, Wh, bh = x.contiguous(), t_emb.contiguous(), Wh.contiguous(), bh.contiguous()
+        x, t_emb = x.contiguous(), t_emb.contiguous()
         N, T = x.shape[0], t_emb.shape[1]
         ws = torch.empty(L.dgm_mlp_workspace_bytes(N), dtype=torch.uint8, device=x.device)
         out = torch.empty((N, Wh.shape[0]), dtype=torch.float32, device=x.device)
@@ -33,7 +70,7 @@ class _MLPFunction(torch.autograd.Function):
             _lib.check(L.dgm_mlp_forward(ctypes.byref(p), N, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(t_emb.data_ptr()),
                                          0 if bcast else T, ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), st))
         ctx.save_for_backward(ws, Wh, bh, *W, *b)
-        ctx.meta = (N, T, bool(bcast), t_emb.requires_grad)
+        ctx.meta = (N, T, bool(bcast), t_emb.requires_grad, [w.shape[0] for w in hw])
         return out
 
     @staticmethod
@@ -41,7 +78,7 @@ class _MLPFunction(torch.autograd.Function):
         L = _lib.lib()
         ws, Wh, bh, *wb = ctx.saved_tensors
         W, b = wb[:8], wb[8:]
-        N, T, bcast, need_t = ctx.meta
+        N, T, bcast, need_t, head_rows = ctx.meta
         dOut = dOut.contiguous()
         dev = dOut.device
         dW = [torch.empty_like(w) for w in W]
@@ -57,7 +94,9 @@ class _MLPFunction(torch.autograd.Function):
             _lib.check(L.dgm_mlp_backward(ctypes.byref(p), N, ctypes.c_void_p(dOut.data_ptr()), 0 if bcast else T,
                                           ctypes.c_void_p(ws.data_ptr()), dWp, dbp, ctypes.c_void_p(dWh.data_ptr()),
                                           ctypes.c_void_p(dbh.data_ptr()), ctypes.c_void_p(dtemb.data_ptr()), st))
-        return (None, dtemb if need_t else None, None, dWh, dbh, *dW, *db)
+        # the heads' gradients: row blocks of the two stacked buffers (contiguous views, no copies)
+        dWs, dbs = torch.split(dWh, head_rows, 0), torch.split(dbh, head_rows, 0)
+        return (None, dtemb if need_t else None, None, None, *dWs, *dbs, *dW, *db)
 
 
 class _TimeNetFunction(torch.autograd.Function):
@@ -130,8 +169,6 @@ def network_forward(net, heads, x, t_emb, bcast):
         raise RuntimeError("trunk_impl='hip' does not differentiate w.r.t. the positions (the training loop detaches them, "
                            "R/train.py:156); pass xyz.detach() or use trunk_impl='torch'")
     check_supported(net, heads, t_emb)
-    Wh = torch.cat([m.weight for m in heads], 0)
-    bh = torch.cat([m.bias for m in heads], 0)
     W = [l.weight for l in net.linear]
     b = [l.bias for l in net.linear]
-    return _MLPFunction.apply(x, t_emb, bcast, Wh, bh, *W, *b)
+    return _MLPFunction.apply(x, t_emb, bcast, len(heads), *[m.weight for m in heads], *[m.bias for m in heads], *W, *b)

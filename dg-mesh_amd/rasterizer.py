@@ -200,6 +200,74 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_cov3Ds_precomp, None)
 
 
+class _RasterizeGaussiansSplitSH(torch.autograd.Function):
+    """The training loop's variant of _RasterizeGaussians: SH coefficients as the model stores them, in two tensors
+    (features_dc (P,1,3), features_rest (P,M-1,3)), scales / rotations given, no precomputed colours or covariances.
+    Same kernels through dgm_rasterize_{forward,backward}_split_sh; what it saves is get_features' torch.cat and the two
+    strided copies autograd needs to split that concatenation's gradient again."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh_dc, sh_rest, opacities, scales, rotations, raster_settings):
+        rs = raster_settings
+        if means3D.ndimension() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        L = _lib.lib()
+        P, H, W = means3D.size(0), int(rs.image_height), int(rs.image_width)
+        if sh_dc.shape != (P, 1, 3) or sh_rest.dim() != 3 or sh_rest.shape[0] != P or sh_rest.shape[2] != 3 or sh_rest.shape[1] < 1:
+            raise RuntimeError("split SH: features_dc (P,1,3) and features_rest (P,M-1,3) required")
+        dev = means3D.device
+        means3D, opacities = _f32c(means3D, "means3D"), _f32c(opacities, "opacity")
+        scales, rotations = _f32c(scales, "scales"), _f32c(rotations, "rotations")
+        sh_dc, sh_rest = _f32c(sh_dc, "features_dc"), _f32c(sh_rest, "features_rest")
+        bg, view, proj, campos = (_f32c(rs.bg, "background"), _f32c(rs.viewmatrix, "viewmatrix"),
+                                  _f32c(rs.projmatrix, "projmatrix"), _f32c(rs.campos, "campos"))
+        out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom, binning, img = (torch.empty((0,), dtype=torch.uint8, device=dev) for _ in range(3))
+        M = 1 + sh_rest.shape[1]
+        rendered = ctypes.c_int(0)
+        cbs = (_resizer(geom), _resizer(binning), _resizer(img))
+        t_call = time.perf_counter()
+        with torch.cuda.device(dev):
+            _lib.check(L.dgm_rasterize_forward_split_sh(
+                cbs[0], None, cbs[1], None, cbs[2], None, P, int(rs.sh_degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh_dc),
+                _ptr(sh_rest), None, _ptr(opacities), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), None, _ptr(view),
+                _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), _ptr(out_color),
+                _ptr(radii), int(bool(rs.debug)), _stream(), ctypes.byref(rendered)))
+        global LAST_NUM_RENDERED, FORWARD_CALL_SECONDS
+        LAST_NUM_RENDERED = rendered.value
+        FORWARD_CALL_SECONDS += time.perf_counter() - t_call
+        ctx.raster_settings, ctx.num_rendered, ctx.consts = rs, rendered.value, (bg, view, proj, campos)
+        ctx.save_for_backward(means3D, scales, rotations, radii, sh_dc, sh_rest, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return out_color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        L = _lib.lib()
+        rs = ctx.raster_settings
+        means3D, scales, rotations, radii, sh_dc, sh_rest, geom, binning, img = ctx.saved_tensors
+        bg, view, proj, campos = ctx.consts
+        P, dev = means3D.size(0), means3D.device
+        dL = _f32c(grad_out_color, "dL_dout_color")
+        H, W = dL.size(1), dL.size(2)
+        M = 1 + sh_rest.shape[1]
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors = new(P, 3), new(P, 3), new(P, NUM_CHANNELS)
+        dL_dconic, dL_dopacity, dL_dcov3D = new(P, 2, 2), new(P, 1), new(P, 6)
+        dL_dscales, dL_drotations = new(P, 3), new(P, 4)
+        dL_ddc, dL_drest = torch.empty_like(sh_dc), torch.empty_like(sh_rest)
+        if P != 0:
+            with torch.cuda.device(dev):
+                _lib.check(L.dgm_rasterize_backward_split_sh(
+                    P, int(rs.sh_degree), M, int(ctx.num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh_dc), _ptr(sh_rest),
+                    None, _ptr(scales), float(rs.scale_modifier), _ptr(rotations), None, _ptr(view), _ptr(proj), _ptr(campos),
+                    float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img), _ptr(dL),
+                    _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                    _ptr(dL_ddc), _ptr(dL_drest), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(rs.debug)), _stream()))
+        return dL_dmeans3D, dL_dmeans2D, dL_ddc, dL_drest, dL_dopacity, dL_dscales, dL_drotations, None
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -240,3 +308,9 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+
+    def forward_split_sh(self, means3D, means2D, opacities, shs_dc, shs_rest, scales, rotations):
+        """forward(shs=cat(shs_dc, shs_rest, 1), scales=..., rotations=...) without forming the concatenation: the two SH
+        tensors of the model (features_dc (P,1,3), features_rest (P,M-1,3)) go to the kernels as they are."""
+        return _RasterizeGaussiansSplitSH.apply(means3D, means2D, shs_dc, shs_rest, opacities, scales, rotations,
+                                                self.raster_settings)

@@ -211,10 +211,21 @@ class GaussianModel:
         """The per-iteration bookkeeping of R/train.py:489-496 (max_radii2D of the visible Gaussians, then
         add_densification_stats) written with masks instead of boolean indexing: identical values, but no
         nonzero() and hence no host synchronisation inside the step."""
-        vis = visibility_filter
+        g = None if viewspace_point_tensor is None else viewspace_point_tensor.grad
+        f32c = lambda t: t.dtype == torch.float32 and t.is_contiguous()
+        if radii.is_cuda and radii.dtype == torch.int32 and radii.is_contiguous() and f32c(self.max_radii2D) and \
+                (g is None or (f32c(g) and g.shape[1] == 3 and f32c(self.xyz_gradient_accum) and f32c(self.denom))):
+            # one launch instead of seven elementwise ones (csrc/densify.hip: densify_stats_kernel)
+            from . import _lib
+            from .densify import _stream, _vp
+            P = radii.shape[0]
+            with torch.cuda.device(radii.device):
+                _lib.check(_lib.lib().dgm_densify_stats(P, None if g is None else _vp(g), _vp(radii), _vp(self.max_radii2D),
+                                                        _vp(self.xyz_gradient_accum), _vp(self.denom), _stream()))
+            return
+        vis = visibility_filter if visibility_filter is not None else radii > 0
         r = radii.to(self.max_radii2D.dtype)
         self.max_radii2D = torch.where(vis, torch.maximum(self.max_radii2D, r), self.max_radii2D)
-        g = None if viewspace_point_tensor is None else viewspace_point_tensor.grad
         if g is not None:
             self.xyz_gradient_accum += torch.norm(g[:, :2], dim=-1, keepdim=True) * vis.unsqueeze(-1)
             self.denom += vis.unsqueeze(-1).to(self.denom.dtype)
@@ -298,17 +309,23 @@ def eval_sh(deg, sh, dirs):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, is_6dof=False, scaling_modifier=1.0,
-           override_color=None, delta=None):
+           override_color=None, delta=None, lean=False):
     """R/gaussian_renderer/__init__.py:32-119.  viewpoint_camera needs FoVx, FoVy, image_height, image_width,
     world_view_transform, full_proj_transform, camera_center (torch tensors on the GPU).
     delta: optionally the deformation network's raw (P, >= 10) output [d_xyz | d_rotation | d_scaling | ...] instead of
-    the three slices; activations + deformation then run as one fused kernel (glue.gaussian_apply)."""
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
-                                          device=pc.get_xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    the three slices; activations + deformation then run as one fused kernel (glue.gaussian_apply).
+    lean: the training loop's variant -- `viewspace_points` is an uninitialised leaf (the rasterizer never reads its
+    values, only routes dL/dmeans2D into its .grad) and `visibility_filter` is None (track_densification_stats derives it
+    from `radii`): three elementwise launches fewer per step."""
+    if lean:
+        screenspace_points = torch.empty_like(pc.get_xyz).requires_grad_(True)
+    else:
+        screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
+                                              device=pc.get_xyz.device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(
@@ -340,17 +357,25 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, i
         cov3D_precomp, scales, rotations = pc.get_covariance(scaling_modifier), None, None
     shs = None
     colors_precomp = override_color
-    if colors_precomp is None:
+    # lean: the two SH tensors go to the kernels unconcatenated (GaussianRasterizer.forward_split_sh)
+    split_sh = (lean and colors_precomp is None and not getattr(pipe, "convert_SHs_python", False) and cov3D_precomp is None
+                and means3D.is_cuda and pc._features_rest.shape[1] > 0)
+    if colors_precomp is None and not split_sh:
         if getattr(pipe, "convert_SHs_python", False):  # as in the reference: view directions from the CANONICAL xyz
             shs_view = pc.get_features.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2)
             dir_pp = pc.get_xyz - viewpoint_camera.camera_center.reshape(1, 3)
             colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True)) + 0.5, 0.0)
         else:
             shs = pc.get_features
-    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "radii": radii, "means3D": means3D}
+    if split_sh:
+        rendered_image, radii = rasterizer.forward_split_sh(means3D, means2D, opacity, pc._features_dc, pc._features_rest,
+                                                            scales, rotations)
+    else:
+        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                           opacities=opacity, scales=scales, rotations=rotations,
+                                           cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points,
+            "visibility_filter": None if lean else radii > 0, "radii": radii, "means3D": means3D}
 
 
 def l1_loss(network_output, gt):

@@ -225,6 +225,7 @@ class Trainer:
         losses = {}
         if delta is not None:
             from .glue import cycle_loss
+            lean = {"lean": True} if self.render_fn is S.render else {}
             if self.world > 1 and self._early is not None:
                 # Data parallel with the early Gaussian-bucket all-reduce: build the cycle branch BEFORE the render branch.
                 # Autograd runs later-built branches first, so the rasterizer's backward -- after which the Gaussian
@@ -234,9 +235,9 @@ class Trainer:
                 means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
                 back = self.deform_back.step_raw(means, self.time_input(cam, N, iteration))
                 losses["cycle_loss"] = cycle_loss(delta, back)
-                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta)
+                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta, **lean)
             else:
-                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta)
+                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta, **lean)
                 back = self.deform_back.step_raw(pkg["means3D"].detach(), self.time_input(cam, N, iteration))
                 losses["cycle_loss"] = cycle_loss(delta, back)
         else:
@@ -270,7 +271,10 @@ class Trainer:
         else:
             self.bucket.zero()
         losses, pkg = self.loss_terms(cam, iteration)
-        loss = sum(losses.values())
+        terms = list(losses.values())
+        loss = terms[0]
+        for t in terms[1:]:  # (not sum(): its 0 + ... start is one more launch)
+            loss = loss + t
         if self._early is not None:
             self._early.update(left=self._early["n"], work=None, views=None, armed=True)
         loss.backward()
@@ -278,7 +282,7 @@ class Trainer:
             self._early["armed"] = False
         rebound = False
         if self.track_stats and iteration < self.opt.densify_until_iter:  # R/train.py:488-496
-            g.track_densification_stats(pkg.get("viewspace_points"), pkg["visibility_filter"], pkg["radii"])
+            g.track_densification_stats(pkg.get("viewspace_points"), pkg.get("visibility_filter"), pkg["radii"])
             if self.densify:
                 rebound = self.maybe_densify(iteration)
         grads = None

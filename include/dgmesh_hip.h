@@ -81,6 +81,28 @@ int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, 
                            float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                            float* dL_dscale, float* dL_drot, int debug, void* stream);
 
+/* The same two calls for SH coefficients stored in two tensors, as the reference's model keeps them (_features_dc (P,1,3)
+ * and _features_rest (P,M-1,3), gaussian_model_dpsr_dynamic_anchor.py:135-138): shs = the DC rows, shs_rest = the others;
+ * the backward writes dL_dsh (P,1,3) and dL_dsh_rest (P,M-1,3).  Spares the caller torch.cat (get_features) and the
+ * strided split of its gradient.  shs_rest == NULL (and dL_dsh_rest == NULL): exactly the calls above. */
+int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                                   dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                                   int width, int height, const float* means3D, const float* shs, const float* shs_rest,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                                   int* num_rendered);
+int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* background, int width, int height,
+                                    const float* means3D, const float* shs, const float* shs_rest,
+                                    const float* colors_precomp, const float* scales, float scale_modifier,
+                                    const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                    const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                    const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                                    const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                    float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
+                                    float* dL_dscale, float* dL_drot, int debug, void* stream);
+
 /* present: (P) bytes, 1 = view-space z > 0.2 */
 int dgm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream);
@@ -276,6 +298,11 @@ int dgm_adam_step(int n_tensors, float* const* params, const float* const* grads
  *   dgm_densify_apply: out[t][j] = in[t][source(j)] for all n_tensors (<= 24) tensors of row width width[t] floats; rows of
  *     new points are zero where is_moment[t] != 0; the xyz / scaling rows of split children are rewritten from the
  *     caller's standard-normal samples z[2][P][3] (device).  src_scratch: (K + C + 2 S) * 4 bytes. */
+/* Per-iteration statistics (dgmesh/train.py:489-496, gaussian_model_dpsr_dynamic_anchor.py:679-682), in place, for the
+ * Gaussians with radii > 0: max_radii2D = max(max_radii2D, radii); with grad2d != NULL (dL/dmeans2D, (P,3)) also
+ * grad_accum += |grad2d[:, :2]| and denom += 1.  All (P) fp32 on the device. */
+int dgm_densify_stats(int P, const float* grad2d, const int* radii, float* max_radii2D, float* grad_accum, float* denom,
+                      void* stream);
 size_t dgm_densify_scratch_bytes(int P);
 size_t dgm_densify_totals_offset(int P);
 int dgm_densify_decide(int P, const float* grad_accum, const float* denom, const float* scaling, const float* opacity,

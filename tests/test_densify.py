@@ -218,3 +218,35 @@ def test_dp2_replicas_stay_identical_through_a_densify_step():
         assert torch.equal(a, b)
     for a, b in zip(r0["moments"], r1["moments"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_stats_kernel_equals_reference_indexing():
+    """dgm_densify_stats (one launch; what GaussianModel.track_densification_stats uses on the GPU) == the reference's
+    boolean-index bookkeeping (train.py:489-496 + add_densification_stats, gaussian_model_dpsr_dynamic_anchor.py:679-682):
+    max_radii2D and denom bit-equal, the gradient-norm accumulator to fp32 rounding.  Also the lean form: no filter given,
+    no gradient (max_radii2D only)."""
+    S = pkg("scene")
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(3)
+    for P in (1, 255, 1000):
+        g1, g2 = S.GaussianModel(sh_degree=3, device=dev), S.GaussianModel(sh_degree=3, device=dev)
+        raw = [rng.randn(P, 3), rng.randn(P, 1, 3), rng.randn(P, 15, 3), rng.randn(P, 3), rng.randn(P, 4), rng.randn(P, 1)]
+        for g in (g1, g2):
+            g.load_raw(*raw)
+            g.training_setup(S.OptimizationParams())
+        for step in range(3):
+            vp = torch.zeros(P, 3, device=dev, requires_grad=True)
+            vp.grad = torch.tensor(rng.randn(P, 3).astype(np.float32), device=dev)
+            radii = torch.tensor(rng.randint(0, 40, P).astype(np.int32), device=dev)
+            vis = radii > 0
+            g1.max_radii2D[vis] = torch.max(g1.max_radii2D[vis], radii[vis].to(g1.max_radii2D.dtype))
+            g1.add_densification_stats(vp, vis)
+            g2.track_densification_stats(vp, None, radii)
+        assert torch.equal(g1.max_radii2D, g2.max_radii2D) and torch.equal(g1.denom, g2.denom)
+        assert torch.allclose(g1.xyz_gradient_accum, g2.xyz_gradient_accum, rtol=1e-6, atol=0)
+        before = (g2.xyz_gradient_accum.clone(), g2.denom.clone())
+        radii = torch.full((P,), 77, dtype=torch.int32, device=dev)
+        g2.track_densification_stats(None, None, radii)
+        assert bool((g2.max_radii2D == 77).all())
+        assert torch.equal(before[0], g2.xyz_gradient_accum) and torch.equal(before[1], g2.denom)

@@ -315,6 +315,42 @@ def test_module_api_autograd(orc, syn):
                                     rs.campos, False, False)
 
 
+@pytest.mark.parametrize("P,degree", [(3000, 3), (257, 3), (1000, 1), (700, 0)])
+def test_split_sh_equals_concatenated(syn, P, degree):
+    """GaussianRasterizer.forward_split_sh (features_dc / features_rest handed over as two tensors) is the same computation as
+    forward(shs=cat(dc, rest)): image, radii and every gradient bit-equal; the two SH gradients are the two slices of dL_dsh.
+    Sizes cover a tail block whose row count is not a multiple of four (scalar staging) and lower active degrees."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H = 160, 112
+    a = raster_args(syn, P, W, H, seed=5, kind="aniso", bg=(0.2, 0.4, 0.6))
+    dev = "cuda"
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=a["tanfovx"], tanfovy=a["tanfovy"], bg=torch.tensor(a["bg"], device=dev),
+        scale_modifier=1.0, viewmatrix=torch.tensor(a["viewmatrix"], device=dev),
+        projmatrix=torch.tensor(a["projmatrix"], device=dev), sh_degree=degree, campos=torch.tensor(a["campos"], device=dev),
+        prefiltered=False, debug=False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    dL = torch.tensor(np.random.RandomState(3).randn(3, H, W).astype(np.float32), device=dev)
+    out = []
+    for split in (False, True):
+        leaf = {k: torch.tensor(a[k], device=dev, requires_grad=True) for k in ("means3D", "opacities", "scales", "rotations")}
+        dc = torch.tensor(a["sh"][:, :1].copy(), device=dev, requires_grad=True)
+        rest = torch.tensor(a["sh"][:, 1:].copy(), device=dev, requires_grad=True)
+        means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+        if split:
+            img, radii = rast.forward_split_sh(leaf["means3D"], means2D, leaf["opacities"], dc, rest, leaf["scales"],
+                                               leaf["rotations"])
+        else:
+            img, radii = rast(means3D=leaf["means3D"], means2D=means2D, shs=torch.cat((dc, rest), 1), colors_precomp=None,
+                              opacities=leaf["opacities"], scales=leaf["scales"], rotations=leaf["rotations"],
+                              cov3D_precomp=None)
+        (img * dL).sum().backward()
+        out.append([img.detach(), radii, means2D.grad, dc.grad, rest.grad] + [leaf[k].grad for k in sorted(leaf)])
+    for x, y in zip(*out):
+        assert x.shape == y.shape and torch.equal(x, y)
+    assert float(out[1][3].abs().sum()) > 0 and (degree == 0 or float(out[1][4].abs().sum()) > 0)
+
+
 def test_knn_exact(orc, syn):
     from simple_knn._C import distCUDA2
     rng = np.random.RandomState(0)

@@ -181,3 +181,37 @@ def test_time_noise_schedule_and_shape():
     t2 = tr.time_input(Cam, 7, 5000)
     assert t2.stride(0) == 0 and float(t2[0, 0]) != 0.25 and abs(float(t2[0, 0]) - 0.25) < 0.01 * 0.1 * 6
     assert torch.equal(t2[0], t2[6])
+
+
+def test_pack_heads_keeps_the_module_and_makes_the_heads_adjacent():
+    """mlp_hip.pack_heads: head weights / biases re-homed back to back in output order (what lets the fused kernels read
+    [Wh | bh] in place, without torch.cat) -- same outputs, same state_dict names and shapes, the layout survives
+    load_state_dict, and _stacked() is then a view of the parameters' own memory."""
+    import torch
+    D, M = pkg("deform"), pkg("mlp_hip")
+    torch.manual_seed(0)
+    net = D.DeformNetworkNormal(is_blender=True, trunk_impl="torch")
+    x, t = torch.randn(17, 3), torch.full((17, 1), 0.3)
+    before = [o.detach().clone() for o in net(x, t)]
+    keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    heads = net.head_modules()
+    assert not M._adjacent([m.weight for m in heads])
+    ids = [id(p) for p in net.parameters()]
+    M.pack_heads(heads)
+    assert M._adjacent([m.weight for m in heads]) and M._adjacent([m.bias for m in heads])
+    assert ids == [id(p) for p in net.parameters()]
+    assert keys == [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    for a, b in zip(before, net(x, t)):
+        assert torch.equal(a, b)
+    n_out = sum(m.weight.shape[0] for m in heads)
+    Wh = M._stacked([m.weight for m in heads], (n_out, 256))
+    assert Wh.data_ptr() == heads[0].weight.data_ptr() and torch.equal(Wh, torch.cat([m.weight for m in heads], 0))
+    bh = M._stacked([m.bias for m in heads], (n_out,))
+    assert bh.data_ptr() == heads[0].bias.data_ptr() and torch.equal(bh, torch.cat([m.bias for m in heads], 0))
+    sd = {k: torch.randn_like(v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    assert M._adjacent([m.weight for m in heads]) and torch.equal(heads[1].weight, sd["gaussian_rotation.weight"])
+    # an optimizer step through the parameters is visible through the stacked view (no stale copy)
+    with torch.no_grad():
+        heads[2].weight.add_(1.0)
+    assert torch.equal(M._stacked([m.weight for m in heads], (n_out, 256)), torch.cat([m.weight for m in heads], 0))
