@@ -382,10 +382,6 @@ __global__ void mlp_reduce_dw_kernel(int chunks, int db_chunks, int Kp, int in_f
 }
 
 // The same reduction in ONE pass for the matrix-core paths (256 partial tiles of 256 KB per layer: the read is the cost).
-// Workgroup = a 2 x 32 piece of the (k, j) plane as 16 float4 positions, times 16 groups of chunks: every thread streams
-// its group's chunks with sixteen 16-byte loads in flight (one round for the usual 256 chunks), the sixteen group sums
-// meet in LDS (fixed order), and the piece is written transposed into the PyTorch (out, in) layout.  The first 32
-// workgroups also reduce eight columns each of the bias-gradient rows (db_rows of them).
 struct ReduceDwJob {
     int chunks, db_rows, Kp, in_features, nblocks;
     const float* partial;
@@ -398,10 +394,21 @@ struct ReduceDwBatch {
     ReduceDwJob job[8];
 };
 // All eight layers of a network in ONE launch at the end of its backward pass (blockIdx.y = layer; every layer keeps its own
-// partial tiles until then): seven launches and their ramps fewer per pass, and the bias-gradient rows ride along.
+// partial tiles until then).  Workgroup = a KT x JT piece of the (k, j) plane as 64 float4 positions (one wave-wide load =
+// KT row segments of JT * 4 contiguous bytes of one partial tile), times four groups of chunks (the four waves): every
+// thread streams its group's chunks with sixteen 16-byte loads in flight, the four group sums meet in LDS (fixed order), and
+// the piece is written transposed into the PyTorch (out, in) layout.  With eight layers in the grid there are enough
+// workgroups (>= 2048) to read in segments of 256+ bytes and still fill the chip, which a single layer's launch could not.
+// The first 32 workgroups of a layer also reduce eight columns each of its bias-gradient rows (db_rows of them).
+#ifndef RDW_KT
+#define RDW_KT 4
+#endif
+static constexpr int RDW_JT = 256 / RDW_KT;  // KT * JT = 256 elements per workgroup
+static inline int reduce_dw_blocks(int Kp) { return (Kp / RDW_KT) * (MLP_W / RDW_JT); }
 __global__ void __launch_bounds__(256)
 mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
-    __shared__ float4 red[16][16];
+    constexpr int KT = RDW_KT, JT = RDW_JT, JQ = JT / 4, JB = MLP_W / JT;
+    __shared__ float4 red[4][64];
     __shared__ float redb[32][8];
     const ReduceDwJob& jb = rb.job[blockIdx.y];
     if ((int)blockIdx.x >= jb.nblocks) return;
@@ -410,11 +417,11 @@ mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
     const float* __restrict__ partial_db = jb.partial_db;
     float* __restrict__ dW = jb.dW;
     float* __restrict__ db = jb.db;
-    const int tid = threadIdx.x, pos = tid & 15, grp = tid >> 4;
-    const int k0 = (blockIdx.x >> 3) * 2, j0 = (blockIdx.x & 7) * 32;
+    const int tid = threadIdx.x, pos = tid & 63, grp = tid >> 6;
+    const int k0 = ((int)blockIdx.x / JB) * KT, j0 = ((int)blockIdx.x % JB) * JT;
     {
-        const int k = k0 + (pos >> 3), j = j0 + (pos & 7) * 4;
-        const int per = (chunks + 15) >> 4;
+        const int k = k0 + pos / JQ, j = j0 + (pos % JQ) * 4;
+        const int per = (chunks + 3) >> 2;
         const int c1 = min(chunks, (grp + 1) * per);
         int c = grp * per;
         const size_t cs = (size_t)Kp * MLP_W;
@@ -448,23 +455,21 @@ mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
         redb[g32][tid & 7] = s;
     }
     __syncthreads();
-    if (tid < 64) {  // thread -> column j0 + tid / 2, row k0 + tid % 2
-        const int jj = tid >> 1, kk = tid & 1;
-        const float* r = reinterpret_cast<const float*>(&red[0][0]) + (kk * 8 + (jj >> 2)) * 4 + (jj & 3);
-        float s = r[0];
-#pragma unroll
-        for (int g = 1; g < 16; g++) s += r[g * 64];
+    {   // thread -> row k0 + tid % KT, column j0 + tid / KT: consecutive threads write consecutive k of one output row
+        const int kk = tid % KT, jj = tid / KT;
+        const float* r = reinterpret_cast<const float*>(&red[0][0]) + (kk * JQ + (jj >> 2)) * 4 + (jj & 3);
+        const float s = ((r[0] + r[256]) + r[512]) + r[768];
         const int k = k0 + kk;
         int dst;
         if (Kp == MLP_W) dst = k;
         else if (k < MLP_EMB) dst = k < emb_dim ? k : -1;
         else dst = k - MLP_EMB + emb_dim;
         if (dst >= 0) dW[(size_t)(j0 + jj) * in_features + dst] = s;
-    } else if (do_db && tid < 72) {
-        const int c = tid - 64;
-        float s = redb[0][c];
-        for (int g = 1; g < 32; g++) s += redb[g][c];
-        db[blockIdx.x * 8 + c] = s;
+    }
+    if (do_db && tid < 8) {
+        float s = redb[0][tid];
+        for (int g = 1; g < 32; g++) s += redb[g][tid];
+        db[blockIdx.x * 8 + tid] = s;
     }
 }
 
@@ -1155,7 +1160,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
                                    K2, G, w.partial_l[l], w.partial_db_l[l]);
             ReduceDwJob& jb = rb.job[l];
-            jb.chunks = d.chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = Kp / 2 * 8;
+            jb.chunks = d.chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = reduce_dw_blocks(Kp);
             jb.partial = w.partial_l[l], jb.partial_db = w.partial_db_l[l], jb.dW = dW[l], jb.db = db[l];
             if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;
         }
