@@ -91,3 +91,38 @@ def test_dp2_pack_mode_on_gpu():
         assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (k, (a - b).abs().max())
     fresh = snapshot(make_trainer(0, 1))
     assert any(not torch.equal(a, b) for a, b in zip(r0, fresh))
+
+
+@pytest.mark.gpu
+def test_lean_step_equals_the_reference_shaped_step():
+    """The training loop's lean render (SH tensors unconcatenated through dgm_rasterize_*_split_sh, uninitialised leaf for
+    the screen-space gradient, no visibility mask; head weights read in place) against the same Trainer driving render() the
+    way the reference calls it (get_features' torch.cat, zeros + 0, radii > 0): after three steps every parameter and the
+    densification statistics are bit-equal, and the lean step launches no torch.cat at all.  (The statistics kernel itself is
+    checked against the reference's indexing form in test_densify.py.)"""
+    S = pkg("scene")
+    a = make_trainer(0, 1)
+    b = make_trainer(0, 1)
+    b.render_fn = lambda *args, **kw: S.render(*args, **kw)  # not `S.render` itself -> Trainer does not ask for lean
+    calls = {"cat": 0}
+    cat = torch.cat
+
+    def counting_cat(*args, **kw):
+        calls["cat"] += 1
+        return cat(*args, **kw)
+
+    it = a.opt.warm_up + 10
+    for s in range(3):
+        torch.cat = counting_cat
+        try:
+            a.step(it + s)
+        finally:
+            torch.cat = cat
+        b.step(it + s)
+    assert calls["cat"] == 0, "the lean step still concatenates something"
+    torch.cuda.synchronize()
+    for x, y in zip(snapshot(a), snapshot(b)):
+        assert torch.equal(x, y)
+    assert torch.equal(a.g.max_radii2D, b.g.max_radii2D) and torch.equal(a.g.denom, b.g.denom)
+    assert float(a.g.denom.sum()) > 0
+    assert torch.equal(a.g.xyz_gradient_accum, b.g.xyz_gradient_accum) and float(a.g.xyz_gradient_accum.sum()) > 0
