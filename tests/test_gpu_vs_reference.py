@@ -160,6 +160,115 @@ def test_reference_kernels_timed_beside_ours(syn):
     assert ms_our < min(ms_ref, ms_fma)
 
 
+def test_reference_shaped_train_step_timed_beside_ours():
+    """The WHOLE cfg2 train step the way the reference runs it, on the same MI355X: its rasterizer kernels (oracle/_ref)
+    behind an autograd.Function, and everything else as the reference does it under PyTorch-ROCm -- nn.Linear networks,
+    get_features' torch.cat, activations / deltas as elementwise ops, l1 + SSIM as five grouped convolutions, the cycle loss
+    as torch ops, boolean-index statistics, three torch.optim.Adam (train.py:129-321, 517-530; without its per-iteration
+    torch.cuda.empty_cache()).  Against bench.py's Trainer on the same scene.  Numbers -> gpurun_out/ref_vs_ours_step.json."""
+    import importlib
+    import json
+    import math
+    import os
+    import sys
+    import time
+
+    import torch
+
+    from conftest import ROOT, pkg
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    S, T = pkg("scene"), pkg("trainer")
+    L = R.lib("_fma")
+    p = R.p
+
+    class RefRaster(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, sh, opac, scales, rots, cam, bg, degree):
+            P, M = means3D.shape[0], sh.shape[1]
+            H, W = int(cam.image_height), int(cam.image_width)
+            tx, ty = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+            means3D, sh, opac, scales, rots = [x.contiguous() for x in (means3D, sh, opac, scales, rots)]
+            color = torch.zeros(3, H, W, device="cuda")
+            radii = torch.zeros(P, dtype=torch.int32, device="cuda")
+            n = L.ref_forward(P, degree, M, p(bg), W, H, p(means3D), p(sh), None, p(opac), p(scales), 1.0, p(rots), None,
+                              p(cam.world_view_transform), p(cam.full_proj_transform), p(cam.camera_center), tx, ty, p(color),
+                              p(radii), None)
+            ctx.save_for_backward(means3D, sh, scales, rots, radii)
+            ctx.misc = (cam, bg, degree, n, tx, ty)
+            ctx.mark_non_differentiable(radii)
+            return color, radii
+
+        @staticmethod
+        def backward(ctx, dL, _):
+            means3D, sh, scales, rots, radii = ctx.saved_tensors
+            cam, bg, degree, n, tx, ty = ctx.misc
+            P, M = means3D.shape[0], sh.shape[1]
+            H, W = int(cam.image_height), int(cam.image_width)
+            z = lambda *s: torch.zeros(s, device="cuda")
+            g2, gcon, gop, gcol, g3, gcov, gsh, gsc, grot = (z(P, 3), z(P, 4), z(P, 1), z(P, 3), z(P, 3), z(P, 6), z(P, M, 3),
+                                                             z(P, 3), z(P, 4))
+            dL = dL.contiguous()
+            L.ref_backward(P, degree, M, n, p(bg), W, H, p(means3D), p(sh), None, p(scales), 1.0, p(rots), None,
+                           p(cam.world_view_transform), p(cam.full_proj_transform), p(cam.camera_center), tx, ty, p(radii), p(dL),
+                           p(g2), p(gcon), p(gop), p(gcol), p(g3), p(gcov), p(gsh), p(gsc), p(grot))
+            return g3, g2, gsh, gop, gsc, grot, None, None, None
+
+    def ref_render(cam, pc, pipe, bg, d_xyz, d_rotation, d_scaling, is_6dof=False, **kw):  # gaussian_renderer/__init__.py:32-119
+        screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
+        screenspace_points.retain_grad()
+        means3D = pc.get_xyz + d_xyz
+        color, radii = RefRaster.apply(means3D, screenspace_points, pc.get_features, pc.get_opacity, pc.get_scaling + d_scaling,
+                                       pc.get_rotation + d_rotation, cam, bg, pc.active_sh_degree)
+        return {"render": color, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+                "means3D": means3D}
+
+    dev = torch.device("cuda", 0)
+    bench.WORKLOAD = "cfg2"
+
+    def run(tr, steps=20, reference_stats=False):
+        it0 = tr.opt.warm_up + 2000
+        def one(i):
+            loss, pkg_ = tr.step(it0 + i)
+            if reference_stats:  # train.py:489-496, with the boolean indexing (and its nonzero() syncs) of the reference
+                with torch.no_grad():
+                    vis, radii, g = pkg_["visibility_filter"], pkg_["radii"], tr.g
+                    g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], radii[vis].to(g.max_radii2D.dtype))
+                    g.add_densification_stats(pkg_["viewspace_points"], vis)
+            return loss.item()  # train.py:315
+        for i in range(6):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(6 + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    ours, _ = bench.build_scene(dev, 0, 1, "hip")
+    ms_ours = run(ours)
+    del ours
+    base, _ = bench.build_scene(dev, 0, 1, "torch")  # same scene, the networks as nn.Linear stacks
+    ref = T.Trainer(base.g, base.deform, base.deform_back, base.cameras, background=base.bg, is_blender=True,
+                    render_fn=ref_render, fused_adam=False, fused_loss=False, fused_glue=False, track_stats=False)
+    assert ref.multi_adam is None and not ref.fused_glue
+    ref.pack, ref.bucket = True, None  # gradients set to None every step (zero_grad(set_to_none=True)), no flat bucket
+    for q in ref.params:
+        q.grad = None
+    ms_ref = run(ref, reference_stats=True)
+    rec = {"workload": "cfg2 train step (800x800, 100 k Gaussians, deform + deform_back), one MI355X, fp32",
+           "reference_shaped_ms_per_step": round(ms_ref, 3), "reference_shaped_it_s": round(1e3 / ms_ref, 1),
+           "this_library_ms_per_step": round(ms_ours, 3), "this_library_it_s": round(1e3 / ms_ours, 1),
+           "ratio": round(ms_ref / ms_ours, 2),
+           "reference_shaped": "reference rasterizer kernels (oracle/_ref, hipify-perl + hipcc -O3) + PyTorch-ROCm for the MLPs, "
+                               "activations, L1 + SSIM convolutions, cycle loss, statistics, 3 x torch.optim.Adam; no empty_cache()",
+           "timing": "20 steps after 6 warm-up steps, loss.item() every step on both sides"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "ref_vs_ours_step.json"), "w"), indent=1)
+    print(rec)
+    assert ms_ours < ms_ref
+
+
 def test_default_fma_contraction_moves_integers_rarely(orc, syn):
     """A build of the reference with hipcc's default -ffp-contract=fast is NOT bit-identical in radii / lists: this is
     why the parity definition fixes the contraction-free evaluation.  The drift must stay tiny."""
