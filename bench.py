@@ -323,6 +323,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(P, W, H)
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+        if WORKLOAD == "cfg2":  # informational, offline: the reference's own step on this GPU model (a -m gpu test measures it)
+            try:
+                r = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_vs_ours_step.json")))
+                out["reference_same_gpu"] = {"value": r["reference_shaped_it_s"], "unit": "it/s",
+                                             "source": "profiles/r02_ref_vs_ours_step.json (committed measurement of "
+                                                       "tests/test_gpu_vs_reference.py, not taken in this run)"}
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
