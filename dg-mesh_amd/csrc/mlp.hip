@@ -392,7 +392,16 @@ struct ReduceDwJob {
 struct ReduceDwBatch {
     int emb_dim;
     ReduceDwJob job[8];
+    // blockIdx.y == 8: the heads' partial sums (mlp_heads_bwd_kernel) ride along, see reduce_heads_body
+    int h_chunks, h_nout;
+    const float* h_partial_W;
+    const float* h_partial_b;
+    float* h_dW;
+    float* h_db;
 };
+__device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, const float* __restrict__ partial_W,
+                                                  const float* __restrict__ partial_b, float* __restrict__ dWh,
+                                                  float* __restrict__ dbh);
 // All eight layers of a network in ONE launch at the end of its backward pass (blockIdx.y = layer; every layer keeps its own
 // partial tiles until then).  Workgroup = a KT x JT piece of the (k, j) plane as 64 float4 positions (one wave-wide load =
 // KT row segments of JT * 4 contiguous bytes of one partial tile), times four groups of chunks (the four waves): every
@@ -410,6 +419,11 @@ mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
     constexpr int KT = RDW_KT, JT = RDW_JT, JQ = JT / 4, JB = MLP_W / JT;
     __shared__ float4 red[4][64];
     __shared__ float redb[32][8];
+    if (blockIdx.y == 8) {  // (workgroup-uniform branch)
+        if ((int)blockIdx.x < 8 * rb.h_nout)
+            reduce_heads_body(blockIdx.x & 7, blockIdx.x >> 3, rb.h_chunks, rb.h_partial_W, rb.h_partial_b, rb.h_dW, rb.h_db);
+        return;
+    }
     const ReduceDwJob& jb = rb.job[blockIdx.y];
     if ((int)blockIdx.x >= jb.nblocks) return;
     const int chunks = jb.chunks, db_rows = jb.db_rows, Kp = jb.Kp, in_features = jb.in_features, emb_dim = rb.emb_dim;
@@ -601,13 +615,13 @@ mlp_heads_bwd_kernel(int N, int NC, const float* __restrict__ dOut, const float*
 // dWh[o][c] = sum_chunks partial_W[chunk][o][c], dbh[o] = sum_chunks partial_b[chunk][o].  Grid (8 column blocks, n_out):
 // a workgroup owns 32 columns of one output row as 8 float4 positions x 32 chunk groups (a wave instruction reads 128 contiguous
 // bytes of eight chunks), group sums meet in LDS in a fixed order; the first column block of each row also reduces its bias.
-__global__ void __launch_bounds__(256)
-mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W, const float* __restrict__ partial_b,
-                        float* __restrict__ dWh, float* __restrict__ dbh) {
+__device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, const float* __restrict__ partial_W,
+                                                  const float* __restrict__ partial_b, float* __restrict__ dWh,
+                                                  float* __restrict__ dbh) {
     __shared__ float4 red[32][8];
     __shared__ float redb[256];
     const int tid = threadIdx.x, pos = tid & 7, grp = tid >> 3;
-    const int o = blockIdx.y, c0 = blockIdx.x * 32 + pos * 4;
+    const int c0 = bx * 32 + pos * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* src = partial_W + (size_t)o * MLP_W + c0;
     int k = grp;
@@ -625,20 +639,25 @@ mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W,
     }
     red[grp][pos] = s;
     float sb = 0.f;
-    if (blockIdx.x == 0)
+    if (bx == 0)
         for (int c = tid; c < chunks; c += 256) sb += partial_b[(size_t)c * 16 + o];
     redb[tid] = sb;
     __syncthreads();
     if (tid < 8) {
         float4 t = red[0][tid];
         for (int g = 1; g < 32; g++) t.x += red[g][tid].x, t.y += red[g][tid].y, t.z += red[g][tid].z, t.w += red[g][tid].w;
-        *reinterpret_cast<float4*>(dWh + (size_t)o * MLP_W + blockIdx.x * 32 + tid * 4) = t;
+        *reinterpret_cast<float4*>(dWh + (size_t)o * MLP_W + bx * 32 + tid * 4) = t;
     }
-    if (blockIdx.x == 0 && tid == 8) {
+    if (bx == 0 && tid == 8) {
         float t = 0.f;
         for (int i = 0; i < 256; i++) t += redb[i];
         dbh[o] = t;
     }
+}
+__global__ void __launch_bounds__(256)
+mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W, const float* __restrict__ partial_b,
+                        float* __restrict__ dWh, float* __restrict__ dbh) {
+    reduce_heads_body(blockIdx.x, blockIdx.y, chunks, partial_W, partial_b, dWh, dbh);
     (void)NC;
 }
 
@@ -756,7 +775,6 @@ struct Ws {
     float *wsc_f[8], *wsc_d[8], *wsc_e;    // their inverse column scales (wsc_e: the embedding half of the skip layer)
     unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
     unsigned* cmaxE;                       // [256] column maxima of the embedding (right behind cmaxY: one memset clears both)
-    unsigned *cmaxW;                       // [16][256] column maxima of the weight matrices (prep3 pass 1)
     unsigned* mask[8];
     size_t bytes;
 };
@@ -887,12 +905,11 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.wsc_f[l] = take(MLP_W * 4);
     for (int l = 0; l < 8; l++) w.wsc_d[l] = take(MLP_W * 4);
     w.wsc_e = take(MLP_W * 4);
-    // one block, cleared by ONE fill at the start of the forward pass (the backward pass of a network always follows its own
-    // forward pass on the same workspace): cmaxY [8] | cmaxE [1] | cmaxG [8] | cmaxW [PREP3_MAX_JOBS], 256 words each
-    w.cmaxY = (unsigned*)take((9 + 8 + PREP3_MAX_JOBS) * MLP_W * 4);
+    // one block, cleared by the weight-preparation launch at the start of the forward pass (the backward pass of a network
+    // always follows its own forward pass on the same workspace): cmaxY [8] | cmaxE [1] | cmaxG [8], 256 words each
+    w.cmaxY = (unsigned*)take((9 + 8) * MLP_W * 4);
     w.cmaxE = w.cmaxY + 8 * MLP_W;
     w.cmaxG = w.cmaxY + 9 * MLP_W;
-    w.cmaxW = w.cmaxY + 17 * MLP_W;
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     w.partial_h = take((size_t)hchunks * 16 * MLP_W * 4);
     w.partial_hb = take((size_t)hchunks * 16 * 4);
@@ -983,17 +1000,15 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             }
         }
         add(0, MLP_W, 32, MLP_W, 0, 0, p->n_out, p->Wh, w.Wh6f);
-        hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
         if (n3 > 0) {
-            // cmaxY | cmaxE | cmaxG | cmaxW are one block: one fill clears the maxima of this forward AND its backward pass
-            // (a repeated backward pass finds maxima that are at least as large: still valid scales)
-            if (hipMemsetAsync(w.cmaxY, 0, (9 + 8 + PREP3_MAX_JOBS) * MLP_W * 4, st) != hipSuccess)
-                return mlp_fail("mlp_forward: memset failed");
-            const int pthreads = (MLP_EMB + MLP_W) / 8 * MLP_W;
-            hipLaunchKernelGGL(mlp_prep3_max_kernel, dim3((pthreads + 255) / 256, n3), dim3(256), 0, st, p3, w.cmaxW);
-            hipLaunchKernelGGL(mlp_prep3_batch_kernel, dim3((pthreads + 255) / 256, n3), dim3(256), 0, st, p3, (const unsigned*)w.cmaxW);
+            // one launch: every trunk matrix's column maxima + planes, the heads' planes (the only bf16x6 job left in this
+            // mode), and the clearing of cmaxY | cmaxE | cmaxG -- one block of running column maxima for this forward AND its
+            // backward pass (a repeated backward pass finds maxima that are at least as large: still valid scales)
+            hipLaunchKernelGGL(mlp_prep3_all_kernel, dim3(8, n3 + 1), dim3(256), 0, st, p3, n3, pb.job[nj - 1], w.cmaxY,
+                               (9 + 8) * MLP_W);
             if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_forward: cannot raise the LDS limit of mlp_gemm3r_kernel");
-        }
+        } else
+            hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
     }
     {
         hipLaunchKernelGGL(mlp_embed_kernel, dim3((N + 7) / 8), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.emb);
@@ -1087,8 +1102,9 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                // cleared by the forward pass)
         if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
     }
-    hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3(8, p->n_out), dim3(256), 0, st, hchunks, p->n_out, w.partial_h, w.partial_hb,
-                       dWh, dbh);
+    if (f32)  // (the matrix-core paths fold this into their one reduction launch at the end of the pass)
+        hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3(8, p->n_out), dim3(256), 0, st, hchunks, p->n_out, w.partial_h,
+                           w.partial_hb, dWh, dbh);
     float* G = w.Ga;
     float* Gn = w.Gb;
     const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
@@ -1175,8 +1191,11 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
             Gn = t;
         }
     }
-    if (!f32)  // the weight gradients of all eight layers: one reduction of their partial tiles
-        hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, 8), dim3(256), 0, st, rb);
+    if (!f32) {  // the weight gradients of all eight layers and of the heads: one reduction of their partial tiles
+        rb.h_chunks = hchunks, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
+        rb.h_dW = dWh, rb.h_db = dbh;
+        hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, 9), dim3(256), 0, st, rb);
+    }
     if (!per_row_t && dtemb != nullptr)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
                            db[p->skip_layer], p->W[p->skip_layer], layer_in(p, p->skip_layer), dtemb);

@@ -90,40 +90,59 @@ __device__ __forceinline__ float prep3_src(const Prep3Job& j, int k, int col) {
     return k < j.k_valid ? j.W[(size_t)k * j.in_features + j.hoff + col] : 0.f;
 }
 
-// pass 1 (blockIdx.y = job, one thread per (8-deep k group, column)): column maxima of |B| into cmax[job][col] (float
-// bits, zeroed by the caller) -- one atomic per thread, ~40 per address
-__global__ void __launch_bounds__(256) mlp_prep3_max_kernel(const Prep3Batch b, unsigned* __restrict__ cmax) {
+// Every trunk matrix of a network in ONE launch (f16x3 forward pass), together with the two small jobs that used to precede
+// it: grid (8, n3 + 1).
+//   blockIdx.y < n3 : job y, columns [32 x, 32 x + 32): thread = (column, one of eight k-group slots); a thread keeps its
+//                     <= 6 k-groups of 8 values in registers, the eight slot maxima of a column meet in LDS (no atomics, no
+//                     zero-filled maxima needed), then the column's power-of-two scale, the split, the two planes and the inverse scale;
+//   blockIdx.y == n3: x < 4: the heads' bf16x6 planes (mlp_bf16x6.hpp: prep6_one, 32 x 32 threads' worth);
+//                     x >= 4: clear `zero_words` words at `zero` (the running column maxima of this forward / backward pass).
+__global__ void __launch_bounds__(256)
+mlp_prep3_all_kernel(const Prep3Batch b, int n3, const Prep6Job heads, unsigned* __restrict__ zero, int zero_words) {
+    __shared__ float smax[8][32];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.y == n3) {
+        if (blockIdx.x < 4) {
+            for (int idx = blockIdx.x * 256 + tid; idx < (heads.Kp >> 3) * heads.ncols; idx += 1024) prep6_one(heads, idx);
+        } else {
+            for (int i = (blockIdx.x - 4) * 256 + tid; i < zero_words; i += 1024) zero[i] = 0u;
+        }
+        return;
+    }
     const Prep3Job& j = b.job[blockIdx.y];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (j.Kp >> 3) * j.ncols) return;
-    const int kg = idx / j.ncols, col = idx % j.ncols;
+    const int col = blockIdx.x * 32 + (tid & 31), slot = tid >> 5, nkg = j.Kp >> 3;
+    float e[6][8];
     float mx = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(prep3_src(j, kg * 8 + i, col)));
-    atomicMax(cmax + blockIdx.y * 256 + col, __float_as_uint(mx));
-}
-
-// pass 2: scale by the column's power of two, split, write the two planes (and the inverse scales)
-__global__ void __launch_bounds__(256) mlp_prep3_batch_kernel(const Prep3Batch b, const unsigned* __restrict__ cmax) {
-    const Prep3Job& j = b.job[blockIdx.y];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (j.Kp >> 3) * j.ncols) return;
-    const int kg = idx / j.ncols, col = idx % j.ncols;
-    float sc, inv;
-    scale_from_max_bits(cmax[blockIdx.y * 256 + col], sc, inv);
-    if (kg == 0) j.inv_scale[col] = inv;
-    float e[8];
+    for (int it = 0; it < 6; it++) {
+        const int kg = slot + 8 * it;
 #pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = prep3_src(j, kg * 8 + i, col) * sc;
-    uint4 H, L;
-    split2h(e[0], e[1], H.x, L.x);
-    split2h(e[2], e[3], H.y, L.y);
-    split2h(e[4], e[5], H.z, L.z);
-    split2h(e[6], e[7], H.w, L.w);
-    const int stage = kg >> 1, g = kg & 1;
-    uint4* dst = j.Bp + ((size_t)stage * 4 + g) * j.ncols + col;
-    dst[0] = H;
-    dst[2 * j.ncols] = L;
+        for (int i = 0; i < 8; i++) {
+            e[it][i] = kg < nkg ? prep3_src(j, kg * 8 + i, col) : 0.f;
+            mx = fmaxf(mx, fabsf(e[it][i]));
+        }
+    }
+    smax[slot][tid & 31] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 8; g++) mx = fmaxf(mx, smax[g][tid & 31]);
+    float sc, inv;
+    scale_from_max_bits(__float_as_uint(mx), sc, inv);
+    if (slot == 0) j.inv_scale[col] = inv;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int kg = slot + 8 * it;
+        if (kg < nkg) {
+            uint4 H, L;
+            split2h(e[it][0] * sc, e[it][1] * sc, H.x, L.x);
+            split2h(e[it][2] * sc, e[it][3] * sc, H.y, L.y);
+            split2h(e[it][4] * sc, e[it][5] * sc, H.z, L.z);
+            split2h(e[it][6] * sc, e[it][7] * sc, H.w, L.w);
+            uint4* dst = j.Bp + ((size_t)(kg >> 1) * 4 + (kg & 1)) * j.ncols + col;
+            dst[0] = H;
+            dst[2 * j.ncols] = L;
+        }
+    }
 }
 
 // ---- the trunk-layer GEMM, weights stationary in registers -------------------------------------------------------------
