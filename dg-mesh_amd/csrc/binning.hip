@@ -580,19 +580,31 @@ tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned
                 __threadfence_block();
                 __syncthreads();
             }
-            if (phase == 0) {
-                bool tie = false;
+            if (phase == 0) {  // as in radix_sort_tile: only a run longer than kTieRun pays for the index passes
+                bool long_run = false;
 #pragma unroll 4
-                for (int i = threadIdx.x; i + 1 < n; i += WAVES * 64) tie = tie | (bufA[i].x == bufA[i + 1].x);
-                resort = __syncthreads_or(tie) != 0;
+                for (int i = threadIdx.x; i + kTieRun < n; i += WAVES * 64) long_run = long_run | (bufA[i].x == bufA[i + kTieRun].x);
+                resort = __syncthreads_or(long_run) != 0;
                 if (!resort) break;
             }
         }
-#pragma unroll 4
+        // gather through the payload; the members of short runs of equal depth (with thousands of entries between two
+        // depths a pair is the rule, not the exception) are placed by ascending Gaussian index here
+#pragma unroll 2
         for (int i = threadIdx.x; i < n; i += WAVES * 64) {
-            const uint4 e = seg[bufA[i].y];
-            point_list[r.x + i] = e.x;
-            upos[r.x + i] = e.z;
+            const uint2 me = bufA[i];
+            const uint4 e = seg[me.y];
+            unsigned at = (unsigned)i;
+            if (!resort && ((i > 0 && bufA[i - 1].x == me.x) || (i + 1 < n && bufA[i + 1].x == me.x))) {
+                int s0 = i, s1 = i + 1;
+                while (s0 > 0 && bufA[s0 - 1].x == me.x) s0--;
+                while (s1 < n && bufA[s1].x == me.x) s1++;
+                unsigned below = 0u;
+                for (int j = s0; j < s1; j++) below += seg[bufA[j].y].x < e.x ? 1u : 0u;
+                at = (unsigned)s0 + below;
+            }
+            point_list[r.x + at] = e.x;
+            upos[r.x + at] = e.z;
         }
         __syncthreads();
     }

@@ -254,6 +254,25 @@ def test_depth_ties_sorted_by_index(orc, syn):
     assert np.array_equal(f_hip["ranges"], f_or["binning"]["ranges"])
 
 
+@pytest.mark.parametrize("P,groups", [(6000, 2500), (17000, 7000), (6000, 1), (9000, 1), (9000, 3)])
+def test_depth_ties_in_long_tile_lists(orc, syn, P, groups):
+    """The same rule in the worklist kernel for long lists (pairs in LDS up to 8192 entries, in global memory beyond): with
+    thousands of entries between two depths, equal neighbours are the rule -- short runs (Gaussian i sits on the point of
+    Gaussian i % groups: runs of two or three) are placed by index while gathering; a run longer than 32 (groups = 1 or 3:
+    all P on one / three points) takes the index passes.  Every Gaussian covers the whole 32 x 32 image."""
+    a = raster_args(syn, P, 32, 32, seed=21, kind="init", extent=0.4)
+    a["scales"] = (a["scales"] * 0 + 0.5).astype(np.float32)
+    a["opacities"] = (a["opacities"] * 0 + 0.004).astype(np.float32)
+    a["means3D"][:, :] = a["means3D"][np.arange(P) % groups]
+    f_hip = G.hip_forward(a)
+    f_or = oracle_forward(orc, a)
+    n = f_or["binning"]["ranges"][:, 1] - f_or["binning"]["ranges"][:, 0]
+    assert n.max() >= P * 0.95
+    assert np.array_equal(f_hip["point_list"], f_or["binning"]["point_list"])
+    assert np.array_equal(f_hip["ranges"], f_or["binning"]["ranges"])
+    assert np.array_equal(np.sort(f_hip["upos"]), np.arange(f_or["num_rendered"], dtype=np.uint32))
+
+
 @pytest.mark.parametrize("variant", ["colors_precomp", "cov3D_precomp", "deg0", "deg1", "deg2", "black_bg"])
 def test_optional_inputs(orc, syn, variant):
     a = raster_args(syn, 2000, 128, 96, seed=9, kind="aniso")
