@@ -428,8 +428,8 @@ tile_sort_radix_mid_kernel(int tiles, const unsigned* __restrict__ big_list, con
 // and the length is unbounded; (key, payload) pairs ping-pong between two buffers: in LDS for segments up to kBigLds entries,
 // else carved from the backward's row slab, which is idle during the forward pass (16 bytes per entry of its 48; all traffic
 // stays inside the tile's own segment, i.e. in L2).
-// Equal depths: as in the small kernel, an index sort in front of a second depth sort when (and only when) the depth-sorted
-// segment has equal neighbours.
+// Equal depths: as in the small kernel -- runs up to kTieRun are placed by Gaussian index while gathering (among thousands of
+// entries a pair of equal depth bits is the rule), and only a longer run costs an index sort in front of a second depth sort.
 template <int WAVES>
 __device__ __forceinline__ void radix_pass_global(const uint2* __restrict__ src, uint2* __restrict__ dst, int n, int shift,
                                                   unsigned (*cnt)[256]) {
