@@ -432,7 +432,7 @@ tile_sort_radix_mid_kernel(int tiles, const unsigned* __restrict__ big_list, con
 // entries a pair of equal depth bits is the rule), and only a longer run costs an index sort in front of a second depth sort.
 template <int WAVES>
 __device__ __forceinline__ void radix_pass_global(const uint2* __restrict__ src, uint2* __restrict__ dst, int n, int shift,
-                                                  unsigned (*cnt)[256]) {
+                                                  unsigned (*cnt)[256], unsigned* dstart = nullptr) {
     constexpr int GB = 8;  // batches whose loads are in flight together (the passes are latency-bound: L2 round trips)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nbw = (n + WAVES * 64 - 1) / (WAVES * 64);  // batches of 64 per wave
@@ -475,6 +475,10 @@ __device__ __forceinline__ void radix_pass_global(const uint2* __restrict__ src,
         const unsigned tot = t.x + t.y + t.z + t.w;
         const unsigned base = wave_inclusive_scan_u32(tot) - tot;
         uint4 run = make_uint4(base, base + t.x, base + t.x + t.y, base + t.x + t.y + t.z);
+        if (dstart != nullptr) {  // where each digit's bucket begins in dst (dstart[256] = n)
+            reinterpret_cast<uint4*>(dstart)[lane] = run;
+            if (lane == 63) dstart[256] = base + tot;
+        }
 #pragma unroll
         for (int w = 0; w < WAVES; w++) {
             reinterpret_cast<uint4*>(&cnt[w][0])[lane] = run;
@@ -534,6 +538,78 @@ __device__ __forceinline__ unsigned varying_bits_global(const uint2* __restrict_
     return v;
 }
 
+// Segments that do not fit the LDS pair buffers: ONE pass through global memory -- a stable partition by the most significant
+// varying byte of the depth -- then consecutive buckets are taken through LDS in groups of up to kBigLds entries (copy in, the
+// remaining passes in LDS, gather + tie placement straight into point_list / upos).  Equal keys share a bucket, so runs never
+// straddle groups.  Returns false (nothing final written) for what this shape does not cover -- one depth for the whole segment, a
+// bucket larger than the LDS buffers, a run of equal depths longer than kTieRun -- and the caller's all-global passes take over.
+template <int WAVES>
+__device__ __forceinline__ bool msd_first_sort(int n, unsigned rx, const uint4* __restrict__ seg, uint2* __restrict__ gA,
+                                               uint2* __restrict__ gB, uint2* lds, unsigned (*cnt)[256], unsigned* s_red,
+                                               unsigned* dstart, unsigned* __restrict__ point_list,
+                                               unsigned* __restrict__ upos) {
+    const int tid = threadIdx.x;
+#pragma unroll 4
+    for (int i = tid; i < n; i += WAVES * 64) gA[i] = make_uint2(seg[i].y, (unsigned)i);
+    __threadfence_block();
+    __syncthreads();
+    const unsigned varying = varying_bits_global<WAVES>(gA, n, s_red);
+    if (varying == 0u) return false;
+    const int tb = (31 - __clz((int)varying)) & ~7;
+    radix_pass_global<WAVES>(gA, gB, n, tb, cnt, dstart);
+    if (__syncthreads_or(tid < 256 && dstart[tid + 1] - dstart[tid] > (unsigned)kBigLds) != 0) return false;
+    uint2* L0 = lds;
+    uint2* L1 = lds + kBigLds;
+    bool ok = true;
+    for (int d0 = 0; d0 < 256;) {  // (every thread walks the same buckets: dstart is in LDS)
+        const unsigned s0 = dstart[d0];
+        int d1 = d0 + 1;
+        while (d1 < 256 && dstart[d1 + 1] - s0 <= (unsigned)kBigLds) d1++;
+        const int m = (int)(dstart[d1] - s0);
+        if (m > 0) {
+#pragma unroll 4
+            for (int i = tid; i < m; i += WAVES * 64) L0[i] = gB[s0 + i];
+            __syncthreads();
+            uint2* cur = L0;
+            uint2* oth = L1;
+            for (int shift = 0; shift <= tb; shift += 8) {
+                if (((varying >> shift) & 255u) == 0u) continue;
+                if (shift == tb && d1 - d0 == 1) continue;  // a single bucket: its top byte is one value
+                radix_pass_global<WAVES>(cur, oth, m, shift, cnt);
+                uint2* t = cur;
+                cur = oth;
+                oth = t;
+            }
+            bool long_run = false;
+#pragma unroll 4
+            for (int i = tid; i + kTieRun < m; i += WAVES * 64) long_run = long_run | (cur[i].x == cur[i + kTieRun].x);
+            if (__syncthreads_or(long_run) != 0) {
+                ok = false;
+                break;
+            }
+#pragma unroll 2
+            for (int i = tid; i < m; i += WAVES * 64) {
+                const uint2 me = cur[i];
+                const uint4 e = seg[me.y];
+                unsigned at = (unsigned)i;
+                if ((i > 0 && cur[i - 1].x == me.x) || (i + 1 < m && cur[i + 1].x == me.x)) {
+                    int a0 = i, a1 = i + 1;
+                    while (a0 > 0 && cur[a0 - 1].x == me.x) a0--;
+                    while (a1 < m && cur[a1].x == me.x) a1++;
+                    unsigned below = 0u;
+                    for (int j = a0; j < a1; j++) below += seg[cur[j].y].x < e.x ? 1u : 0u;
+                    at = (unsigned)a0 + below;
+                }
+                point_list[rx + s0 + at] = e.x;
+                upos[rx + s0 + at] = e.z;
+            }
+            __syncthreads();
+        }
+        d0 = d1;
+    }
+    return ok;
+}
+
 __global__ void __launch_bounds__(1024)
 tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
                            const uint2* __restrict__ ranges, const uint4* __restrict__ inst, uint2* __restrict__ pairs, size_t R,
@@ -542,6 +618,7 @@ tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned
     extern __shared__ __attribute__((aligned(16))) uint2 lds_pairs[];  // 2 x kBigLds pairs: segments up to kBigLds entries
     __shared__ __attribute__((aligned(16))) unsigned cnt[WAVES][256];  // ping-pong in LDS, longer ones in global memory
     __shared__ unsigned s_red[2];
+    __shared__ __attribute__((aligned(16))) unsigned dstart[260];
     const unsigned count = *big_count;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
         const uint2 r = ranges[big_list[w]];
@@ -549,6 +626,11 @@ tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned
         const uint4* seg = inst + r.x;
         uint2* bufA = n <= kBigLds ? lds_pairs : pairs + r.x;  // two pair buffers of this segment
         uint2* bufB = n <= kBigLds ? lds_pairs + kBigLds : pairs + R + r.x;
+        if (n > kBigLds &&
+            msd_first_sort<WAVES>(n, r.x, seg, bufA, bufB, lds_pairs, cnt, s_red, dstart, point_list, upos)) {  // (uniform)
+            __syncthreads();
+            continue;
+        }
         bool resort = false;
         for (int phase = 0; phase < 3; phase++) {  // 0: by depth; after a tie only: 1: by index, 2: by depth again
             uint2* cur = bufA;

@@ -254,12 +254,15 @@ def test_depth_ties_sorted_by_index(orc, syn):
     assert np.array_equal(f_hip["ranges"], f_or["binning"]["ranges"])
 
 
-@pytest.mark.parametrize("P,groups", [(6000, 2500), (17000, 7000), (6000, 1), (9000, 1), (9000, 3)])
+@pytest.mark.parametrize("P,groups", [(6000, 2500), (17000, 7000), (6000, 1), (9000, 1), (9000, 3), (17000, 2), (20000, 9000)])
 def test_depth_ties_in_long_tile_lists(orc, syn, P, groups):
     """The same rule in the worklist kernel for long lists (pairs in LDS up to 8192 entries, in global memory beyond): with
     thousands of entries between two depths, equal neighbours are the rule -- short runs (Gaussian i sits on the point of
-    Gaussian i % groups: runs of two or three) are placed by index while gathering; a run longer than 32 (groups = 1 or 3:
-    all P on one / three points) takes the index passes.  Every Gaussian covers the whole 32 x 32 image."""
+    Gaussian i % groups: runs of two or three) are placed by index while gathering; a run longer than 32 (groups = 1, 2 or 3:
+    all P on one / two / three points) takes the index passes.  Beyond 8192 entries the list first takes one partition pass
+    by its most significant varying depth byte and then goes through LDS in groups of buckets; one depth only, buckets larger
+    than the LDS buffers (17000 on two points) and long runs inside a group (9000 on three) fall back to the all-global passes.
+    Every Gaussian covers the whole 32 x 32 image."""
     a = raster_args(syn, P, 32, 32, seed=21, kind="init", extent=0.4)
     a["scales"] = (a["scales"] * 0 + 0.5).astype(np.float32)
     a["opacities"] = (a["opacities"] * 0 + 0.004).astype(np.float32)
