@@ -241,7 +241,8 @@ def main():
                 pass
             return None, None
 
-        f16x3 = mlp_impl == "hip" and L.lib().dgm_mlp_set_gemm(-1) == 2  # (-1: query, mode unchanged)
+        gemm_mode = L.lib().dgm_mlp_set_gemm(-1) if mlp_impl == "hip" else -1  # (-1: query, mode unchanged)
+        f16x3 = gemm_mode in (2, 3)
         mfma_per_product = 3.0 if f16x3 else 6.0  # f16x3: 3 MFMAs per fp32 product on the f16 pipe; bf16x6: 6 on the bf16 pipe
         layer_flops = 2.0 * P * 256 * 256                       # one 256 -> 256 layer over N = P rows
         layer_bytes = 2.0 * P * 256 * 4 + P * 32 + 256 * 256 * 4  # A in + C out (fp32) + ReLU mask bits + the weights once

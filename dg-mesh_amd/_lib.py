@@ -84,6 +84,7 @@ SYMBOLS = {
     "dgm_timenet_forward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_timenet_backward": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgm_mlp_workspace_bytes": (_c.c_size_t, [_i]),
+    "dgm_mlp_describe_workspace": (_i, [_i, _c.POINTER(_c.c_size_t), _i]),
     "dgm_mlp_forward": (_i, [_c.POINTER(MlpParams), _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_mlp_backward": (_i, [_c.POINTER(MlpParams), _i, _vp, _i, _vp, _vp * 8, _vp * 8, _vp, _vp, _vp, _vp]),
 }

@@ -21,10 +21,12 @@
 //  * t is the same for every row in training, so dL/dt_emb = db . W[:, t-columns] (no per-row GEMM); the general
 //    per-row case has its own small kernel.
 #include <stdlib.h>
+#include <string.h>
 
 #include "dgm_common.hpp"
 #include "mlp_bf16x6.hpp"
 #include "mlp_f16x3.hpp"
+#include "mlp_planes.hpp"
 
 namespace dgm {
 
@@ -393,13 +395,13 @@ struct ReduceDwBatch {
     int emb_dim;
     ReduceDwJob job[8];
     // blockIdx.y == 8: the heads' partial sums (mlp_heads_bwd_kernel) ride along, see reduce_heads_body
-    int h_chunks, h_nout;
+    int h_chunks, h_bchunks, h_nout;  // (h_bchunks: rows of h_partial_b -- the plane path leaves one per 32-row tile)
     const float* h_partial_W;
     const float* h_partial_b;
     float* h_dW;
     float* h_db;
 };
-__device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, const float* __restrict__ partial_W,
+__device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, int bchunks, const float* __restrict__ partial_W,
                                                   const float* __restrict__ partial_b, float* __restrict__ dWh,
                                                   float* __restrict__ dbh);
 // All eight layers of a network in ONE launch at the end of its backward pass (blockIdx.y = layer; every layer keeps its own
@@ -421,7 +423,7 @@ mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
     __shared__ float redb[32][8];
     if (blockIdx.y == 8) {  // (workgroup-uniform branch)
         if ((int)blockIdx.x < 8 * rb.h_nout)
-            reduce_heads_body(blockIdx.x & 7, blockIdx.x >> 3, rb.h_chunks, rb.h_partial_W, rb.h_partial_b, rb.h_dW, rb.h_db);
+            reduce_heads_body(blockIdx.x & 7, blockIdx.x >> 3, rb.h_chunks, rb.h_bchunks, rb.h_partial_W, rb.h_partial_b, rb.h_dW, rb.h_db);
         return;
     }
     const ReduceDwJob& jb = rb.job[blockIdx.y];
@@ -615,7 +617,7 @@ mlp_heads_bwd_kernel(int N, int NC, const float* __restrict__ dOut, const float*
 // dWh[o][c] = sum_chunks partial_W[chunk][o][c], dbh[o] = sum_chunks partial_b[chunk][o].  Grid (8 column blocks, n_out):
 // a workgroup owns 32 columns of one output row as 8 float4 positions x 32 chunk groups (a wave instruction reads 128 contiguous
 // bytes of eight chunks), group sums meet in LDS in a fixed order; the first column block of each row also reduces its bias.
-__device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, const float* __restrict__ partial_W,
+__device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, int bchunks, const float* __restrict__ partial_W,
                                                   const float* __restrict__ partial_b, float* __restrict__ dWh,
                                                   float* __restrict__ dbh) {
     __shared__ float4 red[32][8];
@@ -640,7 +642,7 @@ __device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, con
     red[grp][pos] = s;
     float sb = 0.f;
     if (bx == 0)
-        for (int c = tid; c < chunks; c += 256) sb += partial_b[(size_t)c * 16 + o];
+        for (int c = tid; c < bchunks; c += 256) sb += partial_b[(size_t)c * 16 + o];
     redb[tid] = sb;
     __syncthreads();
     if (tid < 8) {
@@ -657,7 +659,7 @@ __device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, con
 __global__ void __launch_bounds__(256)
 mlp_reduce_heads_kernel(int chunks, int NC, const float* __restrict__ partial_W, const float* __restrict__ partial_b,
                         float* __restrict__ dWh, float* __restrict__ dbh) {
-    reduce_heads_body(blockIdx.x, blockIdx.y, chunks, partial_W, partial_b, dWh, dbh);
+    reduce_heads_body(blockIdx.x, blockIdx.y, chunks, chunks, partial_W, partial_b, dWh, dbh);
     (void)NC;
 }
 
@@ -776,6 +778,14 @@ struct Ws {
     unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
     unsigned* cmaxE;                       // [256] column maxima of the embedding (right behind cmaxY: one memset clears both)
     unsigned* mask[8];
+    // plane path (mlp_planes.hpp): tile exponents of the embedding / Y_l / dOut / the two gradient buffers, the lane-native
+    // fp32 half of the skip layer, the dOut planes, per-matrix maxima, the heads' planes and the per-matrix inverse scales
+    int *Eexp, *Yexp[8], *Dexp, *Gexp[2];
+    float4* Cin;
+    unsigned char* Dp;
+    unsigned* matmax;
+    uint4 *Wh4f, *Wh4b;
+    float *wsc_hf, *wsc_hb;
     size_t bytes;
 };
 int num_cus() {
@@ -812,13 +822,17 @@ DwPlan dw6_plan(int N, int Kp, bool x3) {
 //    skip layer, the heads and the K = 96 / 352 weight gradients run the bf16x6 kernels
 // 0: bf16x6 everywhere (fp32 operands split exactly into 3 bf16, 6 partial products on the bf16 matrix cores)
 // 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3|bf16x6|f32.
+// 3: f16x3p (default; mlp_planes.hpp): the f16x3 arithmetic on plane-format activations -- split once by the producer,
+//    one exponent per 32-row tile; needs a broadcast time embedding (temb_stride == 0), else the call runs mode 2.
 int g_gemm_mode = [] {
     const char* e = getenv("DGM_MLP_GEMM");
-    if (e == nullptr) return 2;
-    if (e[0] == 'b') return 0;
-    if (e[0] == 'f' && e[1] == '3') return 1;
-    return 2;
+    if (e == nullptr) return 3;
+    if (strcmp(e, "bf16x6") == 0) return 0;
+    if (strcmp(e, "f32") == 0) return 1;
+    if (strcmp(e, "f16x3") == 0) return 2;
+    return 3;  // "f16x3p"
 }();
+int effective_mode(int temb_stride) { return (g_gemm_mode == 3 && temb_stride != 0) ? 2 : g_gemm_mode; }
 // arithmetic the last forward pass on a workspace ran in: the backward pass must match (its scales and masks were produced by
 // that forward pass).  A small host-side table keyed by the workspace pointer; an unknown workspace is not checked.
 struct WsMode {
@@ -840,8 +854,6 @@ int recall_ws_mode(const void* ws) {
         if (e.ws == ws) return e.mode;
     return -1;
 }
-bool use_f32_mfma() { return g_gemm_mode == 1; }
-bool use_f16x3() { return g_gemm_mode == 2; }
 #define G3R_LDS(K_) (2 * 32 * (4 * (K_) + 16) + 256 + 2 * 8 * 32 * 4)  // A planes (double buffered) + row scales + mask words
 #define DW3E_LDS(MT_) (2 * (4 * (MT_) * 32 + DW3_U) * 16)  // X and G stages, two planes each, double buffered
 hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once per device
@@ -857,6 +869,18 @@ hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once 
     if (e == hipSuccess) d = true;
     return e;
 }
+// plane path: a weight-gradient chunk is a run of whole 32-row tiles, one chunk per CU (or fewer)
+struct P4Plan {
+    int ntiles, tiles_per_chunk, chunks;
+};
+P4Plan p4_plan(int N) {
+    P4Plan d;
+    d.ntiles = (N + 31) / 32;
+    d.tiles_per_chunk = (d.ntiles + num_cus() - 1) / num_cus();
+    if (d.tiles_per_chunk < 1) d.tiles_per_chunk = 1;
+    d.chunks = (d.ntiles + d.tiles_per_chunk - 1) / d.tiles_per_chunk;
+    return d;
+}
 Ws carve(char* base, int N) {
     Ws w;
     char* p = align_ptr(base);
@@ -865,7 +889,8 @@ Ws carve(char* base, int N) {
         p = align_ptr(p + b);
         return (float*)at;
     };
-    const size_t n = (size_t)N;
+    const size_t n = ((size_t)N + 31) / 32 * 32;  // every per-row tensor is padded to whole 32-row tiles (plane path)
+    const size_t ntiles = n / 32;
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
     w.emb = take(n * MLP_EMB * 4);
     for (int l = 0; l < 8; l++) w.Y[l] = take(n * MLP_W * 4);
@@ -888,7 +913,12 @@ Ws carve(char* base, int N) {
         for (int x3 = 0; x3 < 2; x3++) {
             const DwPlan d = dw6_plan(N > 0 ? N : 1, Kp, x3 != 0);
             if ((size_t)d.chunks * Kp > rows) rows = (size_t)d.chunks * Kp;
-            if ((size_t)d.chunks * 2 > dbr) dbr = (size_t)d.chunks * 2;
+            if ((size_t)d.chunks * 8 > dbr) dbr = (size_t)d.chunks * 8;  // (plane path: 8 bias-gradient rows per chunk)
+        }
+        {   // plane path: chunks of whole tiles, at most one per CU
+            const P4Plan pp = p4_plan(N > 0 ? N : 1);
+            if ((size_t)pp.chunks * Kp > rows) rows = (size_t)pp.chunks * Kp;
+            if ((size_t)pp.chunks * 8 > dbr) dbr = (size_t)pp.chunks * 8;
         }
         if (l == 5 && pfl > rows) rows = pfl;  // the fp32-MFMA path reduces layer by layer through this one
         if (l == 5 && pdb > dbr) dbr = pdb;
@@ -910,9 +940,22 @@ Ws carve(char* base, int N) {
     w.cmaxY = (unsigned*)take((9 + 8) * MLP_W * 4);
     w.cmaxE = w.cmaxY + 8 * MLP_W;
     w.cmaxG = w.cmaxY + 9 * MLP_W;
-    const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
-    w.partial_h = take((size_t)hchunks * 16 * MLP_W * 4);
-    w.partial_hb = take((size_t)hchunks * 16 * 4);
+    size_t hchunks = (N + HD_ROWS - 1) / HD_ROWS;
+    if ((size_t)p4_plan(N > 0 ? N : 1).chunks > hchunks) hchunks = p4_plan(N > 0 ? N : 1).chunks;
+    w.partial_h = take(hchunks * 16 * MLP_W * 4);
+    w.partial_hb = take((hchunks > ntiles ? hchunks : ntiles) * 16 * 4);
+    w.Eexp = (int*)take(ntiles * 4);
+    for (int l = 0; l < 8; l++) w.Yexp[l] = (int*)take(ntiles * 4);
+    w.Dexp = (int*)take(ntiles * 4);
+    w.Gexp[0] = (int*)take(ntiles * 4);
+    w.Gexp[1] = (int*)take(ntiles * 4);
+    w.Cin = (float4*)take(n * MLP_W * 4);
+    w.Dp = (unsigned char*)take(n * 128);
+    w.matmax = (unsigned*)take(P4_MAX_MATS * 4);
+    w.Wh4f = (uint4*)take((size_t)MLP_W * 32 * 4);
+    w.Wh4b = (uint4*)take((size_t)16 * MLP_W * 4);
+    w.wsc_hf = take(64);
+    w.wsc_hb = take(64);
     w.bytes = (size_t)(p - base) + 256;
     return w;
 }
@@ -937,19 +980,196 @@ int check_params(const dgm_mlp_params* p) {
     if (!p->Wh || !p->bh) return mlp_fail("mlp: NULL head pointer");
     return 0;
 }
+
+// ---- plane path (mlp_planes.hpp) -----------------------------------------------------------------------------------------
+template <typename K>
+hipError_t p4_lds_attr(K kernel, int bytes, bool* done) {  // dynamic LDS above 48 KB needs the attribute once per device
+    if (*done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) *done = true;
+    return e;
+}
+#define P4_LAUNCH(kernel_, cfg_lds_, grid_, st_, args_)                                                                \
+    {                                                                                                                  \
+        static bool done_[DGM_MAX_DEVICES] = {false};                                                                  \
+        if (p4_lds_attr(kernel_, cfg_lds_, &done_[current_device_slot()]) != hipSuccess)                               \
+            return mlp_fail("mlp: cannot raise the LDS limit of a plane-path kernel");                                 \
+        hipLaunchKernelGGL(kernel_, dim3(grid_), dim3(512), cfg_lds_, st_, args_);                                     \
+    }
+typedef Gemm4Cfg<16, 1024, 512, 0, false, 8> CfgFwd;
+typedef Gemm4Cfg<16, 1024, 512, 2, false, 8> CfgSkip;
+typedef Gemm4Cfg<16, 1024, 512, 1, false, 8> CfgBwd;
+typedef Gemm4Cfg<6, 384, 192, 0, true, 8> CfgL0;
+typedef Gemm4Cfg<16, 1024, 512, 3, false, 1> CfgHeads;
+typedef Gemm4Cfg<1, 128, 64, 1, false, 8> CfgG7;
+typedef Dw4Cfg<8, 8, 1024, 512, 1024, 512> CfgDw;
+typedef Dw4Cfg<3, 8, 384, 192, 1024, 512> CfgDwE;
+typedef Dw4Cfg<8, 1, 1024, 512, 128, 64> CfgDwH;
+
+int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* temb, const Ws& w, float* out, hipStream_t st) {
+    const P4Plan pl = p4_plan(N);
+    const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
+    const int sk = p->skip_layer;
+    // embedding planes + the maxima of the nine weight tensors (W_0 .. W_7, Wh)
+    AbsMaxBatch am;
+    am.n_jobs = 9;
+    for (int l = 0; l < 8; l++) am.job[l].W = p->W[l], am.job[l].n = MLP_W * layer_in(p, l);
+    am.job[8].W = p->Wh, am.job[8].n = p->n_out * MLP_W;
+    hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + am.n_jobs), dim3(256), 0, st, N, nt, x, temb, 0, p->t_dim,
+                       (unsigned char*)w.emb, w.Eexp, am, w.matmax);
+    // every weight matrix as two binary16 planes, one power-of-two scale per matrix
+    Prep4Batch pb;
+    int nj = 0;
+    auto add = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp, uint4* Bp,
+                   float* inv_scale, int mat) {
+        Prep4Job& q = pb.job[nj++];
+        q.j.mode = mode, q.j.Kp = Kp, q.j.ncols = ncols, q.j.in_features = in_features, q.j.emb_dim = p->emb_dim, q.j.hoff = hoff;
+        q.j.k_valid = k_valid, q.j.col_valid = col_valid, q.j.W = Wp, q.j.Bp = Bp, q.j.inv_scale = inv_scale, q.mat = mat;
+    };
+    for (int l = 0; l < 8; l++) {
+        if (l == sk) {  // K = 352 = embedding half (rides along with layer 0) | trunk half
+            add(0, MLP_EMB, MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_e, l);
+            add(0, MLP_W, MLP_W, layer_in(p, l), p->emb_dim, MLP_W, MLP_W, p->W[l], w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l], l);
+        } else
+            add(0, layer_kp(p, l), MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_f[l], l);
+        if (l >= 1) add(1, MLP_W, MLP_W, layer_in(p, l), l == sk ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l], w.Wd3[l], w.wsc_d[l], l);
+    }
+    add(0, MLP_W, 32, MLP_W, 0, MLP_W, p->n_out, p->Wh, w.Wh4f, w.wsc_hf, 8);   // heads forward: B[k][o] = Wh[o][k]
+    add(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh4b, w.wsc_hb, 8);    // heads backward: B[o][c] = Wh[o][c]
+    hipLaunchKernelGGL(mlp_prep4_kernel, dim3(8, nj), dim3(256), 0, st, pb, w.matmax);
+
+    Gemm4Args a;
+    memset(&a, 0, sizeof(a));
+    a.ntiles = nt, a.M = N;
+    // layer 0 (K = 96) with the embedding half of the skip layer as second output
+    a.A = (const unsigned char*)w.emb, a.Aexp = w.Eexp, a.Bp = w.Wt3[0], a.b_inv = w.wsc_f[0], a.bias = p->b[0];
+    a.mask_out = w.mask[0], a.C = (unsigned char*)w.Y[0], a.Cexp = w.Yexp[0];
+    a.Bp2 = w.Wt3[sk], a.b_inv2 = w.wsc_e, a.bias2 = p->b[sk], a.out2 = w.Cin;
+    P4_LAUNCH((mlp_gemm4_kernel<6, 384, 192, 0, true, 8>), CfgL0::LDS, gx, st, a)
+    a.Bp2 = nullptr, a.b_inv2 = nullptr, a.bias2 = nullptr, a.out2 = nullptr;
+    for (int l = 1; l < 8; l++) {
+        a.A = (const unsigned char*)w.Y[l - 1], a.Aexp = w.Yexp[l - 1], a.b_inv = w.wsc_f[l], a.bias = p->b[l];
+        a.mask_out = w.mask[l], a.C = (unsigned char*)w.Y[l], a.Cexp = w.Yexp[l];
+        if (l == sk) {
+            a.Bp = w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, a.cin = w.Cin;
+            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 2, false, 8>), CfgSkip::LDS, gx, st, a)
+            a.cin = nullptr;
+        } else {
+            a.Bp = w.Wt3[l];
+            dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
+            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>), CfgFwd::LDS, gx, st, a)
+            dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
+        }
+    }
+    // heads: out = Y7 Wh^T + bh (one computing wave per workgroup; HBM-bound: one pass over Y7)
+    a.A = (const unsigned char*)w.Y[7], a.Aexp = w.Yexp[7], a.Bp = w.Wh4f, a.b_inv = w.wsc_hf, a.bias = p->bh;
+    a.mask_out = nullptr, a.C = nullptr, a.Cexp = nullptr, a.out = out, a.ldo = p->n_out, a.n_valid = p->n_out;
+    P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 3, false, 1>), CfgHeads::LDS, gx, st, a)
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
+    return 0;
+}
+
+int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws& w, float* const* dW, float* const* db, float* dWh,
+                    float* dbh, float* dtemb, hipStream_t st) {
+    const P4Plan pl = p4_plan(N);
+    const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
+    const int sk = p->skip_layer;
+    // dOut -> planes (zero columns / rows beyond n_out / N) + the heads' bias-gradient partial sums
+    hipLaunchKernelGGL(mlp_dout4_kernel, dim3((nt + 3) / 4), dim3(256), 0, st, N, nt, p->n_out, dOut, w.Dp, w.Dexp, w.partial_hb);
+    unsigned char* G = (unsigned char*)w.Ga;
+    unsigned char* Gn = (unsigned char*)w.Gb;
+    int *Ge = w.Gexp[0], *Gne = w.Gexp[1];
+    Gemm4Args a;
+    memset(&a, 0, sizeof(a));
+    a.ntiles = nt, a.M = N;
+    // G_7 = (dOut Wh) masked by layer 7's ReLU
+    a.A = w.Dp, a.Aexp = w.Dexp, a.Bp = w.Wh4b, a.b_inv = w.wsc_hb, a.mask_in = w.mask[7], a.C = G, a.Cexp = Ge;
+    P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8>), CfgG7::LDS, gx, st, a)
+    Dw4Args d;
+    memset(&d, 0, sizeof(d));
+    d.ntiles = nt, d.tiles_per_chunk = pl.tiles_per_chunk;
+    // heads' weight gradient: dWh[o][c] = sum_r dOut[r][o] Y7[r][c]
+    d.X = (const unsigned char*)w.Y[7], d.Xexp = w.Yexp[7], d.G = w.Dp, d.Gexp = w.Dexp, d.partial = w.partial_h, d.chunk_stride = 0;
+    d.partial_db = nullptr;
+    P4_LAUNCH((mlp_dw4_kernel<8, 1, 1024, 512, 128, 64>), CfgDwH::LDS, pl.chunks, st, d)
+    ReduceDwBatch rb;
+    rb.emb_dim = p->emb_dim;
+    int rb_blocks = 0;
+    for (int l = 7; l >= 0; l--) {
+        if (l >= 1) {  // backward data first: G_{l-1} = (G_l W_l) masked, into the other buffer
+            a.A = G, a.Aexp = Ge, a.Bp = w.Wd3[l], a.b_inv = w.wsc_d[l], a.mask_in = w.mask[l - 1], a.C = Gn, a.Cexp = Gne;
+            dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
+            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
+            dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
+        }
+        const int Kp = layer_kp(p, l);
+        d.G = G, d.Gexp = Ge, d.chunk_stride = (size_t)Kp * MLP_W;
+        if (l == 0 || l == sk) {  // the embedding's rows of the gradient (rows 0 .. 95 of the K = 96 / 352 partial tile)
+            d.X = (const unsigned char*)w.emb, d.Xexp = w.Eexp, d.partial = w.partial_l[l], d.partial_db = w.partial_db_l[l];
+            P4_LAUNCH((mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>), CfgDwE::LDS, pl.chunks, st, d)
+        }
+        if (l != 0) {
+            d.X = (const unsigned char*)w.Y[l - 1], d.Xexp = w.Yexp[l - 1];
+            d.partial = w.partial_l[l] + (l == sk ? (size_t)MLP_EMB * MLP_W : 0);
+            d.partial_db = l == sk ? nullptr : w.partial_db_l[l];  // (the skip layer's bias gradient came with its embedding half)
+            dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
+            P4_LAUNCH((mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>), CfgDw::LDS, pl.chunks, st, d)
+            dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
+        }
+        ReduceDwJob& jb = rb.job[l];
+        jb.chunks = pl.chunks, jb.db_rows = 8 * pl.chunks, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = reduce_dw_blocks(Kp);
+        jb.partial = w.partial_l[l], jb.partial_db = w.partial_db_l[l], jb.dW = dW[l], jb.db = db[l];
+        if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;
+        if (l >= 1) {
+            unsigned char* t = G;
+            G = Gn, Gn = t;
+            int* te = Ge;
+            Ge = Gne, Gne = te;
+        }
+    }
+    rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
+    rb.h_dW = dWh, rb.h_db = dbh;
+    hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, 9), dim3(256), 0, st, rb);
+    if (dtemb != nullptr)
+        hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
+                           db[sk], p->W[sk], layer_in(p, sk), dtemb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
+    return 0;
+}
 }  // namespace
 
 extern "C" {
 
 int dgm_mlp_set_gemm(int mode) {
     const int prev = g_gemm_mode;
-    if (mode >= 0 && mode <= 2) g_gemm_mode = mode;
+    if (mode >= 0 && mode <= 3) g_gemm_mode = mode;
     return prev;
 }
 
 size_t dgm_mlp_workspace_bytes(int N) {
     Ws w = carve(nullptr, N > 0 ? N : 0);
     return w.bytes;
+}
+
+int dgm_mlp_describe_workspace(int N, size_t* offs, int capacity) {
+    Ws w = carve(nullptr, N > 0 ? N : 0);
+    const char* base = nullptr;
+    const void* f[DGM_MLP_WS_FIELDS];
+    int n = 0;
+    f[n++] = w.emb;
+    for (int l = 0; l < 8; l++) f[n++] = w.Y[l];
+    for (int l = 0; l < 8; l++) f[n++] = w.mask[l];
+    f[n++] = w.Ga, f[n++] = w.Gb;
+    f[n++] = w.Eexp;
+    for (int l = 0; l < 8; l++) f[n++] = w.Yexp[l];
+    f[n++] = w.Dexp, f[n++] = w.Gexp[0], f[n++] = w.Gexp[1];
+    f[n++] = w.Cin, f[n++] = w.Dp;
+    for (int l = 0; l < 8; l++) f[n++] = w.partial_l[l];
+    for (int l = 0; l < 8; l++) f[n++] = w.partial_db_l[l];
+    for (int i = 0; i < n && i < capacity; i++) offs[i] = (size_t)((const char*)f[i] - base);
+    return n;
 }
 
 int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float* temb, int temb_stride, char* workspace,
@@ -959,8 +1179,10 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     if (!x || !temb || !workspace || !out) return mlp_fail("mlp_forward: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
-    remember_ws_mode(workspace, g_gemm_mode);
-    const bool f32 = use_f32_mfma();
+    const int mode = effective_mode(temb_stride);
+    remember_ws_mode(workspace, mode);
+    if (mode == 3) return forward_planes(p, N, x, temb, w, out, st);
+    const bool f32 = mode == 1;
     if (f32) {
         for (int l = 0; l < 8; l++) {
             const int Kp = layer_kp(p, l);
@@ -969,7 +1191,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
                                l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
         }
     } else {  // all weight re-layouts of the network in one launch per arithmetic
-        const bool x3 = use_f16x3();
+        const bool x3 = mode == 2;
         Prep6Batch pb;
         int nj = 0, max_threads = 0;
         auto add = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp,
@@ -1012,7 +1234,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     }
     {
         hipLaunchKernelGGL(mlp_embed_kernel, dim3((N + 7) / 8), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.emb);
-        if (use_f16x3()) {
+        if (mode == 2) {
             const int nbx = (int)(((size_t)N * 3 + 3071) / 3072), nbt = temb_stride != 0 ? 256 : 1;
             hipLaunchKernelGGL(mlp_embed_cmax_kernel, dim3(nbx + nbt), dim3(256), 0, st, N, nbx, x, temb, temb_stride, p->t_dim,
                                w.cmaxE);
@@ -1032,7 +1254,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         }
         if (!f32) {
             const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
-            if (K1 + K2 == MLP_EMB + MLP_W && use_f16x3()) {
+            if (K1 + K2 == MLP_EMB + MLP_W && mode == 2) {
                 // skip layer, trunk half: Y5 = relu(Y4 * W5[:, emb:]^T + C_in), C_in = emb * W5[:, :emb]^T + b5 already in Y5
                 // (not under the mlp_layer_fwd stage timer: it also reads C_in, 1.5x the bytes of a plain 256 -> 256 layer)
                 hipLaunchKernelGGL((mlp_gemm3p_kernel<2, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A2, lda2,
@@ -1041,7 +1263,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
             } else if (K1 + K2 == MLP_EMB + MLP_W) {  // skip layer: bf16x6, weights streamed through LDS
                 hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2,
                                    lda2, K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W);
-            } else if (use_f16x3()) {
+            } else if (mode == 2) {
                 if (K1 + K2 == MLP_W) {
                     dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
                     hipLaunchKernelGGL((mlp_gemm3p_kernel<0, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
@@ -1083,21 +1305,23 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     if (check_params(p)) return 1;
     if (N <= 0) return 0;
     if (!dOut || !workspace || !dW || !db || !dWh || !dbh) return mlp_fail("mlp_backward: NULL pointer");
+    const int mode = effective_mode(temb_stride);
     {
         const int fm = recall_ws_mode(workspace);
-        if (fm >= 0 && fm != g_gemm_mode)
+        if (fm >= 0 && fm != mode)
             return mlp_fail("mlp_backward: the arithmetic mode changed since the forward pass on this workspace (dgm_mlp_set_gemm)");
     }
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
+    if (mode == 3) return backward_planes(p, N, dOut, w, dW, db, dWh, dbh, dtemb, st);
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
     const int grid = (N + GM - 1) / GM;
-    const bool f32 = use_f32_mfma();
+    const bool f32 = mode == 1;
     // heads: G7 (masked by layer 7's ReLU, read off Y7 itself) and the partial sums of dWh / dbh in one pass over Y7
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, p->Wh, w.Y[7], w.Ga,
                        w.partial_h, w.partial_hb);
-    const bool x3 = use_f16x3();
+    const bool x3 = mode == 2;
     if (x3) {  // (the column maxima of the G_l for the weight gradients' scales, accumulated by the backward-data GEMMs, were
                // cleared by the forward pass)
         if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
@@ -1192,7 +1416,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
         }
     }
     if (!f32) {  // the weight gradients of all eight layers and of the heads: one reduction of their partial tiles
-        rb.h_chunks = hchunks, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
+        rb.h_chunks = hchunks, rb.h_bchunks = hchunks, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
         rb.h_dW = dWh, rb.h_db = dbh;
         hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, 9), dim3(256), 0, st, rb);
     }

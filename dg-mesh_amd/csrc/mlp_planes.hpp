@@ -1,0 +1,732 @@
+// The MLP trunk on "plane-format" activations ("f16x3p", dgm_mlp_set_gemm(3), the default).
+//
+// Same arithmetic as mlp_f16x3.hpp -- every fp32 operand scaled by a power of two and split into two binary16 numbers, three
+// partial products per product on v_mfma_f32_32x32x16_f16, fp32 accumulation -- but the split happens ONCE, in the epilogue of
+// the kernel that produces a tensor, and the tensor lives in HBM as its two binary16 planes (4 bytes per element, the traffic
+// of fp32):
+//     T[row] = [ h : K halves | l : K halves ]          value = (h + l) * 2^-e[row / 32]
+// with ONE exponent per 32-row tile (block floating point: the tile's maximum lands in [2^14, 2^15), so an element keeps 22
+// significant bits down to 2^-11 of its tile's maximum and 2^-39 of that maximum absolutely below).  A scale that is constant
+// over a 32-row tile is constant along the contraction of the layer GEMMs (features) AND, up to a per-tile power of two that the
+// weight-gradient kernel folds into one operand, along the contraction of the weight gradients (rows) -- so the three consumers
+// of a tensor (next layer, backward data, weight gradient) read the planes as they are: no row maxima, no scales, no split, no
+// staging registers.  The layer GEMM streams them into LDS with global_load_lds_dwordx4 and feeds the fragments to the MFMAs
+// unchanged; the weight-gradient kernel only transposes 8 x 8 blocks of halves in registers (v_perm).
+//
+// All tensors are padded to a multiple of 32 rows (the workspace is ours), padded rows hold finite values and the gradient
+// tensors' padded rows are exactly zero (they descend from zero rows of dOut), so no kernel predicates rows.
+#pragma once
+#include "dgm_common.hpp"
+#include "mlp_f16x3.hpp"
+
+namespace dgm {
+
+// exponent e of a tile from the float bits of its non-negative maximum: stored = value * 2^e, maximum -> [2^14, 2^15).
+// Clamped so that 2^e and 2^-e are normal floats (an all-zero tile gets a harmless finite scale).
+__device__ __forceinline__ int p4_exp_from_max_bits(unsigned bits) {
+    int eb = (int)((bits >> 23) & 0xffu);
+    eb = eb < 20 ? 20 : (eb > 250 ? 250 : eb);
+    return 141 - eb;
+}
+__device__ __forceinline__ float p4_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }  // e in [-126, 127]
+
+// 2^d (d <= 0) as a pair of binary16 (for v_pk_mul_f16); exact down to the smallest subnormal, 0 below
+__device__ __forceinline__ unsigned p4_pow2_h2(int d) {
+    unsigned h;
+    if (d >= -14) h = (unsigned)(d + 15) << 10;
+    else if (d >= -24) h = 1u << (d + 24);
+    else h = 0u;
+    return h | (h << 16);
+}
+
+// one wave-wide 1 KiB copy global -> LDS (lane i: 16 bytes from its own global address to lds_dst + 16 i); the destination
+// is wave-uniform.  Issued from inline asm: through the builtin the compiler treats the LDS-DMA as a store that may alias
+// every later ds_read and drains vmcnt in front of them.  Completion is ordered by hand (s_waitcnt vmcnt(0) + barrier).
+__device__ __forceinline__ void p4_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+#define P4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define P4_STEP_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ unsigned p4_lds_addr(const void* p) {
+    return (unsigned)(unsigned long)((__attribute__((address_space(3))) const char*)p);
+}
+
+// ---- per-matrix maxima + positional encoding ------------------------------------------------------------------------
+struct AbsMaxJob {
+    const float* W;
+    int n;
+};
+static constexpr int P4_MAX_MATS = 12;
+struct AbsMaxBatch {
+    int n_jobs;
+    AbsMaxJob job[P4_MAX_MATS];
+};
+
+// emb planes [Np][2][96] binary16 + one exponent per 32-row tile, rows >= N zero.
+//   emb[r] = [x, sin(x 2^0), cos(x 2^0), ..., sin(x 2^9), cos(x 2^9) | t_emb[r] | 0...]   (time_utils.py:24-55)
+// Grid: ntiles workgroups (one 32-row tile each) + am.n_jobs workgroups that reduce max |W| of one weight tensor each into
+// matmax[job] (float bits) -- the scales of the weight planes; riding along here saves a launch in front of the weight
+// preparation, which needs them.
+__global__ void __launch_bounds__(256)
+mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
+                  unsigned char* __restrict__ Ep, int* __restrict__ Eexp, const AbsMaxBatch am, unsigned* __restrict__ matmax) {
+    __shared__ float se[32][96 + 1];
+    __shared__ float smax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if ((int)blockIdx.x >= ntiles) {
+        const AbsMaxJob& jb = am.job[(int)blockIdx.x - ntiles];
+        float m = 0.f;
+        const int n4 = jb.n >> 2;
+        if ((((uintptr_t)jb.W) & 15) == 0) {
+            const float4* p = reinterpret_cast<const float4*>(jb.W);
+            for (int i = tid; i < n4; i += 256) {
+                const float4 v = p[i];
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+            for (int i = n4 * 4 + tid; i < jb.n; i += 256) m = fmaxf(m, fabsf(jb.W[i]));
+        } else {
+            for (int i = tid; i < jb.n; i += 256) m = fmaxf(m, fabsf(jb.W[i]));
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        if (lane == 0) smax[wv] = m;
+        __syncthreads();
+        if (tid == 0) matmax[(int)blockIdx.x - ntiles] = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+        return;
+    }
+    const int tile = blockIdx.x, r0 = tile * 32;
+    float mx = 0.f;
+    // sin / cos: lane < 60 of wave w evaluates one (row, frequency, axis) triple of rows 8 w + 2 it + {0, 1}
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        if (lane < 60) {
+            const int sub = lane / 30, p = lane - 30 * sub, rl = 8 * wv + 2 * it + sub, r = r0 + rl;
+            const int q = p / 3, a = p - 3 * q;
+            float sn = 0.f, cs = 0.f;
+            if (r < N) sincosf(x[3 * r + a] * (float)(1 << q), &sn, &cs);
+            se[rl][3 + 6 * q + a] = sn;
+            se[rl][6 + 6 * q + a] = cs;
+        }
+    }
+    // x, the time embedding, the zero padding: 36 columns per row
+    for (int i = tid; i < 32 * 36; i += 256) {
+        const int rl = i / 36, j = i - 36 * rl, r = r0 + rl;
+        float v = 0.f;
+        int c;
+        if (j < 3) {
+            c = j;
+            if (r < N) v = x[3 * r + j];
+        } else {
+            const int t = j - 3;
+            c = 63 + t;
+            if (r < N && t < T) v = temb[(size_t)r * temb_stride + t];
+        }
+        se[rl][c] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if (lane == 0) smax[wv] = mx;
+    __syncthreads();
+    // sin / cos columns are bounded by 1: fold that bound in instead of reducing them
+    const float tm = fmaxf(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])), 1.0f);
+    const int e = p4_exp_from_max_bits(__float_as_uint(tm));
+    const float sc = p4_pow2(e);
+    if (tid == 0) Eexp[tile] = e;
+    // 32 rows x 24 column quads: one 8-byte store per plane and quad
+    for (int i = tid; i < 32 * 24; i += 256) {
+        const int rl = i / 24, c4 = (i - 24 * rl) * 4;
+        unsigned h0, l0, h1, l1;
+        split2h(se[rl][c4] * sc, se[rl][c4 + 1] * sc, h0, l0);
+        split2h(se[rl][c4 + 2] * sc, se[rl][c4 + 3] * sc, h1, l1);
+        unsigned char* d = Ep + (size_t)(r0 + rl) * 384 + c4 * 2;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + 192) = make_uint2(l0, l1);
+    }
+}
+
+// ---- weight planes with ONE power-of-two scale per matrix ---------------------------------------------------------------
+// Same layout and source mapping as mlp_prep3_all_kernel (Bp[((stage*2 + plane)*2 + g)*ncols + col] = 8 halves of
+// B[k = stage*16 + g*8 + e][col] * scale), but the scale comes from the matrix maximum the embed launch left in matmax[mat]:
+// in the plane-format GEMM the weights are the M-side operand, a per-column scale would cost a multiplication per output
+// element and tile.  inv_scale[0] = 1 / scale.  Grid (ncols / 32 <= 8, jobs).
+struct Prep4Job {
+    Prep3Job j;
+    int mat;
+};
+static constexpr int P4_MAX_JOBS = 20;
+struct Prep4Batch {
+    Prep4Job job[P4_MAX_JOBS];
+};
+__global__ void __launch_bounds__(256)
+mlp_prep4_kernel(const Prep4Batch b, const unsigned* __restrict__ matmax) {
+    const Prep4Job& pj = b.job[blockIdx.y];
+    const Prep3Job& j = pj.j;
+    if ((int)blockIdx.x * 32 >= j.ncols) return;
+    const int tid = threadIdx.x, col = blockIdx.x * 32 + (tid & 31), slot = tid >> 5, nkg = j.Kp >> 3;
+    float sc, inv;
+    scale_from_max_bits(matmax[pj.mat], sc, inv);
+    if (blockIdx.x == 0 && tid == 0) j.inv_scale[0] = inv;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int kg = slot + 8 * it;
+        if (kg < nkg) {
+            float e[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) e[i] = prep3_src(j, kg * 8 + i, col);
+            uint4 H, L;
+            split2h(e[0] * sc, e[1] * sc, H.x, L.x);
+            split2h(e[2] * sc, e[3] * sc, H.y, L.y);
+            split2h(e[4] * sc, e[5] * sc, H.z, L.z);
+            split2h(e[6] * sc, e[7] * sc, H.w, L.w);
+            uint4* dst = j.Bp + ((size_t)(kg >> 1) * 4 + (kg & 1)) * j.ncols + col;
+            dst[0] = H;
+            dst[2 * j.ncols] = L;
+        }
+    }
+}
+
+// ---- dOut (N, n_out) fp32 -> planes [Np][2][32] + exponents, and the heads' bias-gradient partial sums --------------------
+// One wave per 32-row tile (lane = row, column half); columns >= n_out and rows >= N are zero, which is what makes every
+// gradient tensor's padded rows exactly zero.  partial_b[tile][16] = column sums of the tile (the heads' bias gradient).
+__global__ void __launch_bounds__(256)
+mlp_dout4_kernel(int N, int ntiles, int NC, const float* __restrict__ dOut, unsigned char* __restrict__ Dp, int* __restrict__ Dexp,
+                 float* __restrict__ partial_b) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wv;
+    if (tile >= ntiles) return;
+    const int rl = lane & 31, hf = lane >> 5, r = tile * 32 + rl;
+    float v[8];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = 8 * hf + i;
+        v[i] = (r < N && c < NC) ? dOut[(size_t)r * NC + c] : 0.f;
+        mx = fmaxf(mx, fabsf(v[i]));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    const int e = p4_exp_from_max_bits(__float_as_uint(mx));
+    const float sc = p4_pow2(e);
+    if (lane == 0) Dexp[tile] = e;
+    uint4 H, L;
+    split2h(v[0] * sc, v[1] * sc, H.x, L.x);
+    split2h(v[2] * sc, v[3] * sc, H.y, L.y);
+    split2h(v[4] * sc, v[5] * sc, H.z, L.z);
+    split2h(v[6] * sc, v[7] * sc, H.w, L.w);
+    unsigned char* d = Dp + (size_t)r * 128 + hf * 16;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(d) = H;
+    *reinterpret_cast<uint4*>(d + 32) = z;
+    *reinterpret_cast<uint4*>(d + 64) = L;
+    *reinterpret_cast<uint4*>(d + 96) = z;
+    // column sums over the 32 rows of the tile (lanes of one half), fixed order
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float s = v[i];
+#pragma unroll
+        for (int dd = 16; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd, 64);
+        if (rl == 0) partial_b[(size_t)tile * 16 + 8 * hf + i] = s;
+    }
+}
+
+// ---- the layer GEMM on planes ----------------------------------------------------------------------------------------------
+// C^T tile = W-planes (M side: 32 output columns per wave, stationary in registers) x A-planes^T (N side: the 32 rows of a
+// tile, from LDS): with the activations on the N side a lane of the accumulator holds ONE row and 16 of the wave's 32 output
+// columns -- four runs of four consecutive columns -- so the epilogue emits 8-byte pieces of the output planes (no 2-byte
+// stores), needs no ballots for the ReLU mask, and the per-tile input scale is one scalar.
+//   EPI 0: Y = relu(acc c + bias)            planes + tile exponent + ReLU mask out          (c = 2^-e_in / weight scale)
+//   EPI 1: G' = mask ? acc c : 0             planes + tile exponent out (backward data; mask of the layer below)
+//   EPI 2: Y = relu(acc c + Cin)             like EPI 0, Cin = the embedding half of the skip layer incl. its bias
+//   EPI 3: out[row][o] = acc c + bias[o]     fp32, o < n_valid (the heads; only wave 0 computes, the others help loading)
+//   DUAL : a second weight matrix over the same activations, out2 = acc2 c2 + bias2 (fp32, lane-native layout: the Cin of
+//          EPI 2) -- layer 0 and the embedding half of the skip layer share one read of the embedding.
+// Persistent grid, one 8-wave workgroup per CU, tiles round-robin.  Per tile step j every wave runs
+//   S : stores of tile j-2's output planes (staged in LDS by E2, read back as 1 KiB rows) and of tile j-1's mask block
+//   L : the global->LDS copy of tile j+1's rows (this wave's share), straight into the other A buffer
+//   M : the MFMAs of tile j, fragments from LDS, with
+//   E2: the second half of tile j-1's epilogue sliced in between -- tile maximum (8 wave maxima from LDS) -> exponent ->
+//       scale, split, 8-byte stores into the LDS staging tile
+//   E1: first half of tile j's epilogue -- unscale, bias / ReLU / mask, element maxima, wave maximum -> LDS
+// and one barrier.  The tile exponent needs the maximum over all 8 waves' columns, hence the two halves around a barrier.
+// Mask block of a tile: [32 rows][8 waves] words, bit 16 g + 4 q + e of word (row, w) <-> column 32 w + 8 q + 4 g + e
+// (private to this kernel: EPI 0 / 2 write it, EPI 1 reads it).
+struct Gemm4Args {
+    int ntiles, M;
+    const unsigned char* A;     // input planes, row pitch ROWB
+    const int* Aexp;            // [ntiles]
+    const uint4* Bp;            // weight planes
+    const float* b_inv;         // [1] 1 / weight scale
+    const float* bias;          // [256] (EPI 0) / [n_valid] (EPI 3)
+    const unsigned* mask_in;    // EPI 1
+    unsigned* mask_out;         // EPI 0 / 2
+    unsigned char* C;           // output planes [Np][2][256]
+    int* Cexp;                  // [ntiles]
+    const float4* cin;          // EPI 2: [ntiles][8][4][64] float4
+    const uint4* Bp2;           // DUAL
+    const float* b_inv2;
+    const float* bias2;
+    float4* out2;               // DUAL: [ntiles][8][4][64] float4
+    float* out;                 // EPI 3
+    int ldo, n_valid;
+};
+
+template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
+struct Gemm4Cfg {
+    static constexpr int PITCH = ROWB + 16;
+    static constexpr int ABYTES = 32 * PITCH;
+    static constexpr int A_END = (2 * ABYTES + 255) & ~255;
+    static constexpr bool PLANES_OUT = EPI != 3;
+    static constexpr int O_BYTES = PLANES_OUT ? 2 * 32768 : 0;
+    static constexpr int LDS = A_END + O_BYTES + 2 * 1024 + 2 * 8 * 4 + 64;
+};
+
+template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
+__global__ void __launch_bounds__(512)
+mlp_gemm4_kernel(const Gemm4Args a) {
+    using Cfg = Gemm4Cfg<KS, ROWB, PLANEB, EPI, DUAL, NCW>;
+    constexpr int PITCH = Cfg::PITCH, ABYTES = Cfg::ABYTES;
+    constexpr int LPR = ROWB / 16;                           // 16-byte pieces (lanes) per row
+    constexpr int RPI = LPR == 64 ? 1 : 64 / (LPR + 1);      // rows per copy instruction (one idle lane = the row pad)
+    constexpr int NI = (32 + RPI - 1) / RPI;                 // copy instructions per tile
+    constexpr bool PLANES_OUT = Cfg::PLANES_OUT;
+    constexpr int NCOLS = NCW * 32;
+    static_assert(!DUAL || EPI == 0, "the second output rides along with a ReLU layer");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Abuf = smem;                                       // [2][32][PITCH]
+    unsigned char* Obuf = smem + Cfg::A_END;                          // [2][32][1024] staging of the output planes (swizzled)
+    unsigned* mbuf = reinterpret_cast<unsigned*>(smem + Cfg::A_END + Cfg::O_BYTES);  // [2][32][8] mask words
+    float* tmaxs = reinterpret_cast<float*>(mbuf + 512);              // [2][8] wave maxima
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int G = gridDim.x;
+    const int my_tiles = (a.ntiles - (int)blockIdx.x + G - 1) / G;
+    if (my_tiles <= 0) return;
+    const bool computing = wv < NCW;
+
+    // stationary weights: M-side fragments of this wave's 32 output columns
+    f16x8 wh[KS], wl[KS];
+    f16x8 wh2[DUAL ? KS : 1], wl2[DUAL ? KS : 1];
+    float binv = 0.f, binv2 = 0.f;
+    float bias[16], bias2[DUAL ? 16 : 1];
+    if (computing) {
+        const int col = wv * 32 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const uint4* b = a.Bp + ((size_t)ks * 4 + g) * NCOLS + col;
+            wh[ks] = as_f16x8(b[0]), wl[ks] = as_f16x8(b[2 * NCOLS]);
+            if (DUAL) {
+                const uint4* b2 = a.Bp2 + ((size_t)ks * 4 + g) * NCOLS + col;
+                wh2[DUAL ? ks : 0] = as_f16x8(b2[0]), wl2[DUAL ? ks : 0] = as_f16x8(b2[2 * NCOLS]);
+            }
+        }
+        binv = a.b_inv[0];
+        if (DUAL) binv2 = a.b_inv2[0];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int o = wv * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+            bias[i] = 0.f;
+            if (EPI == 0) bias[i] = a.bias[o];
+            if (EPI == 3) bias[i] = o < a.n_valid ? a.bias[o] : 0.f;
+            if (DUAL) bias2[DUAL ? i : 0] = a.bias2[o];
+        }
+    }
+
+    // copy geometry of this lane: instruction n covers rows n RPI .. n RPI + RPI - 1
+    const int cp_row = LPR == 64 ? 0 : lane / (LPR + 1), cp_piece = LPR == 64 ? lane : lane % (LPR + 1);
+    const bool cp_lane_ok = cp_piece < LPR && cp_row < RPI;
+    const unsigned abuf_lds = p4_lds_addr(Abuf);
+#define G4_COPY(tile_, pb_)                                                                                            \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int n0_ = 0; n0_ < NI; n0_ += 8) {                                                      \
+            const int n_ = n0_ + wv;                                                                                   \
+            if (n_ < NI) {                                                                                             \
+                const int row_ = n_ * RPI + cp_row;                                                                    \
+                if (cp_lane_ok && row_ < 32) {                                                                         \
+                    const unsigned char* src_ = a.A + ((size_t)(tile_) * 32 + row_) * ROWB + cp_piece * 16;            \
+                    p4_glds16(src_, __builtin_amdgcn_readfirstlane(abuf_lds + (pb_) * ABYTES + n_ * RPI * PITCH));     \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc, acc2;
+    float v[16];          // E1 -> E2: the tile's unscaled outputs of this lane (row li; columns 8 q + 4 g + e of the wave)
+    // lane constants of the staging-tile swizzle: 8-byte chunk u = 64 p + 8 w + 2 q + g of row r lives at chunk u ^ (r & 15)
+    const unsigned st_x8 = (unsigned)(((8 * wv + g) ^ (li & 15)) << 3);
+
+    // prologue: tile 0 into buffer 0
+    G4_COPY(blockIdx.x, 0)
+    P4_STEP_BARRIER();
+
+    for (int j = 0; j < my_tiles + 2; j++) {
+        const int pb = j & 1;
+        const int tile = blockIdx.x + j * G;
+        const bool has_m = j < my_tiles;            // MFMAs + E1 of tile j
+        const bool has_e2 = PLANES_OUT && j >= 1 && j <= my_tiles;   // tile j - 1
+        const bool has_s = PLANES_OUT && j >= 2;    // tile j - 2
+        int e_in = 0;
+        unsigned mhalf = 0u;
+        float4 cinv[EPI == 2 ? 4 : 1];
+        if (has_m && computing) {
+            e_in = __builtin_amdgcn_readfirstlane(a.Aexp[tile]);
+            if (EPI == 1)
+                mhalf = reinterpret_cast<const unsigned short*>(a.mask_in)[(((size_t)tile * 32 + li) * 8 + wv) * 2 + g];
+            if (EPI == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) cinv[EPI == 2 ? q : 0] = a.cin[(((size_t)tile * 8 + wv) * 4 + q) * 64 + lane];
+            }
+        }
+        // ---- S: tile j-2's planes, tile j-1's mask block
+        if (has_s) {
+            const int ts = tile - 2 * G;
+            const unsigned char* ob = Obuf + pb * 32768;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int r = wv * 4 + rr;
+                const int mp = (r >> 1) & 7;
+                uint4 val = *reinterpret_cast<const uint4*>(ob + r * 1024 + ((lane ^ mp) << 4));
+                if (rr & 1) val = make_uint4(val.z, val.w, val.x, val.y);
+                *reinterpret_cast<uint4*>(a.C + ((size_t)ts * 32 + r) * 1024 + lane * 16) = val;
+            }
+        }
+        if ((EPI == 0 || EPI == 2) && j >= 1 && j <= my_tiles && wv == 7) {
+            const uint4 mv = reinterpret_cast<const uint4*>(mbuf + (1 - pb) * 256)[lane];
+            reinterpret_cast<uint4*>(a.mask_out + (size_t)(tile - G) * 256)[lane] = mv;
+        }
+        // ---- L: tile j+1 into the other buffer (its last readers finished before the previous barrier)
+        if (j + 1 < my_tiles) G4_COPY(tile + G, 1 - pb)
+
+        // ---- E2 prologue: exponent of tile j-1 from the eight wave maxima
+        float so = 0.f;
+        unsigned char* ow = Obuf + (1 - pb) * 32768 + li * 1024;
+        if (has_e2 && computing) {
+            const float4 t0 = *reinterpret_cast<const float4*>(tmaxs + (1 - pb) * 8);
+            const float4 t1 = *reinterpret_cast<const float4*>(tmaxs + (1 - pb) * 8 + 4);
+            const float tm = fmaxf(fmaxf(fmaxf(t0.x, t0.y), fmaxf(t0.z, t0.w)), fmaxf(fmaxf(t1.x, t1.y), fmaxf(t1.z, t1.w)));
+            const int eo = p4_exp_from_max_bits(__float_as_uint(tm));
+            so = p4_pow2(eo);
+            if (tid == 0) a.Cexp[tile - G] = eo;
+        }
+#define G4_E2_SLICE(q_)                                                                                                \
+    if (has_e2 && computing) {                                                                                         \
+        unsigned h0_, l0_, h1_, l1_;                                                                                   \
+        split2h(v[4 * (q_)] * so, v[4 * (q_) + 1] * so, h0_, l0_);                                                     \
+        split2h(v[4 * (q_) + 2] * so, v[4 * (q_) + 3] * so, h1_, l1_);                                                 \
+        unsigned char* d_ = ow + (st_x8 ^ ((q_) << 4));                                                                \
+        *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                                          \
+        *reinterpret_cast<uint2*>(d_ + 512) = make_uint2(l0_, l1_);                                                    \
+    }
+
+        // ---- M (+ E2 slices)
+        if (has_m && computing) {
+            const unsigned char* ps = Abuf + pb * ABYTES + li * PITCH + g * 16;
+            f16x8 fh[2], fl[2];
+            fh[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps));
+            fl[0] = as_f16x8(*reinterpret_cast<const uint4*>(ps + PLANEB));
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                if (ks + 1 < KS) {
+                    fh[(ks + 1) & 1] = as_f16x8(*reinterpret_cast<const uint4*>(ps + (ks + 1) * 32));
+                    fl[(ks + 1) & 1] = as_f16x8(*reinterpret_cast<const uint4*>(ps + PLANEB + (ks + 1) * 32));
+                }
+                // two accumulator chains, alternated MFMA by MFMA (DUAL: one chain per output)
+                if (DUAL) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], fh[ks & 1], ks == 0 ? zero16 : acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl2[DUAL ? ks : 0], fh[ks & 1], ks == 0 ? zero16 : acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], fl[ks & 1], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh2[DUAL ? ks : 0], fl[ks & 1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], fh[ks & 1], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh2[DUAL ? ks : 0], fh[ks & 1], acc2, 0, 0, 0);
+                } else if (ks == 0) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0], fh[0], zero16, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0], fh[0], zero16, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0], fl[0], acc2, 0, 0, 0);
+                } else if (ks & 1) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], fh[ks & 1], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], fh[ks & 1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], fl[ks & 1], acc, 0, 0, 0);
+                } else {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], fh[ks & 1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], fh[ks & 1], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], fl[ks & 1], acc2, 0, 0, 0);
+                }
+                if (PLANES_OUT) {
+                    if (ks == (2 * KS) / 6 && KS > 1) G4_E2_SLICE(0)
+                    if (ks == (3 * KS) / 6 && KS > 1) G4_E2_SLICE(1)
+                    if (ks == (4 * KS) / 6 && KS > 1) G4_E2_SLICE(2)
+                    if (ks == (5 * KS) / 6 && KS > 1) G4_E2_SLICE(3)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (PLANES_OUT && (KS == 1 || !(has_m && computing))) {  // (no MFMA phase to hide them in)
+            G4_E2_SLICE(0)
+            G4_E2_SLICE(1)
+            G4_E2_SLICE(2)
+            G4_E2_SLICE(3)
+        }
+
+        // ---- E1: tile j
+        if (has_m && computing) {
+            const float c = binv * p4_pow2(-e_in);
+            if (DUAL) {  // second output: linear, lane-native fp32 (coalesced 1 KiB stores)
+                const float c2 = binv2 * p4_pow2(-e_in);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float4 o;
+                    o.x = acc2[4 * q + 0] * c2 + bias2[DUAL ? 4 * q + 0 : 0];
+                    o.y = acc2[4 * q + 1] * c2 + bias2[DUAL ? 4 * q + 1 : 0];
+                    o.z = acc2[4 * q + 2] * c2 + bias2[DUAL ? 4 * q + 2 : 0];
+                    o.w = acc2[4 * q + 3] * c2 + bias2[DUAL ? 4 * q + 3 : 0];
+                    a.out2[(((size_t)tile * 8 + wv) * 4 + q) * 64 + lane] = o;
+                }
+            }
+            if (EPI == 3) {
+                const int row = tile * 32 + li;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int o = (i & 3) + 8 * (i >> 2) + 4 * g;
+                    if (o < a.n_valid && row < a.M) a.out[(size_t)row * a.ldo + o] = (acc[i] + acc2[i]) * c + bias[i];
+                }
+            } else {
+                unsigned bits = 0u;
+                float m = 0.f;
+#pragma unroll
+                for (int i = 15; i >= 0; i--) {
+                    const float s = DUAL ? acc[i] : acc[i] + acc2[i];
+                    float t;
+                    if (EPI == 0) t = s * c + bias[i];
+                    else if (EPI == 2) {
+                        const float4 cq = cinv[EPI == 2 ? (i >> 2) : 0];
+                        t = s * c + ((i & 3) == 0 ? cq.x : (i & 3) == 1 ? cq.y : (i & 3) == 2 ? cq.z : cq.w);
+                    } else t = s * c;
+                    if (EPI == 1) {
+                        v[i] = ((mhalf >> i) & 1u) ? t : 0.f;
+                    } else {
+                        asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(t) : "vcc");
+                        v[i] = fmaxf(t, 0.f);
+                    }
+                    m = fmaxf(m, fabsf(v[i]));
+                }
+                m = wave_max_nonneg_lane63(m);
+                if (lane == 63) tmaxs[pb * 8 + wv] = m;
+                if (EPI != 1) reinterpret_cast<unsigned short*>(mbuf + pb * 256)[(li * 8 + wv) * 2 + g] = (unsigned short)bits;
+            }
+        }
+        P4_STEP_BARRIER();
+    }
+#undef G4_COPY
+#undef G4_E2_SLICE
+}
+
+// ---- weight gradient on planes -----------------------------------------------------------------------------------------------
+// partial[chunk][k][j] = sum over the chunk's rows of X[row][k] * G[row][j], X and G both in plane format.
+// A chunk is a run of whole 32-row tiles; tile t carries the scale 2^(ex_t + eg_t).  With E_ref = min over the chunk, the X side
+// of tile t is multiplied by 2^(E_ref - E_t) <= 1 in binary16 (exact; skipped when it is 1) and the sum is unscaled by
+// 2^-E_ref at the end -- tiles far below the chunk's largest lose their lowest bits, which weigh nothing in the sum.
+// Staging: a thread loads an 8-row x 8-column block of one plane (eight 16-byte loads, a wave instruction = two 512-byte
+// row segments), transposes it with v_perm into eight granules "8 rows of one column" and writes them where the MFMA
+// fragments are read as 16-byte granules: [plane][row group of 8][column], the column position XOR-swizzled inside groups of
+// eight so that the eight granule stores of a thread and the fragment reads are both conflict-free.
+//   NT == 8: wave w owns gradient columns [32 w, 32 w + 32) against all MT x 32 input columns.
+//   NT == 1: 32 gradient columns in all (the heads: G = dOut planes), wave w owns input columns [32 w, 32 w + 32); the result
+//            goes to the heads' partial layout partial[(chunk * 16 + o) * 256 + c].
+// Bias gradients (db = column sums of G) ride along in the G stagers: v_dot2_f32_f16 against (1, 1) per transposed dword, the
+// tile's sums unscaled by 2^-eg_t; partial_db[(chunk * 8 + plane * 4 + row group)][column].
+struct Dw4Args {
+    int ntiles, tiles_per_chunk;
+    const unsigned char* X;
+    const int* Xexp;
+    const unsigned char* G;
+    const int* Gexp;
+    float* partial;       // + row offset already applied
+    size_t chunk_stride;  // floats between chunks
+    float* partial_db;    // may be NULL
+};
+
+__device__ __forceinline__ int dw4_pos(int col) { return (col & ~7) | ((col ^ (col >> 3)) & 7); }
+__device__ __forceinline__ unsigned dw4_dword(const uint4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+// acc + both halves of a dword (v_dot2_f32_f16 against (1, 1))
+__device__ __forceinline__ float dw4_dot_ones(unsigned d, float acc) {
+    const f16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, d), one, acc, false);
+}
+__device__ __forceinline__ unsigned dw4_pk_mul(unsigned d, unsigned f2) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, d) * __builtin_bit_cast(f16x2, f2));
+}
+
+template <int MT, int NT, int XROWB, int XPLANEB, int GROWB, int GPLANEB>
+struct Dw4Cfg {
+    static constexpr int XK = MT * 32, GK = NT * 32;
+    static constexpr int XU = 8 * XK, GU = 8 * GK;  // uint4 granules per stage buffer: [plane 2][row group 4][column]
+    static constexpr int LDS = 2 * (XU + GU) * 16;
+};
+
+template <int MT, int NT, int XROWB, int XPLANEB, int GROWB, int GPLANEB>
+__global__ void __launch_bounds__(512)
+mlp_dw4_kernel(const Dw4Args a) {
+    using Cfg = Dw4Cfg<MT, NT, XROWB, XPLANEB, GROWB, GPLANEB>;
+    constexpr int XK = Cfg::XK, GK = Cfg::GK, XU = Cfg::XU, GU = Cfg::GU;
+    constexpr int XCG = XK / 8, GCG = GK / 8;    // column groups
+    constexpr int XB = XCG * 8, GB = GCG * 8;    // stager threads per operand
+    constexpr int MTW = NT == 8 ? MT : 1;        // m-tiles per wave
+    static_assert(NT == 8 || (NT == 1 && MT == 8), "wave decomposition");
+    static_assert(XB <= 256 && GB <= 256, "stager layout");
+    extern __shared__ __attribute__((aligned(16))) uint4 dw4_lds[];
+    uint4* Xs = dw4_lds;             // [2][XU]
+    uint4* Gs = dw4_lds + 2 * XU;    // [2][GU]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int chunk = blockIdx.x;
+    const int t0 = chunk * a.tiles_per_chunk, t1 = min(a.ntiles, t0 + a.tiles_per_chunk);
+    const int nst = t1 - t0;
+    if (nst <= 0) return;
+
+    // E_ref = min over the chunk's tiles of ex + eg
+    int eref = 0x7fffffff;
+    for (int t = t0; t < t1; t++) eref = min(eref, a.Xexp[t] + a.Gexp[t]);
+    eref = __builtin_amdgcn_readfirstlane(eref);
+
+    // stager geometry
+    const bool isX = tid < XB, isG = tid >= 256 && tid < 256 + GB;
+    const int st = isG ? tid - 256 : tid;
+    const int ncg = isG ? GCG : XCG;
+    const int cg = st % ncg, rg = (st / ncg) & 3, pl = st / (ncg * 4);
+    const unsigned char* src = isG ? a.G + (size_t)pl * GPLANEB + cg * 16 : a.X + (size_t)pl * XPLANEB + cg * 16;
+    const int srow = isG ? GROWB : XROWB;
+    uint4* sdst = (isG ? Gs : Xs) + (pl * 4 + rg) * (isG ? GK : XK) + cg * 8;
+    const int sbuf = isG ? GU : XU;
+    const int swz = cg & 7;
+    uint4 R[8];
+    float cs[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cs[i] = 0.f;
+
+#define DW4_LOAD(t_)                                                                                                   \
+    if (isX || isG) {                                                                                                  \
+        const unsigned char* p_ = src + ((size_t)(t_) * 32 + rg * 8) * srow;                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) R[i_] = *reinterpret_cast<const uint4*>(p_ + (size_t)i_ * srow); \
+    }
+    // transpose the 8 x 8 block: granule c (column 8 cg + c) = rows 0..7 = four dwords of two rows each
+#define DW4_STORE(t_, buf_)                                                                                            \
+    if (isX || isG) {                                                                                                  \
+        const int et_ = a.Xexp[t_] + a.Gexp[t_];                                                                       \
+        const unsigned f2_ = p4_pow2_h2(eref - et_);                                                                   \
+        const bool scale_ = isX && et_ != eref;                                                                        \
+        float tsum_[8];                                                                                                \
+        _Pragma("unroll") for (int c_ = 0; c_ < 8; c_++) {                                                             \
+            const unsigned sel_ = (c_ & 1) ? 0x07060302u : 0x05040100u;                                                \
+            uint4 o_;                                                                                                  \
+            o_.x = __builtin_amdgcn_perm(dw4_dword(R[1], c_ >> 1), dw4_dword(R[0], c_ >> 1), sel_);                    \
+            o_.y = __builtin_amdgcn_perm(dw4_dword(R[3], c_ >> 1), dw4_dword(R[2], c_ >> 1), sel_);                    \
+            o_.z = __builtin_amdgcn_perm(dw4_dword(R[5], c_ >> 1), dw4_dword(R[4], c_ >> 1), sel_);                    \
+            o_.w = __builtin_amdgcn_perm(dw4_dword(R[7], c_ >> 1), dw4_dword(R[6], c_ >> 1), sel_);                    \
+            if (isG && a.partial_db != nullptr) {                                                                      \
+                float s_ = dw4_dot_ones(o_.x, 0.f);                                                                    \
+                s_ = dw4_dot_ones(o_.y, s_), s_ = dw4_dot_ones(o_.z, s_), s_ = dw4_dot_ones(o_.w, s_);                 \
+                tsum_[c_] = s_;                                                                                        \
+            }                                                                                                          \
+            if (scale_) o_.x = dw4_pk_mul(o_.x, f2_), o_.y = dw4_pk_mul(o_.y, f2_), o_.z = dw4_pk_mul(o_.z, f2_), o_.w = dw4_pk_mul(o_.w, f2_); \
+            sdst[(buf_) * sbuf + (c_ ^ swz)] = o_;                                                                     \
+        }                                                                                                              \
+        if (isG && a.partial_db != nullptr) {                                                                          \
+            const float ig_ = p4_pow2(-a.Gexp[t_]);                                                                    \
+            _Pragma("unroll") for (int c_ = 0; c_ < 8; c_++) cs[c_] += tsum_[c_] * ig_;                                \
+        }                                                                                                              \
+    }
+
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+
+    // fragment positions of this lane
+    const int gcol = NT == 8 ? wv * 32 + li : li;
+    const int gpos = dw4_pos(gcol);
+
+    DW4_LOAD(t0)
+    DW4_STORE(t0, 0)
+    if (nst > 1) DW4_LOAD(t0 + 1)
+    __syncthreads();
+    for (int s = 0; s < nst; s++) {
+        const int buf = s & 1;
+        if (s + 1 < nst) {
+            DW4_STORE(t0 + s + 1, buf ^ 1)
+            if (s + 2 < nst) DW4_LOAD(t0 + s + 2)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4* xs = Xs + buf * XU;
+        const uint4* gs = Gs + buf * GU;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int kg = 2 * kk + g;
+            const f16x8 gh = as_f16x8(gs[kg * GK + gpos]), gl = as_f16x8(gs[(4 + kg) * GK + gpos]);
+            if (MTW == 1) {
+                const int xpos = dw4_pos(wv * 32 + li);
+                const f16x8 ah = as_f16x8(xs[kg * XK + xpos]), al = as_f16x8(xs[(4 + kg) * XK + xpos]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc[0], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mp = 0; mp < (MTW + 1) / 2; mp++) {
+                    const int m0 = 2 * mp, m1 = 2 * mp + 1 < MTW ? 2 * mp + 1 : 2 * mp;
+                    const int xp0 = dw4_pos(m0 * 32 + li), xp1 = dw4_pos(m1 * 32 + li);
+                    const f16x8 ah0 = as_f16x8(xs[kg * XK + xp0]), al0 = as_f16x8(xs[(4 + kg) * XK + xp0]);
+                    if (m1 != m0) {  // two accumulators alternate
+                        const f16x8 ah1 = as_f16x8(xs[kg * XK + xp1]), al1 = as_f16x8(xs[(4 + kg) * XK + xp1]);
+                        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, gl, acc[m0], 0, 0, 0);
+                        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, gl, acc[m1], 0, 0, 0);
+                        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, gh, acc[m0], 0, 0, 0);
+                        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, gh, acc[m1], 0, 0, 0);
+                        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, gh, acc[m0], 0, 0, 0);
+                        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, gh, acc[m1], 0, 0, 0);
+                    } else {
+                        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, gl, acc[m0], 0, 0, 0);
+                        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, gh, acc[m0], 0, 0, 0);
+                        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, gh, acc[m0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        P4_LDS_BARRIER();  // LDS-only: the rows just prefetched stay in flight
+    }
+#undef DW4_LOAD
+#undef DW4_STORE
+
+    if (NT == 8) {
+        float* out = a.partial + (size_t)chunk * a.chunk_stride;
+        const int col = wv * 32 + li;
+#pragma unroll
+        for (int mt = 0; mt < MTW; mt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                out[(size_t)k * 256 + col] = ldexpf(acc[mt][r], -eref);
+            }
+        }
+    } else {
+        if (li < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int c = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                a.partial[((size_t)chunk * 16 + li) * 256 + c] = ldexpf(acc[0][r], -eref);
+            }
+        }
+    }
+    if (isG && a.partial_db != nullptr) {
+        float* d = a.partial_db + ((size_t)chunk * 8 + pl * 4 + rg) * GK + cg * 8;
+        *reinterpret_cast<float4*>(d) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+    }
+}
+
+}  // namespace dgm

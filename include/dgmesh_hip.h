@@ -207,16 +207,25 @@ typedef struct {
     const float* bh;
 } dgm_mlp_params;
 
-/* Arithmetic of the trunk GEMMs.  2 (default): "f16x3" -- fp32 operands scaled by a power of two and split into two binary16
+/* Arithmetic of the trunk GEMMs.  3 (default): "f16x3p" -- the f16x3 arithmetic below on plane-format activations: every
+ * activation / gradient tensor lives in HBM as its two binary16 planes with one power-of-two exponent per 32-row tile, split once
+ * by the kernel that produces it (needs a broadcast time embedding, temb_stride == 0; other calls run mode 2).  2: "f16x3" -- fp32 operands scaled by a power of two and split into two binary16
  * numbers, three partial products accumulated in fp32 on the f16 matrix cores; 0: "bf16x6" -- operands split exactly into
- * three bf16 numbers, six partial products; 1: native fp32 MFMA.  All three are fp32 GEMMs to rounding.  Returns the previous
+ * three bf16 numbers, six partial products; 1: native fp32 MFMA.  All four are fp32 GEMMs to rounding.  Returns the previous
  * mode; any other value only queries.  Process-wide; the initial value comes from the environment variable
- * DGM_MLP_GEMM=f16x3|bf16x6|f32.  A forward and its backward must run in the same mode. */
+ * DGM_MLP_GEMM=f16x3p|f16x3|bf16x6|f32.  A forward and its backward must run in the same mode. */
 int dgm_mlp_set_gemm(int mode);
 
 /* Bytes of the workspace that forward fills (embedding, the 8 post-ReLU activations, re-laid-out
  * weights, scratch) and backward consumes; caller-owned, must stay alive between the two calls. */
 size_t dgm_mlp_workspace_bytes(int N);
+
+/* Introspection for tests and tools: byte offsets of the workspace's per-row tensors for N rows, in this order:
+ * emb, Y[0..7], mask[0..7], Ga, Gb, Eexp, Yexp[0..7], Dexp, Gexp[0..1], Cin, Dp, partial[0..7], partial_db[0..7]
+ * (DGM_MLP_WS_FIELDS entries).  In the plane arithmetic (mode 3) emb / Y / G rows are [h : K halves | l : K halves] with one
+ * int exponent per 32-row tile in the matching *exp array: value = (h + l) * 2^-e.  Returns the number of fields. */
+#define DGM_MLP_WS_FIELDS 49
+int dgm_mlp_describe_workspace(int N, size_t* offs, int capacity);
 
 /* out (N, n_out) = heads(trunk(x (N,3), temb)).  temb: (N, t_dim) with row stride temb_stride floats,
  * or ONE row broadcast to all N when temb_stride == 0 (t is identical for all rows in training). */
