@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdgmesh_hip.so")
+# DGM_LIB_PATH: developer override used by tools/build_variant.sh A/B runs (another build of the SAME library)
+LIB_PATH = os.environ.get("DGM_LIB_PATH") or os.path.join(_HERE, "lib", "libdgmesh_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _c = ctypes

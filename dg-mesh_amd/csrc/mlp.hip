@@ -832,7 +832,9 @@ int g_gemm_mode = [] {
     if (strcmp(e, "f16x3") == 0) return 2;
     return 3;  // "f16x3p"
 }();
-int effective_mode(int temb_stride) { return (g_gemm_mode == 3 && temb_stride != 0) ? 2 : g_gemm_mode; }
+// (the plane kernels keep a workgroup's tile exponents in a 512-entry LDS table: beyond 512 tiles per workgroup -- N > 4 M
+// rows on 256 CUs -- the call runs mode 2 as well)
+int effective_mode(int temb_stride, int N);
 // arithmetic the last forward pass on a workspace ran in: the backward pass must match (its scales and masks were produced by
 // that forward pass).  A small host-side table keyed by the workspace pointer; an unknown workspace is not checked.
 struct WsMode {
@@ -880,6 +882,11 @@ P4Plan p4_plan(int N) {
     if (d.tiles_per_chunk < 1) d.tiles_per_chunk = 1;
     d.chunks = (d.ntiles + d.tiles_per_chunk - 1) / d.tiles_per_chunk;
     return d;
+}
+int effective_mode(int temb_stride, int N) {
+    if (g_gemm_mode != 3) return g_gemm_mode;
+    if (temb_stride != 0 || (long long)(N + 31) / 32 > 512LL * num_cus()) return 2;
+    return 3;
 }
 Ws carve(char* base, int N) {
     Ws w;
@@ -1153,6 +1160,12 @@ size_t dgm_mlp_workspace_bytes(int N) {
     return w.bytes;
 }
 
+#ifdef P4_TIMING
+int dgm_p4_timing(unsigned long long* out) {  // (variant builds only: phase timers of the layer GEMM, see mlp_planes.hpp)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dgm::g_p4_timing), sizeof(unsigned long long) * 256 * 8 * 16);
+}
+#endif
+
 int dgm_mlp_describe_workspace(int N, size_t* offs, int capacity) {
     Ws w = carve(nullptr, N > 0 ? N : 0);
     const char* base = nullptr;
@@ -1179,7 +1192,7 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     if (!x || !temb || !workspace || !out) return mlp_fail("mlp_forward: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
-    const int mode = effective_mode(temb_stride);
+    const int mode = effective_mode(temb_stride, N);
     remember_ws_mode(workspace, mode);
     if (mode == 3) return forward_planes(p, N, x, temb, w, out, st);
     const bool f32 = mode == 1;
@@ -1305,7 +1318,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     if (check_params(p)) return 1;
     if (N <= 0) return 0;
     if (!dOut || !workspace || !dW || !db || !dWh || !dbh) return mlp_fail("mlp_backward: NULL pointer");
-    const int mode = effective_mode(temb_stride);
+    const int mode = effective_mode(temb_stride, N);
     {
         const int fm = recall_ws_mode(workspace);
         if (fm >= 0 && fm != mode)
