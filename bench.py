@@ -19,6 +19,13 @@ matrix pipe it issues on (3 MFMAs per fp32 product: 3 x flops / 2.5 PFLOP/s); `b
 `roofline_render_bwd` is the rasterizer backward, the kernel group BASELINE.json's north_star grades against HBM.
 `kernels` lists the same two fractions for every instrumented kernel.  When K < 200 a second, 200-step steady-state
 region is timed and reported as `steady_state` (SURVEY.md section 8d asks for >= 200 iterations).
+`--gpus N` without a launcher environment (no WORLD_SIZE) re-executes this script under torch.distributed.run with N ranks on
+127.0.0.1 (one per GPU, backend nccl = RCCL); it refuses to run when fewer than N devices are visible.  The JSON then also
+carries the RCCL world size observed and the all-reduce of the step's gradient buckets timed on its own.
+`mlp_f32_mode` = the same workload with the MLP GEMMs on the native fp32 MFMA instruction (dgm_mlp_set_gemm(1)), a short extra
+region at N = 1.  `roofline_render_bwd_trained` = the rasterizer backward on SURVEY.md section 8(d)'s trained-like scene (the
+distribution on which north_star's HBM target is approachable), measured here with the library's stage timers; `frac_valu` of
+the blend kernels comes from the committed PMC pass (VALU lane operations / 78.6 T lane-op/s).
 `cpu_baseline` = the same step on the host cores (oracle rasterizer + PyTorch-CPU MLPs; a port of the reference's CPU
 path, not the reference itself, which is not on the GPU box), rank 0 at N=1 only, on a bounded sample.
 """
@@ -144,6 +151,74 @@ def cpu_baseline(P, W, H, max_threads=32):
                       f"fwd+bwd (C/OpenMP) + 2 deformation MLPs fwd+bwd + L1/SSIM + Adam on PyTorch-CPU, {dt:.1f} s each"}
 
 
+def trained_like_render_bwd(dev, iters=12):
+    """Rasterizer forward + backward on SURVEY.md section 8(d)'s trained-like scene (shell of radius 0.8, sigma ~ 0.01,
+    opacity U[0.5, 0.99]: early termination as in a converged scene) at the workload's resolution, stage timers of the library
+    (hipEvents on the launch stream).  Returns the render-backward roofline block north_star asks for."""
+    syn = importlib.import_module("dg-mesh_amd.synthetic")
+    L = importlib.import_module("dg-mesh_amd._lib")
+    RZ = importlib.import_module("dg-mesh_amd.rasterizer")
+    c = syn.CONFIGS[WORKLOAD]
+    P, W, H = c["P"], c["W"], c["H"]
+    g = syn.make_gaussians(P, seed=0, kind="trained", dist2=np.full(P, 1e-4, np.float32))
+    a = syn.activate(g)
+    cam = syn.config_camera(WORKLOAD, frame=3)
+    T = lambda x: torch.tensor(x, device=dev)
+    bg = T(np.ones(3, np.float32))
+    means3D, opac, scales, rots, sh = T(a["means3D"]), T(a["opacities"]), T(a["scales"]), T(a["rotations"]), T(a["shs"])
+    vm, pm, campos = T(cam.world_view_transform), T(cam.full_proj_transform), T(cam.camera_center)
+    tanx, tany = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    e = torch.empty(0, device=dev)
+    dL = torch.randn(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    L.lib().dgm_set_profiling(1)
+    acc = {}
+    n = 0
+    for it in range(iters + 3):
+        n, color, radii, geom, binning, img = RZ._C.rasterize_gaussians(bg, means3D, e, opac, scales, rots, 1.0, e, vm, pm, tanx, tany,
+                                                                       H, W, sh, 3, campos, False, False)
+        RZ._C.rasterize_gaussians_backward(bg, means3D, radii, e, scales, rots, 1.0, e, vm, pm, tanx, tany, dL, sh, 3, campos,
+                                           geom, n, binning, img, False)
+        torch.cuda.synchronize()
+        if it >= 3:
+            for k, v in L.stage_ms().items():
+                acc.setdefault(k, []).append(v)
+    L.lib().dgm_set_profiling(0)
+    med = {k: float(np.median(v)) for k, v in acc.items()}
+    R = int(n)
+    rb_bytes = 40.0 * R + 20.0 * W * H + 36.0 * P
+    grp_bytes = 40.0 * R + 20.0 * W * H + 595.0 * P          # + preprocess backward: the quantity north_star grades
+    rb, pb = med.get("render_bwd", 0.0), med.get("preprocess_bwd", 0.0)
+    ach = rb_bytes / (rb * 1e-3) / 1e9 if rb > 0 else 0.0
+    ach_grp = grp_bytes / ((rb + pb) * 1e-3) / 1e9 if rb + pb > 0 else 0.0
+    return {"scene": "trained-like (SURVEY.md 8d): shell r=0.8, sigma~0.01, opacity U[0.5,0.99]", "num_rendered": R,
+            "kernel": "render_bwd3_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": rb_bytes, "avg_ms": rb,
+            "group_with_preprocess_bwd": {"algorithmic_bytes": grp_bytes, "avg_ms": rb + pb, "achieved": ach_grp,
+                                          "frac": ach_grp / HBM_PEAK_GBS},
+            "render_fwd_ms": med.get("render_fwd", 0.0), "render_fwd_frac_hbm":
+                ((40.0 * R + 20.0 * W * H) / (med["render_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if med.get("render_fwd") else None}
+
+
+def frac_valu_from_profiles():
+    """VALU lane operations / (78.6 T lane-op/s x kernel time) of the blend kernels from the newest committed PMC pass
+    (profiles/r0*_pmc_sq*.json; offline data of the same workload, named in `source`)."""
+    import glob
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*pmc_sq*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            for short in ("render_bwd3_kernel", "render_fwd_kernel"):
+                if short in k and short not in out and "SQ_ACTIVE_INST_VALU" in v and "wall_cycles" in v:
+                    # SQ_ACTIVE_INST_VALU: quad-cycles of VALU execution summed over waves; x4 cycles x 32 lanes per cycle
+                    lane_ops = 4.0 * v["SQ_ACTIVE_INST_VALU"] * 32.0
+                    out[short] = {"valu_lane_ops_per_launch": lane_ops, "frac_valu_at_profiled_clock": lane_ops / (v["wall_cycles"] * 256 * 4 * 32.0),
+                                  "source": "profiles/" + os.path.basename(f)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,11 +229,29 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("DGM_BENCH_WORKLOAD", "cfg2"),
                     help="BASELINE.json config the synthetic scene follows; the metric is quoted on cfg2 (default), the others are "
                          "informational")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode and trained-like extra regions")
     args = ap.parse_args()
     global WORKLOAD
     WORKLOAD = args.workload
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one.  N ranks on this node, one per GPU, rendezvous on 127.0.0.1.
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and os.environ.get("DGM_BENCH_SHARE_GPU") != "1":
+            sys.exit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible -- refusing to time fewer ranks than asked for")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and "WORLD_SIZE" in os.environ and args.gpus > 1:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
@@ -222,6 +315,45 @@ def main():
         s_dt, _, _, _ = timed(STEADY_STEPS, it0 + args.warmup + args.steps)
         steady = {"steps": STEADY_STEPS, "value": STEADY_STEPS * world / s_dt, "ms_per_step": 1e3 * s_dt / STEADY_STEPS}
 
+    # the gradient buckets' all-reduce on its own (what one step exchanges; in the step the larger bucket runs under the MLP
+    # backward passes)
+    allreduce = None
+    if world > 1:
+        bufs = [torch.zeros(n // 4, device=dev) for n in tr.bucket_bytes()]
+        for _ in range(3):
+            for b in bufs:
+                dist.all_reduce(b)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            for b in bufs:
+                dist.all_reduce(b)
+        torch.cuda.synchronize()
+        allreduce = {"ms_per_step_standalone": 1e3 * (time.perf_counter() - t0) / 20, "bucket_bytes": tr.bucket_bytes(),
+                     "backend": dist.get_backend(), "world_size_observed": dist.get_world_size()}
+
+    # strict-fp32 MLP arithmetic on the same workload (N = 1 only: a transparency line, not the headline)
+    f32_mode = None
+    if world == 1 and mlp_impl == "hip" and not args.no_extras:
+        prev = L.lib().dgm_mlp_set_gemm(1)
+        try:
+            for i in range(5):
+                tr.step(it0 + i)
+            n32 = 40
+            f_dt, _, _, _ = timed(n32, it0 + 5)
+            f32_mode = {"value": n32 / f_dt, "unit": "it/s", "ms_per_step": 1e3 * f_dt / n32, "steps": n32,
+                        "arithmetic": "v_mfma_f32_32x32x2_f32 (native fp32 MFMA) in every MLP GEMM"}
+        finally:
+            L.lib().dgm_mlp_set_gemm(prev)
+
+    trained = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            trained = trained_like_render_bwd(dev)
+        except Exception as ex:  # an extra must never take the headline down
+            trained = {"error": str(ex)}
+
     if rank == 0:
         # R of the last frame (all frames of the synthetic orbit are statistically alike)
         R = int((pkg["radii"] > 0).sum().item())  # visible Gaussians (informational)
@@ -247,10 +379,17 @@ def main():
         layer_flops = 2.0 * P * 256 * 256                       # one 256 -> 256 layer over N = P rows
         layer_bytes = 2.0 * P * 256 * 4 + P * 32 + 256 * 256 * 4  # A in + C out (fp32) + ReLU mask bits + the weights once
         dw_bytes = 2.0 * P * 256 * 4 + 256 * 256 * 4  # X in + G in + the gradient once (the per-CU partial tiles are overhead)
+        planes = gemm_mode == 3
+        kn = {3: ("mlp_gemm4_kernel<16,1024,512,0> (256->256 layer forward on planes, N rows)",
+                  "mlp_gemm4_kernel<16,1024,512,1> (256->256 layer backward-data on planes, N rows)",
+                  "mlp_dw4_kernel<8,8> (256x256 weight gradient over N rows, planes)"),
+              2: ("mlp_gemm3p_kernel<0> (256->256 layer forward, N rows)", "mlp_gemm3p_kernel<1> (256->256 layer backward-data, N rows)",
+                  "mlp_dw3b_kernel (256x256 weight gradient over N rows)")}.get(gemm_mode, ("mlp_gemm6r_kernel<0,16,1,8>", "mlp_gemm6r_kernel<1,16,1,8>", "mlp_dw6b_kernel"))
+        pm = ("r03_pmc_gemm4_fwd.json", "r03_pmc_gemm4_bwd.json", "r03_pmc_dw4.json") if planes else ("pmc_gemm3r_fwd.json", "pmc_gemm3r_bwd.json", "pmc_dw3b.json")
         kern = {  # stage -> (kernel name, algorithmic flops, algorithmic bytes, committed PMC file)
-            "mlp_layer_fwd": ("mlp_gemm3p_kernel<0> (256->256 layer forward, N rows)" if f16x3 else "mlp_gemm6r_kernel<0,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_fwd.json"),
-            "mlp_layer_bwd": ("mlp_gemm3p_kernel<1> (256->256 layer backward-data, N rows)" if f16x3 else "mlp_gemm6r_kernel<1,16,1,8>", layer_flops, layer_bytes, "pmc_gemm3r_bwd.json"),
-            "mlp_layer_dw": ("mlp_dw3b_kernel (256x256 weight gradient over N rows)" if f16x3 else "mlp_dw6b_kernel", layer_flops, dw_bytes, "pmc_dw3b.json"),
+            "mlp_layer_fwd": (kn[0], layer_flops, layer_bytes, pm[0]),
+            "mlp_layer_bwd": (kn[1], layer_flops, layer_bytes, pm[1]),
+            "mlp_layer_dw": (kn[2], layer_flops, dw_bytes, pm[2]),
             "render_bwd": ("render_bwd3_kernel", 0.0, alg_bytes, "pmc_render_bwd3.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
             "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
@@ -287,7 +426,9 @@ def main():
                                                                  "workload, committed (not measured in this run)") if src else None,
                          "algorithmic_bytes": by, "algorithmic_flops": fl, "avg_ms": r["avg_ms"], "launches_per_step": r["launches_per_step"],
                          "ms_per_step": r["ms_per_step"], "frac_hbm": r["frac_hbm"], "frac_mfma_pipe": r.get("frac_mfma_pipe"),
-                         "arithmetic": ("f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
+                         "arithmetic": ("f16x3p: activations / gradients stored as 2 binary16 planes with one exponent per 32-row tile, "
+                                        "split once by the producer, 3 MFMAs per product" if planes else
+                                        "f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
                                         if f16x3 else "bf16x6: 3 bf16 planes, 6 MFMAs per product")})
         rb_traffic, rb_src = pmc_traffic("pmc_render_bwd3.json")
         out = {
@@ -299,7 +440,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("D-NeRF jumpingjacks-like cfg2: 800x800, P=100000 Gaussians, deformation MLP on "
                                     "(deform + deform_back, is_blender), 1 frame per rank per step, fixed P (no densification "
-                                    "inside the timed region)") if WORKLOAD == "cfg2" else
+                                    "inside the timed region); output heads of both networks scaled x0.01 so that the deformation "
+                                    "field is small as after convergence (default init triples every splat's extent)") if WORKLOAD == "cfg2" else
                                    f"{WORKLOAD} of BASELINE.json: {W}x{H}, P={P} Gaussians, deformation MLP on, 1 frame per rank per "
                                    "step, fixed P",
                        "P": P, "W": W, "H": H, "num_rendered": n_inst, "visible": R, "mlp_impl": mlp_impl,
@@ -317,6 +459,19 @@ def main():
             "host_ms_per_step": {"blocked_on_gpu": round(1e3 * blocked_s / args.steps, 3),
                                  "busy": round(1e3 * (elapsed - blocked_s) / args.steps, 3)},
         }
+        out["rccl_world_size"] = dist.get_world_size() if world > 1 else 1
+        if allreduce is not None:
+            out["allreduce"] = allreduce
+        if f32_mode is not None:
+            out["mlp_f32_mode"] = f32_mode
+        if trained is not None:
+            out["roofline_render_bwd_trained"] = trained
+        fv = frac_valu_from_profiles()
+        for short, st_name in (("render_bwd3_kernel", "render_bwd"), ("render_fwd_kernel", "render_fwd")):
+            if short in fv and st_name in kernels:  # against the 2.4 GHz peak: 256 CU x 4 SIMD x 32 lanes = 78.6 T lane-op/s
+                fv[short]["frac_valu"] = fv[short]["valu_lane_ops_per_launch"] / (kernels[st_name]["avg_ms"] * 1e-3 * 78.6e12)
+        if fv:
+            out["frac_valu"] = fv
         if steady is not None:
             out["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:

@@ -58,11 +58,17 @@ def _apply(g, P, scratch, K, C, S, z):
     opt = g.optimizer
     by_name = {grp["name"]: grp for grp in opt.param_groups} if opt is not None else {}
     entries = []  # (name, kind, old tensor, new tensor)
+    empty = {}    # zero-width tensors (max_sh_degree = 0: _features_rest is (P, 0, 3)): nothing to gather, new ones made directly
     for name in GROUPS:
         old = getattr(g, ATTR[name])
         new = torch.empty((Pn,) + tuple(old.shape[1:]), dtype=torch.float32, device=dev)
-        entries.append((name, "param", old.detach().contiguous(), new))
         st = opt.state.get(by_name[name]["params"][0]) if name in by_name else None
+        if old.numel() == 0 and P > 0:
+            empty[name] = {"param": new}
+            if st is not None and "exp_avg" in st:
+                empty[name].update(exp_avg=torch.empty_like(new), exp_avg_sq=torch.empty_like(new))
+            continue
+        entries.append((name, "param", old.detach().contiguous(), new))
         if st is not None and "exp_avg" in st:
             for key in ("exp_avg", "exp_avg_sq"):
                 entries.append((name, key, st[key].contiguous(), torch.empty_like(new)))
@@ -78,7 +84,7 @@ def _apply(g, P, scratch, K, C, S, z):
                 (ctypes.c_int * n)(*[max(e[2].numel() // max(P, 1), 1) for e in entries]),
                 (ctypes.c_int * n)(*[0 if e[1] == "param" else 1 for e in entries]), idx["xyz"], idx["scaling"],
                 idx["rotation"], _vp(z) if z is not None else None, _stream()))
-    new_state = {}
+    new_state = dict(empty)
     for name, kind, _, new in entries:
         new_state.setdefault(name, {})[kind] = new
     for name in GROUPS:
@@ -96,8 +102,10 @@ def _apply(g, P, scratch, K, C, S, z):
 
 
 @torch.no_grad()
-def densify_and_prune(g, max_grad, min_opacity, extent, max_screen_size, generator=None):
-    """densify_and_prune (:542-551).  Returns the new number of Gaussians."""
+def densify_and_prune(g, max_grad, min_opacity, extent, max_screen_size, generator=None, samples=None):
+    """densify_and_prune (:542-551).  Returns the new number of Gaussians.  `samples`: optional (2, P, 3) standard-normal
+    draws for the split children (copy, source row) instead of drawing them from `generator` -- what lets a test feed the
+    draws the reference made."""
     P = g._xyz.shape[0]
     if P == 0:
         return 0
@@ -108,7 +116,12 @@ def densify_and_prune(g, max_grad, min_opacity, extent, max_screen_size, generat
     scratch, K, C, S = _decide(g, P, args=args)
     # one standard-normal triple per (copy, Gaussian): indexed by the SOURCE row, so the samples a split child receives
     # do not depend on how many other Gaussians were selected
-    z = torch.randn((2, P, 3), device=dev, generator=generator) if S > 0 else None
+    if samples is not None:
+        z = torch.as_tensor(samples, dtype=torch.float32, device=dev).contiguous()
+        if tuple(z.shape) != (2, P, 3):
+            raise RuntimeError("densify_and_prune: samples must be (2, P, 3)")
+    else:
+        z = torch.randn((2, P, 3), device=dev, generator=generator) if S > 0 else None
     Pn = _apply(g, P, scratch, K, C, S, z)
     g.xyz_gradient_accum = torch.zeros((Pn, 1), device=dev)   # densification_postfix (:458-460)
     g.denom = torch.zeros((Pn, 1), device=dev)

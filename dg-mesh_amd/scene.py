@@ -189,9 +189,9 @@ class GaussianModel:
         self.active_sh_degree = self.max_sh_degree
 
     # -- densification / pruning / opacity reset (gaussian_model_dpsr_dynamic_anchor.py:291-294, 383-551) on the device --
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None, samples=None):
         from . import densify
-        return densify.densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator)
+        return densify.densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator, samples)
 
     def prune_points(self, mask):
         from . import densify

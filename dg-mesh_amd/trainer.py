@@ -197,6 +197,12 @@ class Trainer:
             dist.all_reduce(self.g.denom, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self.g.max_radii2D, op=dist.ReduceOp.MAX, group=self.group)
 
+    def bucket_bytes(self):
+        """Byte sizes of the flat buckets one step all-reduces (Gaussian bucket, MLP bucket; or the single bucket)."""
+        if self._early is not None:
+            return [self._early["g"].nbytes(), self._early["m"].nbytes()]
+        return [self.bucket.nbytes()] if self.bucket is not None else [self.grad_bytes()]
+
     def grad_bytes(self):
         """Size of the all-reduce payload (all gradients, fp32)."""
         return sum(p.numel() for p in self.params) * 4

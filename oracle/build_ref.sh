@@ -29,3 +29,16 @@ if /opt/rocm/bin/hipcc $COMMON -c simple_knn.cu -o knn_probe.o 2>knn.err; then K
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $KNN forward.cu backward.cu rasterizer_impl.cu "$HERE/ref_shim.cpp" -o "$HERE/_ref/libref_raster.so"
 /opt/rocm/bin/hipcc $COMMON forward.cu backward.cu rasterizer_impl.cu "$HERE/ref_shim.cpp" -o "$HERE/_ref/libref_raster_fma.so"
 echo "build_ref: wrote $(ls "$HERE/_ref")"
+# The reference's Python render() (gaussian_renderer/__init__.py:32-119) and the two pure-torch helper modules it imports,
+# byte-compiled (binaries only, same rule as the kernels) so that a GPU test can execute the reference's own render() over
+# this repo's drop-in packages (tests/test_reference_render.py).
+python3 - "$HERE/_ref/pyref" <<'PY'
+import os, py_compile, sys
+out = sys.argv[1]
+os.makedirs(out, exist_ok=True)
+R = "/root/reference/dgmesh"
+for src, name in ((R + "/gaussian_renderer/__init__.py", "gaussian_renderer.pyc"), (R + "/utils/sh_utils.py", "sh_utils.pyc"),
+                  (R + "/utils/rigid_utils.py", "rigid_utils.pyc")):
+    py_compile.compile(src, cfile=os.path.join(out, name), dfile=os.path.basename(src), doraise=True)
+print("build_ref: wrote pyref/", sorted(os.listdir(out)))
+PY

@@ -134,8 +134,157 @@ def dpsr_golden():
     print("wrote dpsr_small", float(phi.min()), float(phi.max()))
 
 
+def _ref_functions(path, names, ns, subst=()):
+    """Execute the named top-level functions of a reference source file in `ns`.  The only edits are textual substitutions
+    listed by the caller (the hard-coded device="cuda" -> "cpu"); nothing else of the module is imported."""
+    import ast
+    src = open(path).read()
+    for a, b in subst:
+        src = src.replace(a, b)
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), os.path.basename(path), "exec"), ns)
+
+
+CUDA2CPU = (("device='cuda'", "device='cpu'"), ('device="cuda"', 'device="cpu"'))
+
+
+def opacity_field_golden():
+    """f4: the REFERENCE's get_opacity_field_from_gaussians (utils/mesh_utils.py:7-76) with its helpers
+    build_covariance_from_scaling_rotation / gaussian_3d_coeff (utils/general_utils.py:112-192) executed from source on the
+    CPU (kiui.lo, a logging call, is stubbed).  Two cases: the default block rule, and a non-default relax / threshold."""
+    import types
+    ns = {"torch": torch, "np": np, "kiui": types.SimpleNamespace(lo=lambda *a, **k: None)}
+    _ref_functions("/root/reference/dgmesh/utils/general_utils.py",
+                   {"strip_lowerdiag", "strip_symmetric", "build_rotation", "build_scaling_rotation",
+                    "build_covariance_from_scaling_rotation", "gaussian_3d_coeff"}, ns, CUDA2CPU)
+    _ref_functions("/root/reference/dgmesh/utils/mesh_utils.py", {"get_opacity_field_from_gaussians"}, ns)
+    rng = np.random.RandomState(21)
+    n = 6000
+    d = rng.randn(n, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    xyz = (0.8 * d * (1 + 0.08 * rng.randn(n, 1))).astype(np.float32)          # a noisy shell inside the +-1.25 box
+    xyz[:200] = ((rng.rand(200, 3) * 2 - 1) * 1.4).astype(np.float32)           # some outside the box / near block borders
+    rot = rng.randn(n, 4).astype(np.float32)
+    scal = np.exp(rng.uniform(np.log(0.004), np.log(0.05), (n, 3))).astype(np.float32)
+    opa = rng.rand(n, 1).astype(np.float32)
+    opa[::9] *= 0.004                                                            # below the 0.005 pre-filter
+    rec = dict(xyz=xyz, rotation=rot, scaling=scal, opacity=opa)
+    for tag, kw in (("a", dict(resolution=64, num_blocks=8)),
+                    ("b", dict(resolution=48, num_blocks=4, relax_ratio=0.8, opacity_threshold=0.02, bbox_scale=1.1))):
+        occ = ns["get_opacity_field_from_gaussians"](torch.tensor(xyz), torch.tensor(rot), torch.tensor(scal), torch.tensor(opa), **kw)
+        rec["occ_" + tag] = occ.numpy().astype(np.float32)
+        rec["kw_" + tag] = np.array([kw["resolution"], kw["num_blocks"], kw.get("relax_ratio", 0.5), kw.get("opacity_threshold", 0.005),
+                                     kw.get("bbox_scale", 1.25)], np.float64)
+        print("opacity field", tag, float(occ.max()), float((occ > 0).float().mean()))
+    np.savez_compressed(os.path.join(HERE, "opacity_field.npz"), **rec)
+
+
+def densify_golden():
+    """f1: the REFERENCE's optimizer surgery (scene/gaussian_model_dpsr_dynamic_anchor.py:291-294, 364-551) executed from
+    source on the CPU: the method bodies of GaussianModelDPSRDynamicAnchor are compiled into a host class that owns nothing but
+    the seven parameter tensors, a torch.optim.Adam with the reference's group names, and the densification statistics.
+    Edits to the source text: device="cuda" -> "cpu"; torch.cuda.empty_cache() dropped; and the ONE random draw
+    (`torch.normal(mean=means, std=stds)`, :476) is routed to recorded standard-normal samples indexed by source row, so that
+    the device implementation can be fed the identical draws."""
+    import ast
+    src = open("/root/reference/dgmesh/scene/gaussian_model_dpsr_dynamic_anchor.py").read()
+    for a, b in CUDA2CPU + (("torch.cuda.empty_cache()", "pass"),
+                            ("samples = torch.normal(mean=means, std=stds)", "samples = self._recorded_normal(selected_pts_mask, stds)")):
+        assert a in src or a.startswith("device='"), a
+        src = src.replace(a, b)
+    want = {"reset_opacity", "replace_tensor_to_optimizer", "_prune_optimizer", "prune_points", "cat_tensors_to_optimizer",
+            "densification_postfix", "densify_and_split", "densify_and_clone", "prune", "densify_and_prune", "get_scaling",
+            "get_opacity", "get_xyz"}
+    ns = {"torch": torch, "nn": torch.nn, "np": np}
+    _ref_functions("/root/reference/dgmesh/utils/general_utils.py", {"build_rotation", "inverse_sigmoid"}, ns, CUDA2CPU)
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "GaussianModelDPSRDynamicAnchor")
+    body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert {n.name for n in body} == want
+    host = ast.ClassDef(name="RefHost", bases=[], keywords=[], body=body, decorator_list=[])
+    exec(compile(ast.fix_missing_locations(ast.Module([host], [])), "gaussian_model_dpsr_dynamic_anchor.py", "exec"), ns)
+    RefHost = ns["RefHost"]
+    NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "normal")
+    ATTR = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling",
+                rotation="_rotation", normal="_normal")
+
+    def make(P, seed):
+        rng = np.random.RandomState(seed)
+        t = lambda a: torch.tensor(a.astype(np.float32))
+        raw = dict(xyz=t(rng.randn(P, 3) * 0.5), f_dc=t(rng.randn(P, 1, 3)), f_rest=t(rng.randn(P, 3, 3) * 0.1),
+                   opacity=t(rng.randn(P, 1) * 3), scaling=t(np.log(np.exp(rng.uniform(np.log(0.002), np.log(0.2), (P, 3))))),
+                   rotation=t(rng.randn(P, 4)), normal=t(rng.randn(P, 3)))
+        h = RefHost()
+        h.gaussian_param_list = list(NAMES)
+        h.scaling_activation, h.scaling_inverse_activation, h.opacity_activation = torch.exp, torch.log, torch.sigmoid
+        h.percent_dense = 0.01
+        for k in NAMES:
+            setattr(h, ATTR[k], torch.nn.Parameter(raw[k].clone().requires_grad_(True)))
+        h.optimizer = torch.optim.Adam([{"params": [getattr(h, ATTR[k])], "lr": 1e-3, "name": k} for k in NAMES], lr=0.0, eps=1e-15)
+        g = torch.Generator().manual_seed(seed)
+        for _ in range(2):  # non-trivial Adam moments
+            for k in NAMES:
+                getattr(h, ATTR[k]).grad = torch.randn(raw[k].shape, generator=g)
+            h.optimizer.step()
+        h.xyz_gradient_accum = torch.rand((P, 1), generator=g) * 6e-4 * 3
+        h.denom = torch.randint(0, 4, (P, 1), generator=g).float()  # zeros -> NaN -> 0 (:544-545)
+        h.max_radii2D = torch.rand(P, generator=g) * 40
+        z = torch.randn((2, P, 3), generator=g)
+
+        def recorded(self, selected_pts_mask, stds):
+            idx = selected_pts_mask.nonzero().squeeze(1)
+            assert int(idx.max()) < P if idx.numel() else True
+            return stds * torch.cat((z[0][idx], z[1][idx]), 0)
+        RefHost._recorded_normal = recorded
+        return h, z
+
+    def state(h, tag):
+        grp = {x["name"]: x["params"][0] for x in h.optimizer.param_groups}
+        rec = {}
+        for k in NAMES:
+            assert grp[k] is getattr(h, ATTR[k])
+            st = h.optimizer.state[grp[k]]
+            rec[f"{tag}/p/{k}"] = grp[k].detach().numpy().copy()
+            rec[f"{tag}/m/{k}"] = st["exp_avg"].numpy().copy()
+            rec[f"{tag}/v/{k}"] = st["exp_avg_sq"].numpy().copy()
+            rec[f"{tag}/step/{k}"] = np.float64(float(st["step"]))
+        rec[f"{tag}/accum"], rec[f"{tag}/denom"], rec[f"{tag}/max_radii"] = h.xyz_gradient_accum.numpy().copy(), h.denom.numpy().copy(), h.max_radii2D.numpy().copy()
+        return rec
+
+    rec = {}
+    for case, (P, seed, size_limit) in enumerate(((2500, 5, 20), (1500, 6, None))):
+        h, z = make(P, seed)
+        rec.update(state(h, f"c{case}/in"))
+        rec[f"c{case}/z"] = z.numpy()
+        args = np.array([0.0002, 0.005, 0.9, -1 if size_limit is None else size_limit, h.percent_dense], np.float64)
+        rec[f"c{case}/args"] = args
+        with torch.no_grad():
+            h.densify_and_prune(0.0002, 0.005, 0.9, size_limit)
+        rec.update(state(h, f"c{case}/out"))
+        print("densify case", case, P, "->", h._xyz.shape[0])
+        if case == 0:  # then an explicit prune_points and the opacity reset on the surviving set
+            with torch.no_grad():
+                mask = torch.rand(h._xyz.shape[0], generator=torch.Generator().manual_seed(77)) < 0.3
+                h.prune_points(mask)
+                rec["c0/prune_mask"] = mask.numpy()
+                rec.update(state(h, "c0/pruned"))
+                h.reset_opacity()
+                rec.update(state(h, "c0/reset"))
+    np.savez_compressed(os.path.join(HERE, "densify_surgery.npz"), **rec)
+    print("wrote densify_surgery.npz", os.path.getsize(os.path.join(HERE, "densify_surgery.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    mlp_goldens()
-    raster_golden()
-    state_dict_layouts()
-    dpsr_golden()
+    which = set(sys.argv[1:])
+    if not which or "mlp" in which:
+        mlp_goldens()
+    if not which or "raster" in which:
+        raster_golden()
+    if not which or "state_dict" in which:
+        state_dict_layouts()
+    if not which or "dpsr" in which:
+        dpsr_golden()
+    if not which or "opacity_field" in which:
+        opacity_field_golden()
+    if not which or "densify" in which:
+        densify_golden()

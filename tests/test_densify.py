@@ -1,5 +1,6 @@
-"""Densification / pruning / opacity reset on the device (dg-mesh_amd/densify.py, csrc/densify.hip) against a PyTorch
-restatement of the reference's optimizer surgery
+"""Densification / pruning / opacity reset on the device (dg-mesh_amd/densify.py, csrc/densify.hip) against (1) goldens
+produced by the REFERENCE's own methods executed from source (tests/golden/densify_surgery.npz, make_golden.py::densify_golden)
+and (2), at other sizes, a PyTorch restatement of the reference's optimizer surgery -- itself checked against the goldens --
 (/root/reference/dgmesh/scene/gaussian_model_dpsr_dynamic_anchor.py:291-294, 364-551), fed the same statistics, the same
 Adam state and the same standard-normal samples: same decisions (the new P), bit-equal gathered parameters and moments,
 split children to fp32 rounding.  Plus: the optimizer keeps working on the new set, and two data-parallel replicas stay
@@ -175,6 +176,88 @@ def test_prune_points_and_reset_opacity():
     assert grp["opacity"] is g._opacity
     assert float(g.optimizer.state[g._opacity]["exp_avg"].abs().sum()) == 0.0
     assert torch.equal(g.optimizer.state[g._xyz]["exp_avg"], m_xyz)
+
+
+GOLD = os.path.join(ROOT, "tests", "golden", "densify_surgery.npz")
+ATTRS = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling",
+             rotation="_rotation", normal="_normal")
+
+
+def _load_case(gold, tag, dev):
+    """A GaussianModel (sh_degree 1) + Adam state exactly as the golden generator left the reference host before surgery."""
+    S = pkg("scene")
+    g = S.GaussianModel(sh_degree=1, device=dev)
+    t = lambda k: torch.tensor(gold[k], device=dev)
+    g.load_raw(*[t(f"{tag}/p/{k}") for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "normal")])
+    g.training_setup(S.OptimizationParams())
+    grp = {x["name"]: x["params"][0] for x in g.optimizer.param_groups}
+    for k in NAMES:
+        g.optimizer.state[grp[k]] = {"step": torch.tensor(float(gold[f"{tag}/step/{k}"])), "exp_avg": t(f"{tag}/m/{k}"),
+                                     "exp_avg_sq": t(f"{tag}/v/{k}")}
+    g.xyz_gradient_accum, g.denom, g.max_radii2D = t(f"{tag}/accum"), t(f"{tag}/denom"), t(f"{tag}/max_radii")
+    return g
+
+
+def _check_case(g, gold, tag, computed=("xyz", "scaling")):
+    grp = {x["name"]: x["params"][0] for x in g.optimizer.param_groups}
+    for k in NAMES:
+        attr = getattr(g, ATTRS[k])
+        want = torch.tensor(gold[f"{tag}/p/{k}"], device=attr.device)
+        assert attr is grp[k] and attr.shape == want.shape, k
+        if k in computed:  # split children / reset opacities are computed: fp32 rounding only
+            assert torch.allclose(attr.detach(), want, rtol=1e-5, atol=1e-6), k
+        else:
+            assert torch.equal(attr.detach(), want), k
+        st = g.optimizer.state[grp[k]]
+        assert torch.equal(st["exp_avg"].cpu(), torch.tensor(gold[f"{tag}/m/{k}"])), k
+        assert torch.equal(st["exp_avg_sq"].cpu(), torch.tensor(gold[f"{tag}/v/{k}"])), k
+        assert float(st["step"]) == float(gold[f"{tag}/step/{k}"])
+    assert torch.equal(g.xyz_gradient_accum.cpu(), torch.tensor(gold[f"{tag}/accum"]))
+    assert torch.equal(g.denom.cpu(), torch.tensor(gold[f"{tag}/denom"]))
+    assert torch.equal(g.max_radii2D.cpu(), torch.tensor(gold[f"{tag}/max_radii"]))
+
+
+@pytest.mark.gpu
+def test_surgery_matches_the_reference_code_goldens():
+    """tests/golden/densify_surgery.npz holds what the REFERENCE's own methods (densify_and_prune -> prune_points ->
+    reset_opacity of gaussian_model_dpsr_dynamic_anchor.py, executed from source by make_golden.py) did to a model, its Adam
+    state and its statistics; the device implementation is fed the same model and the same normal draws."""
+    gold = np.load(GOLD)
+    dev = torch.device("cuda")
+    for case in (0, 1):
+        g = _load_case(gold, f"c{case}/in", dev)
+        max_grad, min_opacity, extent, size_limit, pd = gold[f"c{case}/args"]
+        assert abs(g.percent_dense - pd) < 1e-12
+        Pn = g.densify_and_prune(max_grad, min_opacity, extent, None if size_limit < 0 else size_limit, samples=gold[f"c{case}/z"])
+        assert Pn == gold[f"c{case}/out/p/xyz"].shape[0]
+        _check_case(g, gold, f"c{case}/out")
+        if case == 0:
+            g.prune_points(torch.tensor(gold["c0/prune_mask"], device=dev))
+            _check_case(g, gold, "c0/pruned")
+            g.reset_opacity()
+            _check_case(g, gold, "c0/reset", computed=("xyz", "scaling", "opacity"))
+
+
+def test_restatement_matches_the_reference_code_goldens():
+    """The PyTorch restatement the other tests compare with (RefSurgery, used at sizes and seeds the golden does not cover)
+    reproduces the reference's own result on the golden inputs -- on the CPU, bit for bit where nothing is computed."""
+    gold = np.load(GOLD)
+    t = lambda k: torch.tensor(gold[k])
+    for case in (0, 1):
+        tag = f"c{case}/in"
+        max_grad, min_opacity, extent, size_limit, pd = gold[f"c{case}/args"]
+        ref = RefSurgery({k: t(f"{tag}/p/{k}") for k in NAMES}, {k: t(f"{tag}/m/{k}") for k in NAMES},
+                         {k: t(f"{tag}/v/{k}") for k in NAMES}, t(f"{tag}/accum"), t(f"{tag}/denom"), t(f"{tag}/max_radii"), float(pd))
+        ref.densify_and_prune(max_grad, min_opacity, extent, None if size_limit < 0 else size_limit, t(f"c{case}/z"))
+        for k in NAMES:
+            want = t(f"c{case}/out/p/{k}")
+            assert ref.p[k].shape == want.shape
+            if k in ("xyz", "scaling"):
+                assert torch.allclose(ref.p[k], want, rtol=1e-6, atol=1e-7), k
+            else:
+                assert torch.equal(ref.p[k], want), k
+            assert torch.equal(ref.m[k], t(f"c{case}/out/m/{k}")) and torch.equal(ref.v[k], t(f"c{case}/out/v/{k}"))
+        assert torch.equal(ref.max_radii, t(f"c{case}/out/max_radii"))
 
 
 def _worker(rank, world, port, out_dir):

@@ -57,6 +57,38 @@ def reference_field(xyzs, rotations, scalings, opacities, resolution, num_blocks
     return occ
 
 
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "opacity_field.npz")
+
+
+def test_restatement_matches_the_reference_code_golden():
+    """reference_field() above (used by the GPU tests at other sizes) against the output of the REFERENCE's own
+    get_opacity_field_from_gaussians executed from source (make_golden.py::opacity_field_golden) -- CPU."""
+    gold = np.load(GOLD)
+    t = lambda k: torch.tensor(gold[k])
+    for tag in ("a", "b"):
+        res, nb, relax, thr, bbox = gold["kw_" + tag]
+        occ = reference_field(t("xyz"), t("rotation"), t("scaling"), t("opacity"), int(res), int(nb), float(relax), float(thr), float(bbox))
+        want = t("occ_" + tag)
+        assert float((occ - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_device_field_matches_the_reference_code_golden():
+    """dgm_opacity_field against the reference's own output on the golden scene (both cases: default block rule; non-default
+    relax ratio / threshold / box)."""
+    M = pkg("mesh_utils")
+    gold = np.load(GOLD)
+    t = lambda k: torch.tensor(gold[k], device="cuda")
+    for tag in ("a", "b"):
+        res, nb, relax, thr, bbox = gold["kw_" + tag]
+        occ = M.get_opacity_field_from_gaussians(t("xyz"), t("rotation"), t("scaling"), t("opacity"), resolution=int(res),
+                                                 num_blocks=int(nb), relax_ratio=float(relax), opacity_threshold=float(thr),
+                                                 bbox_scale=float(bbox))
+        want = t("occ_" + tag)
+        err = float((occ - want).abs().max()) / float(want.abs().max())
+        assert occ.shape == want.shape and err < 1e-5, f"{tag}: {err:.2e}"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("res,nb,P", [(32, 4, 3000), (48, 8, 5000), (30, 4, 2000)])
 def test_matches_reference_loop(res, nb, P):
