@@ -52,7 +52,7 @@ STEADY_STEPS = int(os.environ.get("DGM_BENCH_STEADY_STEPS", "200"))
 WORKLOAD = "cfg2"
 
 
-def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0):
+def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase="gs", dpsr_res=288, n_verts=60000):
     syn = importlib.import_module("dg-mesh_amd.synthetic")
     S = importlib.import_module("dg-mesh_amd.scene")
     D = importlib.import_module("dg-mesh_amd.deform")
@@ -84,8 +84,24 @@ def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0):
                 head.weight.mul_(0.01)
                 head.bias.mul_(0.01)
     bg = torch.tensor([1.0, 1.0, 1.0] if c["white_bg"] else [0.0, 0.0, 0.0], device=dev)
+    mesh = None
+    if phase == "mesh":
+        # mesh co-training phase (R/train.py:165-176, 243-285): the two normal networks on the P Gaussians, DPSR on the deformed
+        # points (grid dpsr_res^3), deform_back + appearance on V vertices.  DiffMC / nvdiffrast are third-party and not
+        # rebuilt: phi is probed at V fixed points that stand in for the mesh vertices (trainer.py).  The appearance network
+        # differentiates w.r.t. its input (vertex positions moved by deform_back), which the fused trunk does not: PyTorch trunk.
+        DP = importlib.import_module("dg-mesh_amd.dpsr")
+        dn = D.DeformModelNormalSep(is_blender=c["is_blender"], model_name="deform_normal", device=dev, trunk_impl=mlp_impl)
+        dbn = D.DeformModelNormalSep(is_blender=c["is_blender"], model_name="deform_back_normal", device=dev, trunk_impl=mlp_impl)
+        app = D.AppearanceModel(is_blender=c["is_blender"], device=dev, trunk_impl="torch")
+        with torch.no_grad():
+            for m in (dn, dbn):  # zero-initialised head in the reference (time_utils.py:248-249): small but non-zero here
+                torch.nn.init.normal_(m.net.gaussian_normal.weight, std=1e-3)
+        extent = c.get("extent", 1.3)
+        mesh = T.MeshPhase(dn, dbn, app, dpsr=DP.DPSR(res=(dpsr_res,) * 3, sig=2.0), n_verts=n_verts, scale=1.1 * extent, seed=seed,
+                           device=dev)
     tr = T.Trainer(g, deform, deform_back, cams, background=bg, is_blender=c["is_blender"], rank=rank, world=world,
-                   seed=seed)
+                   seed=seed, mesh=mesh)
     return tr, (P, W, H)
 
 
@@ -230,6 +246,11 @@ def main():
                     help="BASELINE.json config the synthetic scene follows; the metric is quoted on cfg2 (default), the others are "
                          "informational")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode and trained-like extra regions")
+    ap.add_argument("--phase", default="gs", choices=["gs", "mesh"],
+                    help="gs: dynamic-Gaussian phase (deform + deform_back; the metric's configuration).  mesh: the mesh co-training "
+                         "phase -- four networks on P, DPSR chain, deform_back + appearance on V (BASELINE config 5's 'DPSR mesh step')")
+    ap.add_argument("--dpsr-res", type=int, default=288)
+    ap.add_argument("--verts", type=int, default=60000)
     args = ap.parse_args()
     global WORKLOAD
     WORKLOAD = args.workload
@@ -273,8 +294,10 @@ def main():
     if mlp_impl == "auto":
         mlp_impl = "hip" if hasattr(L.lib(), "dgm_mlp_forward") else "torch"
 
-    tr, (P, W, H) = build_scene(dev, rank, world, mlp_impl)
+    tr, (P, W, H) = build_scene(dev, rank, world, mlp_impl, phase=args.phase, dpsr_res=args.dpsr_res, n_verts=args.verts)
     it0 = tr.opt.warm_up + 2000  # "deformation MLP on" phase (warm_up <= it < dpsr_iter)
+    if args.phase == "mesh":     # every network on, positions unfrozen (it >= dpsr_iter + max(normal_warm_up, 2000))
+        it0 = tr.opt.dpsr_iter + tr.opt.normal_deform_delay + 1000
 
     for i in range(10):  # allocator / code-object / clock priming (untimed, not part of the W warm-up steps requested below)
         tr.step(it0)
@@ -335,7 +358,7 @@ def main():
 
     # strict-fp32 MLP arithmetic on the same workload (N = 1 only: a transparency line, not the headline)
     f32_mode = None
-    if world == 1 and mlp_impl == "hip" and not args.no_extras:
+    if world == 1 and mlp_impl == "hip" and not args.no_extras and args.phase == "gs":
         prev = L.lib().dgm_mlp_set_gemm(1)
         try:
             for i in range(5):
@@ -348,7 +371,7 @@ def main():
             L.lib().dgm_mlp_set_gemm(prev)
 
     trained = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.phase == "gs":
         try:
             trained = trained_like_render_bwd(dev)
         except Exception as ex:  # an extra must never take the headline down
@@ -438,6 +461,10 @@ def main():
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "phase": ("dynamic Gaussian splatting (deform + deform_back)" if args.phase == "gs" else
+                      f"mesh co-training: deform, deform_normal, deform_back, deform_back_normal on P + DPSR {args.dpsr_res}^3 (splat, "
+                      f"spectral solve, read-back, adjoints) + deform_back and appearance on V={args.verts} vertices; DPSR step included, "
+                      "DiffMC / nvdiffrast replaced by a probe of phi (third-party, out of scope)"),
             "config": {"workload": ("D-NeRF jumpingjacks-like cfg2: 800x800, P=100000 Gaussians, deformation MLP on "
                                     "(deform + deform_back, is_blender), 1 frame per rank per step, fixed P (no densification "
                                     "inside the timed region); output heads of both networks scaled x0.01 so that the deformation "

@@ -35,8 +35,12 @@ __device__ __forceinline__ void corners(const float* __restrict__ p, int R, Corn
     for (int d = 0; d < 3; d++) {
         const float q = p[d] / cube;
         const float f = floorf(q);
-        i0[d] = (int)f;
-        i1[d] = (int)fmodf(ceilf(q), size);
+        // (the reference asserts on the device for a coordinate outside [0, 1): its caller clamps; here both corner indices are
+        // wrapped into the periodic grid and a NaN coordinate lands in cell 0 -- never an out-of-bounds access)
+        int lo = f == f ? (int)fmodf(f, size) : 0;
+        i0[d] = lo < 0 ? lo + R : (lo >= R ? R - 1 : lo);
+        int hi = q == q ? (int)fmodf(ceilf(q), size) : 0;
+        i1[d] = hi < 0 ? hi + R : (hi >= R ? R - 1 : hi);
         const float x0 = f * cube, x1 = (f + 1.0f) * cube;
         // weight of the LOW corner uses the distance to the HIGH corner position and vice versa
         const float e0 = p[d] - x1, e1 = p[d] - x0;

@@ -26,10 +26,20 @@ def _adjacent(ts):
     return True
 
 
+def _one_storage(ts):
+    """All tensors live in ONE storage that reaches to the end of the last one (separately allocated tensors can happen to sit
+    back to back in the allocator's address space: as_strided over the first one's storage would then overrun it)."""
+    st = ts[0].untyped_storage()
+    if any(t.untyped_storage().data_ptr() != st.data_ptr() for t in ts):
+        return False
+    need = (ts[0].storage_offset() + sum(t.numel() for t in ts)) * ts[0].element_size()
+    return st.nbytes() >= need
+
+
 def _stacked(ts, shape):
     """The head tensors as ONE (n_out, ...) tensor: a view of their common buffer when pack_heads() laid them out back to
     back (no launch), else a concatenation."""
-    if _adjacent(ts):
+    if _adjacent(ts) and _one_storage(ts):
         stride = (shape[1], 1) if len(shape) == 2 else (1,)
         return torch.as_strided(ts[0].detach(), shape, stride, ts[0].storage_offset())
     return torch.cat([t.detach() for t in ts], 0).contiguous()

@@ -41,7 +41,8 @@ class MultiAdam:
         """Everything that only changes when the parameter set does is gathered once per parameter set and reused: the grouping
         by hyper-parameters, the state slots, the ctypes argument arrays with the pointers of parameters and moments and the
         sizes already filled in.  Per call only gradients, learning rates and step counts are written."""
-        sig = tuple(id(p) for o in self.optimizers for g in o.param_groups for p in g["params"])
+        sig = tuple((id(p), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+                    for o in self.optimizers for g in o.param_groups for p in g["params"])  # (hyper-parameters too: a changed beta / eps regroups)
         if getattr(self, "_sig", None) == sig:
             return self._cached
         by_hyper = {}

@@ -261,6 +261,12 @@ class OptimizationParams:
     densify_until_iter = 15_000
     densification_interval = 100
     opacity_reset_interval = 3000
+    # mesh co-training phase (R/arguments/__init__.py:109, 142, 148-149; R/train.py:124-127)
+    dpsr_iter = 5000
+    normal_warm_up = 1_000
+    normal_deform_delay = 2000   # NORMAL_WARMUP_ITER of R/train.py:127: deform_normal / deform_back_normal start this long after dpsr_iter
+    mask_loss_weight = 10.0
+    mesh_img_loss_weight = 1.0
 
 
 def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):

@@ -3,9 +3,18 @@
 Single-rank semantics follow R/train.py:129-321 and :517-530 (R/ = /root/reference/dgmesh/):
   lr update -> pick camera -> deform MLP (iteration >= warm_up) -> render -> deform_back MLP + cycle losses ->
   0.8*L1 + 0.2*(1-SSIM) -> backward -> Adam steps (eps 1e-15) -> zero grads.
-Densification / pruning / opacity reset run inside the loop when `densify=True` (densify.py).  The mesh branch
-(iteration >= dpsr_iter: DiffMC / nvdiffrast) is out of scope, and
-host synchronisations of the reference's loop that do not change results are dropped
+Densification / pruning / opacity reset run inside the loop when `densify=True` (densify.py).
+
+Mesh co-training phase (`mesh=MeshPhase(...)`, iteration >= dpsr_iter; R/train.py:165-176, 225-235, 243-285, 517-530 and
+R/utils/renderer.py:150-183): the two normal networks (deform_normal, deform_back_normal: DeformNetworkNormalSep on the P
+Gaussians, cycle loss / 4), the DPSR chain on the deformed points and normals (normalise to the unit cube -> trilinear splat ->
+spectral Poisson solve -> sign fix -> minus density threshold), deform_back + appearance on the V mesh vertices, six Adam
+steps (+ the density threshold).  What sits between phi and the image losses in the reference -- DiffMC marching cubes and
+nvdiffrast, third-party packages outside /root/reference (parity unpinned) -- is NOT rebuilt; in its
+place phi is read back trilinearly (grid_interp, with its adjoint) at V fixed probe points and those probes act as the mesh
+vertices, with L1 losses against fixed targets standing in for the mask / mesh-image losses.  Every kernel chain of the phase
+that the reference owns therefore runs and is differentiated; the numbers of the stand-in losses mean nothing.
+Host synchronisations of the reference's loop that do not change results are dropped
 (torch.cuda.empty_cache() every iteration, R/train.py:130; get_psnr's .item(), :315).
 
 Data parallelism (absent in the reference; BASELINE.json north_star): one process per GPU, frames shard across
@@ -89,12 +98,41 @@ def frame_schedule(n_frames, step, rank, world, seed=0):
     return perm[(k * world + rank) % n_frames]
 
 
+class MeshPhase:
+    """The mesh co-training phase's own state: the three extra networks, the DPSR module, the density threshold parameter
+    (R/scene/gaussian_model_dpsr_dynamic_anchor.py:83-86: the 8th Adam group of the Gaussian model), the normalisation
+    (gaussian_center / gaussian_scale, :76-77) and the V probe points that stand in for the DiffMC vertices."""
+
+    def __init__(self, deform_normal, deform_back_normal, appearance, dpsr=None, n_verts=20000, density_thres=0.0,
+                 center=(0.0, 0.0, 0.0), scale=1.0, seed=0, device="cuda", stand_in_weight=1e-6):
+        self.stand_in_weight = stand_in_weight
+        self.deform_normal, self.deform_back_normal, self.appearance, self.dpsr = deform_normal, deform_back_normal, appearance, dpsr
+        dev = torch.device(device)
+        gen = torch.Generator().manual_seed(4242 + seed)
+        self.density_thres = torch.nn.Parameter(torch.tensor(float(density_thres), device=dev))
+        self.center = torch.tensor(center, dtype=torch.float32, device=dev)
+        self.scale = torch.tensor([float(scale)], dtype=torch.float32, device=dev)
+        # probe points in the unit cube (a shell around the centre, where an iso-surface would lie), their world positions,
+        # and fixed targets for the stand-in losses
+        d = torch.randn(n_verts, 3, generator=gen)
+        d = d / d.norm(dim=1, keepdim=True)
+        self.probes = (0.5 + 0.25 * d * (1 + 0.1 * torch.randn(n_verts, 1, generator=gen))).clamp(0.02, 0.98).to(dev)
+        self.verts = ((self.probes * 2.0 - 1.0) * self.scale + self.center).contiguous()
+        self.phi_target = torch.zeros(n_verts, device=dev)
+        self.color_target = torch.rand(n_verts, 3, generator=gen).to(dev)
+        self.optimizer = torch.optim.Adam([{"params": [self.density_thres], "lr": 0.001, "name": "density_thres"}], lr=0.0, eps=1e-15)
+
+    def networks(self):
+        return [self.deform_normal, self.deform_back_normal, self.appearance]
+
+
 class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
                  process_group=None, fused_loss=True, fused_glue=None, track_stats=True, densify=False,
-                 cameras_extent=1.0, prune_threshold=0.005, white_background=True, overlap=True):
+                 cameras_extent=1.0, prune_threshold=0.005, white_background=True, overlap=True, mesh=None):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
+        self.mesh = mesh
         self.cameras = cameras
         self.opt = opt or S.OptimizationParams()
         self.pipe = pipe or S.PipelineParams()
@@ -119,6 +157,11 @@ class Trainer:
         deform.train_setting(self.opt)
         deform_back.train_setting(self.opt)
         self.optimizers = [gaussians.optimizer, deform.optimizer, deform_back.optimizer]
+        if mesh is not None:  # R/train.py:517-524: six optimizers (+ the density threshold's group)
+            for m in mesh.networks():
+                m.train_setting(self.opt)
+                self.optimizers.append(m.optimizer)
+            self.optimizers.append(mesh.optimizer)
         self.multi_adam = None
         if fused:  # same update rule, ONE kernel for every tensor of the three optimizers
             from .optim import MultiAdam
@@ -143,6 +186,10 @@ class Trainer:
         params = [gaussians._xyz, gaussians._features_dc, gaussians._features_rest, gaussians._opacity,
                   gaussians._scaling, gaussians._rotation]
         params += list(deform.net.parameters()) + list(deform_back.net.parameters())
+        if self.mesh is not None:  # the five networks of SURVEY.md section 8(e)'s bucket, the normals, the density threshold
+            for m in self.mesh.networks():
+                params += list(m.net.parameters())
+            params += [gaussians._normal, self.mesh.density_thres]
         self.params = [p for p in params if p.requires_grad]
         # "pack": gradients are fresh tensors every step (no accumulate kernels); "views": .grad lives in the bucket
         self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or self.world > 1) else None
@@ -253,6 +300,9 @@ class Trainer:
                 back = self.deform_back.step(deformed_xyz.detach(), self.time_input(cam, N, iteration))
                 cycle = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rotation) + S.l1_loss(-back[2], d_scaling)) / 3.0
                 losses["cycle_loss"] = cycle
+        if self.mesh is not None and iteration >= opt.dpsr_iter:
+            self.mesh_terms(cam, iteration, losses, pkg, delta if delta is not None else None,
+                            None if delta is not None else (d_xyz if iteration >= opt.warm_up else None))
         image = pkg["render"]
         gt = cam.original_image
         if image.is_cuda and self.fused_loss:  # same value, two HIP kernels instead of 5 convs + autograd
@@ -263,11 +313,52 @@ class Trainer:
             losses["img_loss"] = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - S.ssim(image, gt))
         return losses, pkg
 
+    def mesh_terms(self, cam, iteration, losses, pkg, delta, d_xyz):
+        """The mesh co-training additions of one iteration (see the module docstring); adds to `losses` in place."""
+        g, opt, ms = self.g, self.opt, self.mesh
+        N = g.get_xyz.shape[0]
+        xyz_d = g.get_xyz.detach()
+        t_in = self.time_input(cam, N, iteration)
+        normal_nets = iteration >= opt.dpsr_iter + opt.normal_deform_delay
+        d_normal = ms.deform_normal.step(xyz_d, t_in) if normal_nets else None          # R/train.py:170-175
+        if normal_nets:                                                                   # R/train.py:225-235: cycle / 4
+            d_normal_back = ms.deform_back_normal.step(xyz_d, t_in)
+            l_n = S.l1_loss(-d_normal_back, d_normal)
+            if "cycle_loss" in losses:
+                losses["cycle_loss"] = losses["cycle_loss"] * 0.75 + l_n * 0.25
+        if ms.dpsr is None:  # (CPU test path: the networks and the bucket, no HIP DPSR)
+            if normal_nets:
+                losses["normal_reg"] = (g.get_normal + d_normal).abs().mean() * 1e-3
+            return
+        # R/utils/renderer.py:150-170: points of the deformed Gaussians in the unit cube, their normals, phi, sign, threshold
+        dx = delta[:, :3] if delta is not None else d_xyz
+        freeze_pos = iteration < opt.dpsr_iter + opt.normal_warm_up
+        pts = (xyz_d + dx.detach()) if freeze_pos else (g.get_xyz + dx)
+        pts = ((pts - ms.center) / ms.scale) / 2.0 + 0.5
+        pts = torch.clamp(pts, 1e-6, 1 - 1e-6)
+        normals = g.get_normal + d_normal if d_normal is not None else g.get_normal
+        psr = ms.dpsr(pts.unsqueeze(0), normals.unsqueeze(0))
+        sign = torch.where(psr[0, 0, 0, 0].detach() < 0, -1.0, 1.0)                       # (no host read-back of the sign)
+        psr = psr * sign - ms.density_thres
+        # stand-in for DiffMC -> nvdiffrast: phi at the V probe points; the probes act as the mesh vertices
+        from .dpsr import grid_interp
+        phi_v = grid_interp(psr.unsqueeze(-1), ms.probes.unsqueeze(0))[0, :, 0]
+        # (stand-in losses carry a tiny weight: they exist to drive the chain's backward, not to shape the scene)
+        losses["mask_loss"] = S.l1_loss(phi_v, ms.phi_target) * 100 * opt.mask_loss_weight * ms.stand_in_weight
+        V = ms.verts.shape[0]
+        t_v = self.time_input(cam, V, iteration)
+        back_v = self.deform_back.step(ms.verts, t_v)[0]                                  # R/utils/renderer.py:179-181
+        vtx_color = ms.appearance.step(ms.verts + back_v, t_v)
+        losses["mesh_img_loss"] = S.l1_loss(vtx_color, ms.color_target) * opt.mesh_img_loss_weight * (1e3 * ms.stand_in_weight)
+
     def step(self, iteration):
         g = self.g
         g.update_learning_rate(iteration)
         self.deform.update_learning_rate(iteration)
         self.deform_back.update_learning_rate(iteration)
+        if self.mesh is not None:
+            for m in self.mesh.networks():
+                m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         cam = self.cameras[frame_schedule(len(self.cameras), self.step_count, self.rank, self.world, self.seed)]

@@ -57,6 +57,33 @@ def mlp_goldens():
             print("wrote", cls, blender, [o.shape for o in outs])
 
 
+def mlp_full_gradient_golden():
+    """Every gradient tensor IN FULL (fp16 would not do: stored as float32, ~2 MB compressed) of the reference's
+    DeformNetworkNormal (is_blender) at N = 256, double-precision evaluation of the reference module alongside (what the
+    tolerance in the test is budgeted against)."""
+    sys.path.insert(0, "/root/reference/dgmesh")
+    from utils import time_utils as ref
+
+    rng = np.random.RandomState(17)
+    N = 256
+    x = ((rng.rand(N, 3) * 2 - 1) * 1.3).astype(np.float32)
+    torch.manual_seed(0)
+    net = ref.DeformNetworkNormal(is_blender=True)
+    t = torch.tensor([[0.61]]).expand(N, -1)
+    outs = list(net(torch.tensor(x), t))
+    g = torch.Generator().manual_seed(9)
+    w = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+    rec = {"x": x, "t": np.float32(0.61)}
+    for i, (o, wi) in enumerate(zip(outs, w)):
+        rec[f"out{i}"], rec[f"w{i}"] = o.detach().numpy(), wi.numpy()
+    for name, p in net.named_parameters():
+        if p.grad is not None:
+            rec["grad/" + name] = p.grad.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "mlp_full_grads_DeformNetworkNormal_blender.npz"), **rec)
+    print("wrote full gradients", os.path.getsize(os.path.join(HERE, "mlp_full_grads_DeformNetworkNormal_blender.npz")) // 1024, "KiB")
+
+
 def raster_golden():
     syn = importlib.import_module("dg-mesh_amd.synthetic")
     from oracle import oracle as orc
@@ -278,6 +305,8 @@ if __name__ == "__main__":
     which = set(sys.argv[1:])
     if not which or "mlp" in which:
         mlp_goldens()
+    if not which or "mlp_full" in which:
+        mlp_full_gradient_golden()
     if not which or "raster" in which:
         raster_golden()
     if not which or "state_dict" in which:

@@ -120,3 +120,77 @@ def test_dp2_equals_single_rank_accumulation():
     # and the step really moved the parameters
     fresh = snapshot(make_trainer(0, 1))
     assert any(not torch.equal(a, b) for a, b in zip(r0, fresh))
+
+
+# ---- mesh co-training phase: five networks in the bucket (2 607 545 floats = 10.43 MB) --------------
+def make_mesh_trainer(rank, world, seed=0, **kw):
+    D, T = pkg("deform"), pkg("trainer")
+    tr = make_trainer(rank, world, seed=seed, **kw)
+    torch.manual_seed(seed + 100)
+    extra = [D.DeformModelNormalSep(is_blender=True, model_name="deform_normal", device="cpu", trunk_impl="torch"),
+             D.DeformModelNormalSep(is_blender=True, model_name="deform_back_normal", device="cpu", trunk_impl="torch"),
+             D.AppearanceModel(is_blender=True, device="cpu", trunk_impl="torch")]
+    with torch.no_grad():  # the Sep networks' head is zero-initialised (time_utils.py:248-249): give it something to cycle on
+        for m in extra[:2]:
+            torch.nn.init.normal_(m.net.gaussian_normal.weight, std=0.02)
+    mesh = T.MeshPhase(*extra, dpsr=None, n_verts=64, device="cpu", seed=seed)
+    return T.Trainer(tr.g, tr.deform, tr.deform_back, tr.cameras, background=tr.bg, rank=rank, world=world, seed=seed,
+                     render_fn=tr.render_fn, fused_adam=False, mesh=mesh)
+
+
+def _mesh_snapshot(tr):
+    ps = list(tr.params)
+    return [p.detach().clone() for p in ps]
+
+
+def _mesh_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = make_mesh_trainer(rank, world)
+    it = tr.opt.dpsr_iter + tr.opt.normal_deform_delay + 10
+    for s in range(2):
+        tr.step(it + s)
+    torch.save({"params": _mesh_snapshot(tr), "bytes": tr.grad_bytes()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mesh_phase_bucket_holds_the_five_networks():
+    """The data-parallel bucket of the mesh co-training phase: deform + deform_back (523 051 parameters each) and
+    deform_normal, deform_back_normal, appearance (520 481 each) = 2 607 545 floats = 10.43 MB of MLP gradients -- the figure
+    SURVEY.md section 8(e) / BASELINE.md name -- next to the Gaussian tensors (now including the normals) and the density
+    threshold."""
+    tr = make_mesh_trainer(0, 1)
+    count = lambda m: sum(p.numel() for p in m.net.parameters())
+    nets = [tr.deform, tr.deform_back] + tr.mesh.networks()
+    assert [count(m) for m in nets] == [523051, 523051, 520481, 520481, 520481]
+    P = tr.g._xyz.shape[0]
+    assert tr.grad_bytes() == 4 * (2607545 + 62 * P + 1)  # 62 floats per Gaussian (SURVEY 8e): 59 of the splat + 3 of the normal
+    assert len(tr.optimizers) == 7  # R/train.py:517-524's six + the density threshold's group
+
+
+def test_mesh_phase_dp2_replicas_identical_and_all_networks_step():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        port = 29300 + (os.getpid() % 150)
+        mp.start_processes(_mesh_worker, args=(world, port, d), nprocs=world, join=True, start_method="spawn")
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+        r1 = torch.load(os.path.join(d, "rank1.pt"))
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    fresh = _mesh_snapshot(make_mesh_trainer(0, 1))
+    moved = [not torch.equal(a, b) for a, b in zip(r0["params"], fresh)]
+    tr = make_mesh_trainer(0, 1)
+    # every network of the phase received gradients and stepped (a weight of each changed), and so did the normals
+    off = 6
+    for m in [tr.deform, tr.deform_back, tr.mesh.deform_normal, tr.mesh.deform_back_normal]:
+        n = len(list(m.net.parameters()))
+        assert any(moved[off:off + n]), m.model_name
+        off += n
+    n_app = len(list(tr.mesh.appearance.net.parameters()))
+    idx_normal = off + n_app
+    assert moved[idx_normal], "the Gaussian normals did not move"

@@ -126,3 +126,46 @@ def test_lean_step_equals_the_reference_shaped_step():
     assert torch.equal(a.g.max_radii2D, b.g.max_radii2D) and torch.equal(a.g.denom, b.g.denom)
     assert float(a.g.denom.sum()) > 0
     assert torch.equal(a.g.xyz_gradient_accum, b.g.xyz_gradient_accum) and float(a.g.xyz_gradient_accum.sum()) > 0
+
+
+def make_mesh_trainer(rank, world, res=48, n_verts=4000, **kw):
+    D, T, DP = pkg("deform"), pkg("trainer"), pkg("dpsr")
+    tr = make_trainer(rank, world, **kw)
+    dev = tr.g.get_xyz.device
+    torch.manual_seed(7)
+    dn = D.DeformModelNormalSep(is_blender=True, model_name="deform_normal", device=dev, trunk_impl="hip")
+    dbn = D.DeformModelNormalSep(is_blender=True, model_name="deform_back_normal", device=dev, trunk_impl="hip")
+    app = D.AppearanceModel(is_blender=True, device=dev, trunk_impl="torch")  # differentiates w.r.t. its input: PyTorch trunk
+    with torch.no_grad():
+        for m in (dn, dbn):
+            torch.nn.init.normal_(m.net.gaussian_normal.weight, std=0.02)
+        tr.g._normal.copy_(torch.nn.functional.normalize(tr.g.get_xyz.detach(), dim=1))
+    mesh = T.MeshPhase(dn, dbn, app, dpsr=DP.DPSR(res=(res,) * 3, sig=2.0), n_verts=n_verts, scale=1.0, device=dev, stand_in_weight=1e-3)
+    return T.Trainer(tr.g, tr.deform, tr.deform_back, tr.cameras, background=tr.bg, rank=rank, world=world, seed=0, mesh=mesh)
+
+
+@pytest.mark.gpu
+def test_mesh_phase_step_runs_the_dpsr_chain_and_moves_every_network():
+    """One process, the mesh co-training phase on the GPU code path: four fused-trunk networks on P, the DPSR chain (HIP splat ->
+    rocFFT -> HIP spectral solve -> HIP read-back, all with their adjoints), deform_back + appearance on the probe vertices, the
+    one-launch Adam over seven optimizers.  Every network, the Gaussian normals and positions and the density threshold must
+    receive a finite gradient and move; two identically seeded trainers agree to rounding (the DPSR splat accumulates with
+    atomics, like the reference's scatter_add: not bit-reproducible)."""
+    a, b = make_mesh_trainer(0, 1), make_mesh_trainer(0, 1)
+    before = [p.detach().clone() for p in a.params]
+    it = a.opt.dpsr_iter + a.opt.normal_deform_delay + 1000
+    for s in range(2):
+        la, _ = a.step(it + s)
+        lb, _ = b.step(it + s)
+    torch.cuda.synchronize()
+    assert torch.isfinite(la) and abs(float(la) - float(lb)) < 1e-5 * abs(float(la))
+    for x, y in zip(a.params, b.params):  # (Adam turns a rounding-level gradient difference into at most +-lr per step)
+        assert float((x - y).abs().max()) <= 5e-3
+    moved = [not torch.equal(x.detach(), y) for x, y in zip(a.params, before)]
+    off = 6
+    for m in [a.deform, a.deform_back] + a.mesh.networks():
+        n = len(list(m.net.parameters()))
+        assert any(moved[off:off + n]), m.model_name
+        off += n
+    assert moved[0] and moved[off] and moved[off + 1], "positions / normals / density threshold did not move"
+    assert all(bool(torch.isfinite(p).all()) for p in a.params)
