@@ -338,6 +338,7 @@ def main():
         s_dt, _, _, _ = timed(STEADY_STEPS, it0 + args.warmup + args.steps)
         steady = {"steps": STEADY_STEPS, "value": STEADY_STEPS * world / s_dt, "ms_per_step": 1e3 * s_dt / STEADY_STEPS}
 
+    n_inst_timed = int(RZ.LAST_NUM_RENDERED)  # tile instances R of the timed workload's last frame (the extras below render other scenes)
     # the gradient buckets' all-reduce on its own (what one step exchanges; in the step the larger bucket runs under the MLP
     # backward passes)
     allreduce = None
@@ -380,7 +381,7 @@ def main():
     if rank == 0:
         # R of the last frame (all frames of the synthetic orbit are statistically alike)
         R = int((pkg["radii"] > 0).sum().item())  # visible Gaussians (informational)
-        n_inst = int(importlib.import_module("dg-mesh_amd.rasterizer").LAST_NUM_RENDERED)  # tile instances R
+        n_inst = n_inst_timed  # tile instances R
         bwd_ms, bwd_n = stages.get("render_bwd", (0.0, 0))
         alg_bytes = 40.0 * n_inst + 20.0 * W * H + 36.0 * P  # render bwd per frame
         achieved = (alg_bytes / (bwd_ms * 1e-3) / 1e9) if bwd_ms > 0 else 0.0

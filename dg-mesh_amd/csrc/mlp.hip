@@ -958,7 +958,7 @@ Ws carve(char* base, int N) {
     w.Gexp[1] = (int*)take(ntiles * 4);
     w.Cin = (float4*)take(n * MLP_W * 4);
     w.Dp = (unsigned char*)take(n * 128);
-    w.matmax = (unsigned*)take(P4_MAX_MATS * 4);
+    w.matmax = (unsigned*)take(P4_MAX_MATS * 8 * 4);
     w.Wh4f = (uint4*)take((size_t)MLP_W * 32 * 4);
     w.Wh4b = (uint4*)take((size_t)16 * MLP_W * 4);
     w.wsc_hf = take(64);
@@ -1022,7 +1022,7 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     am.n_jobs = 9;
     for (int l = 0; l < 8; l++) am.job[l].W = p->W[l], am.job[l].n = MLP_W * layer_in(p, l);
     am.job[8].W = p->Wh, am.job[8].n = p->n_out * MLP_W;
-    hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + am.n_jobs), dim3(256), 0, st, N, nt, x, temb, 0, p->t_dim,
+    hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, 0, p->t_dim,
                        (unsigned char*)w.emb, w.Eexp, am, w.matmax);
     // every weight matrix as two binary16 planes, one power-of-two scale per matrix
     Prep4Batch pb;

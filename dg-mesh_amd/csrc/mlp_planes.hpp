@@ -96,37 +96,42 @@ struct AbsMaxBatch {
 
 // emb planes [Np][2][96] binary16 + one exponent per 32-row tile, rows >= N zero.
 //   emb[r] = [x, sin(x 2^0), cos(x 2^0), ..., sin(x 2^9), cos(x 2^9) | t_emb[r] | 0...]   (time_utils.py:24-55)
-// Grid: ntiles workgroups (one 32-row tile each) + am.n_jobs workgroups that reduce max |W| of one weight tensor each into
-// matmax[job] (float bits) -- the scales of the weight planes; riding along here saves a launch in front of the weight
-// preparation, which needs them.
+// Grid: 8 am.n_jobs workgroups that reduce max |W| of an eighth of one weight tensor each into matmax[job][8] (float bits; the
+// weight preparation folds the eight) -- the scales of the weight planes; riding along here saves a launch in front of the weight
+// preparation, which needs them -- followed by ntiles workgroups (one 32-row tile each).
 __global__ void __launch_bounds__(256)
 mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
                   unsigned char* __restrict__ Ep, int* __restrict__ Eexp, const AbsMaxBatch am, unsigned* __restrict__ matmax) {
     __shared__ float se[32][96 + 1];
     __shared__ float smax[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if ((int)blockIdx.x >= ntiles) {
-        const AbsMaxJob& jb = am.job[(int)blockIdx.x - ntiles];
+    constexpr int AS = 8;  // workgroups per weight tensor (the maxima jobs come FIRST in the grid: dispatched last they would be its tail)
+    const int n_am = am.n_jobs * AS;
+    if ((int)blockIdx.x < n_am) {
+        const int job = (int)blockIdx.x / AS, part = (int)blockIdx.x % AS;
+        const AbsMaxJob& jb = am.job[job];
         float m = 0.f;
-        const int n4 = jb.n >> 2;
+        const int per = ((jb.n + AS - 1) / AS + 3) & ~3;  // a multiple of four floats
+        const int i0 = part * per, i1 = min(jb.n, i0 + per);
         if ((((uintptr_t)jb.W) & 15) == 0) {
-            const float4* p = reinterpret_cast<const float4*>(jb.W);
+            const float4* p = reinterpret_cast<const float4*>(jb.W + i0);
+            const int n4 = i1 > i0 ? (i1 - i0) >> 2 : 0;
             for (int i = tid; i < n4; i += 256) {
                 const float4 v = p[i];
                 m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
-            for (int i = n4 * 4 + tid; i < jb.n; i += 256) m = fmaxf(m, fabsf(jb.W[i]));
+            for (int i = i0 + n4 * 4 + tid; i < i1; i += 256) m = fmaxf(m, fabsf(jb.W[i]));
         } else {
-            for (int i = tid; i < jb.n; i += 256) m = fmaxf(m, fabsf(jb.W[i]));
+            for (int i = i0 + tid; i < i1; i += 256) m = fmaxf(m, fabsf(jb.W[i]));
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
         if (lane == 0) smax[wv] = m;
         __syncthreads();
-        if (tid == 0) matmax[(int)blockIdx.x - ntiles] = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+        if (tid == 0) matmax[job * AS + part] = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
         return;
     }
-    const int tile = blockIdx.x, r0 = tile * 32;
+    const int tile = (int)blockIdx.x - n_am, r0 = tile * 32;
     float mx = 0.f;
     // sin / cos: lane < 60 of wave w evaluates one (row, frequency, axis) triple of rows 8 w + 2 it + {0, 1}
 #pragma unroll
@@ -197,7 +202,10 @@ mlp_prep4_kernel(const Prep4Batch b, const unsigned* __restrict__ matmax) {
     if ((int)blockIdx.x * 32 >= j.ncols) return;
     const int tid = threadIdx.x, col = blockIdx.x * 32 + (tid & 31), slot = tid >> 5, nkg = j.Kp >> 3;
     float sc, inv;
-    scale_from_max_bits(matmax[pj.mat], sc, inv);
+    unsigned mb = 0u;  // (non-negative floats order like their bit patterns)
+#pragma unroll
+    for (int i = 0; i < 8; i++) mb = max(mb, matmax[pj.mat * 8 + i]);
+    scale_from_max_bits(mb, sc, inv);
     if (blockIdx.x == 0 && tid == 0) j.inv_scale[0] = inv;
 #pragma unroll
     for (int it = 0; it < 6; it++) {

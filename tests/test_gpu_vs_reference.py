@@ -331,3 +331,51 @@ def test_reference_knn(orc):
         assert np.array_equal(ref.view(np.uint32), orc.knn(pts).view(np.uint32))
         got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+
+
+def test_reference_knn_timed_beside_ours():
+    """simple-knn: the reference's own SimpleKNN::knn (simple_knn.cu:185-221, compiled for gfx950 into oracle/_ref) and
+    dgm_knn_mean_dist2 on the same 100 k / 500 k points and the same GPU, device-resident input and output, median of warm
+    calls; results bit-identical (checked above).  The numbers go to gpurun_out/ref_vs_ours_knn.json (a committed copy:
+    profiles/r03_ref_vs_ours_knn.json)."""
+    import json
+    import os
+    import time
+
+    import torch
+    from simple_knn._C import distCUDA2
+    L = R.lib("")
+    L.ref_knn.restype = None
+    L.ref_knn.argtypes = [R._i, R._vp, R._vp]
+    out = {}
+    for P in (100_000, 500_000):
+        rng = np.random.RandomState(1)
+        pts = torch.tensor(((rng.rand(P, 3) * 2 - 1) * 1.3).astype(np.float32), device="cuda")
+        res = torch.zeros(P, device="cuda")
+
+        def run_ref():
+            L.ref_knn(P, R.p(pts), R.p(res))
+
+        def run_ours():
+            return distCUDA2(pts)
+
+        ms = {}
+        for name, fn in (("reference", run_ref), ("ours", run_ours)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            ms[name] = 1e3 * float(np.median(ts))
+        out[f"P={P}"] = {"reference_ms": round(ms["reference"], 3), "this_library_ms": round(ms["ours"], 3),
+                         "ratio": round(ms["reference"] / ms["ours"], 2), "algorithmic_bytes": 80 * P,
+                         "this_library_frac_hbm": 80 * P / (ms["ours"] * 1e-3) / 8e12}
+    out["timing"] = "median of 9 host-timed synchronous calls after 3 warm-up calls, points and result resident on the device"
+    print(out)
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/ref_vs_ours_knn.json", "w"), indent=1)
+    assert all(v["this_library_ms"] > 0 for k, v in out.items() if k.startswith("P="))
