@@ -53,6 +53,20 @@ __device__ __forceinline__ unsigned p4_pow2_h2(int d) {
     return h | (h << 16);
 }
 
+// (h, l) of two floats scaled by 2^e, without packed-f32 instructions (v_pk_mul_f32 / v_pk_fma_f32 are what the compiler
+// makes of split2h(x0 * s, x1 * s, ...) and they cost ~25 cycles each beside MFMAs): v_ldexp_f32, v_cvt_pk_f16_f32, and the
+// residual x - h as v_fma_mix_f32 (h read as binary16 straight from the packed register)
+__device__ __forceinline__ void p4_split2(float v0, float v1, int e, unsigned& h, unsigned& l) {
+    const float x0 = __builtin_amdgcn_ldexpf(v0, e), x1 = __builtin_amdgcn_ldexpf(v1, e);
+    const f16x2 hh = __builtin_convertvector((f32x2){x0, x1}, f16x2);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hh), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hh), "v"(x1));
+    const f16x2 ll = __builtin_convertvector((f32x2){r0, r1}, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
 // one wave-wide 1 KiB copy global -> LDS (lane i: 16 bytes from its own global address to lds_dst + 16 i); the destination
 // is wave-uniform.  Issued from inline asm: through the builtin the compiler treats the LDS-DMA as a store that may alias
 // every later ds_read and drains vmcnt in front of them.  Completion is ordered by hand (s_waitcnt vmcnt(0) + barrier).
@@ -559,10 +573,19 @@ mlp_gemm4_kernel(const Gemm4Args a) {
         }
         const float c = binv * p4_pow2(-e_prev);
         unsigned bits = 0u;
-        float m = 0.f, so = 0.f;
+        float m = 0.f;
+        int eo = 0;
         float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
         uint4 sv[4], smv = make_uint4(0u, 0u, 0u, 0u);
         const unsigned char* ps = Abuf + ab * ABYTES + li * PITCH + g * 16;
+        if (HS.value && KS > 1) {  // tile j-2's staged rows (and its mask block) back from LDS, long before E2 overwrites the tile
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int r = wv * 4 + rr;
+                sv[rr] = *reinterpret_cast<const uint4*>(Obuf + r * 1024 + ((lane ^ ((r >> 1) & 7)) << 4));
+            }
+            if ((EPI == 0 || EPI == 2) && wv == 7) smv = reinterpret_cast<const uint4*>(mbuf + pb * 256)[lane];
+        }
         P4_T(7)
         // E1 of element i of tile j-1: unscale, bias / Cin / mask, ReLU bit, running maximum -- in place in pv
 #define G4_E1(i_)                                                                                                      \
@@ -585,8 +608,8 @@ mlp_gemm4_kernel(const Gemm4Args a) {
 #define G4_E2(q_)                                                                                                      \
     {                                                                                                                  \
         unsigned h0_, l0_, h1_, l1_;                                                                                   \
-        split2h(pv[4 * (q_)] * so, pv[4 * (q_) + 1] * so, h0_, l0_);                                                   \
-        split2h(pv[4 * (q_) + 2] * so, pv[4 * (q_) + 3] * so, h1_, l1_);                                               \
+        p4_split2(pv[4 * (q_)], pv[4 * (q_) + 1], eo, h0_, l0_);                                                       \
+        p4_split2(pv[4 * (q_) + 2], pv[4 * (q_) + 3], eo, h1_, l1_);                                                   \
         unsigned char* d_ = ow + (st_x8 ^ ((q_) << 4));                                                                \
         *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                                          \
         *reinterpret_cast<uint2*>(d_ + 512) = make_uint2(l0_, l1_);                                                    \
@@ -610,6 +633,16 @@ mlp_gemm4_kernel(const Gemm4Args a) {
                 if (ks + P4_PD < KS) G4_FRAG(ks + P4_PD);
                 G4_MFMA(ks)
             }
+            if (KS > 1 && ks >= 1 && ks < H1) {  // tile j-2's row stores, early in the first half (one per K step when there are enough)
+                constexpr bool WIDE = H1 >= 5;
+                if (ks == 1) G4_SROW(0)
+                if (ks == (WIDE ? 2 : 1)) G4_SROW(1)
+                if (ks == (WIDE ? 3 : 2)) G4_SROW(2)
+                if (ks == (WIDE ? 4 : 2)) {
+                    G4_SROW(3)
+                    if (HS.value && (EPI == 0 || EPI == 2) && wv == 7) reinterpret_cast<uint4*>(a.mask_out + (size_t)(tile - 2 * G) * 256)[lane] = smv;
+                }
+            }
             if (HE.value && !(P4_ABL & 8)) {
                 if (ks < HE1) {  // E1 slices, elements 15 .. 0 in order (the mask bits shift in)
 #pragma unroll
@@ -623,24 +656,18 @@ mlp_gemm4_kernel(const Gemm4Args a) {
                     if (lane == 63) tmaxs[wv] = m;
                     if (EPI != 1) reinterpret_cast<unsigned short*>(mbuf + (1 - pb) * 256)[(li * 8 + wv) * 2 + g] = (unsigned short)bits;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (HS.value) {  // tile j-2's staged rows (and its mask block) back from LDS, before E2 overwrites the staging tile;
-                                 // issued BEHIND the LDS writes above: the barrier then only has to wait for those (LDS
-                                 // operations complete in order), the reads stay in flight across it
+                if (HS.value && KS == 1) {  // (no K loop: staged rows read here, stored right behind the barrier)
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++) {
                         const int r = wv * 4 + rr;
                         sv[rr] = *reinterpret_cast<const uint4*>(Obuf + r * 1024 + ((lane ^ ((r >> 1) & 7)) << 4));
                     }
-                    smv = reinterpret_cast<const uint4*>(mbuf + pb * 256)[lane];  // (every wave: a uniform count of reads in flight)
+                    if ((EPI == 0 || EPI == 2) && wv == 7) smv = reinterpret_cast<const uint4*>(mbuf + pb * 256)[lane];
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 P4_T(1)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 P4_T(2)
-                // MID: the tile maximum needs all eight waves; last step's vector memory is done
-                if (HS.value) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(5)\n\ts_barrier" ::: "memory");
-                else P4_STEP_BARRIER();
+                P4_STEP_BARRIER();  // MID: the tile maximum needs all eight waves; the vector memory issued so far is done
                 P4_T(3)
                 if (HE.value) {
                     t0 = *reinterpret_cast<const float4*>(tmaxs);
@@ -658,14 +685,8 @@ mlp_gemm4_kernel(const Gemm4Args a) {
                 const int s2 = ks - H1;
                 if (s2 == 0 && HE.value) {  // the tile's exponent from the eight wave maxima
                     const float tm = p4_max(p4_max(p4_max(t0.x, t0.y), p4_max(t0.z, t0.w)), p4_max(p4_max(t1.x, t1.y), p4_max(t1.z, t1.w)));
-                    const int eo = p4_exp_from_max_bits(__float_as_uint(tm));
-                    so = p4_pow2(eo);
+                    eo = p4_exp_from_max_bits(__float_as_uint(tm));
                     if (tid == 0) a.Cexp[tile - G] = eo;
-                }
-                if (s2 == 0) { G4_SROW(0) G4_SROW(1) }
-                if (s2 == (H2 >= 2 ? 1 : 0)) {
-                    G4_SROW(2) G4_SROW(3)
-                    if (HS.value && (EPI == 0 || EPI == 2) && wv == 7) reinterpret_cast<uint4*>(a.mask_out + (size_t)(tile - 2 * G) * 256)[lane] = smv;
                 }
                 if (HM.value && j + 2 < my_tiles && !(P4_ABL & 2)) {
 #pragma unroll
@@ -687,8 +708,7 @@ mlp_gemm4_kernel(const Gemm4Args a) {
             }
             if (KS == 1 && HE.value && !(P4_ABL & 8)) {
                 const float tm = p4_max(p4_max(p4_max(t0.x, t0.y), p4_max(t0.z, t0.w)), p4_max(p4_max(t1.x, t1.y), p4_max(t1.z, t1.w)));
-                const int eo = p4_exp_from_max_bits(__float_as_uint(tm));
-                so = p4_pow2(eo);
+                eo = p4_exp_from_max_bits(__float_as_uint(tm));
                 if (tid == 0) a.Cexp[tile - G] = eo;
                 G4_E2(0) G4_E2(1) G4_E2(2) G4_E2(3)
             }

@@ -10,6 +10,10 @@ impl = sys.argv[3] if len(sys.argv) > 3 else "hip"
 dev = "cuda"
 torch.manual_seed(0)
 net = D.DeformNetworkNormal(is_blender=True, trunk_impl=impl).to(dev)
+if os.environ.get("DGM_BENCH_ZERO") == "1":  # power experiment: all-zero operands (same instruction stream, no toggling)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.zero_()
 x = (torch.rand(N, 3, device=dev) * 2 - 1) * 1.3
 t = torch.tensor([[0.3]], device=dev).expand(N, -1)
 w = torch.randn(N, 13, device=dev)
