@@ -414,6 +414,9 @@ def main():
             "mlp_layer_fwd": (kn[0], layer_flops, layer_bytes, pm[0]),
             "mlp_layer_bwd": (kn[1], layer_flops, layer_bytes, pm[1]),
             "mlp_layer_dw": (kn[2], layer_flops, dw_bytes, pm[2]),
+            # backward data + weight gradient of one layer in one launch (plane arithmetic): G_l read once algorithmically
+            "mlp_bwd_pair": ("mlp_bwd_pair_kernel (256->256 backward-data on part of the CUs + 256x256 weight gradient on the rest)",
+                             2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r03_pmc_bwd_pair.json"),
             "render_bwd": ("render_bwd3_kernel", 0.0, alg_bytes, "pmc_render_bwd3.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
             "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out

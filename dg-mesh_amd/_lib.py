@@ -131,7 +131,7 @@ def check(status):
         raise RuntimeError(lib().dgm_last_error().decode() or "libdgmesh_hip error")
 
 
-STAGE_COUNT = 11
+STAGE_COUNT = 12
 
 
 def stage_ms():

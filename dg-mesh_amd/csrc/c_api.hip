@@ -252,7 +252,7 @@ int dgm_get_stage_ms(float* ms, int capacity) {
 const char* dgm_stage_name(int s) {
     static const char* names[DGM_STAGE_COUNT] = {"preprocess_fwd", "bin_count",      "bin_scan",      "bin_scatter",
                                                  "tile_sort",      "render_fwd",     "render_bwd",    "preprocess_bwd",
-                                                 "mlp_layer_fwd",  "mlp_layer_bwd",  "mlp_layer_dw"};
+                                                 "mlp_layer_fwd",  "mlp_layer_bwd",  "mlp_layer_dw",  "mlp_bwd_pair"};
     return (s >= 0 && s < DGM_STAGE_COUNT) ? names[s] : "?";
 }
 

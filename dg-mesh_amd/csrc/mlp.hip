@@ -386,15 +386,16 @@ __global__ void mlp_reduce_dw_kernel(int chunks, int db_chunks, int Kp, int in_f
 // The same reduction in ONE pass for the matrix-core paths (256 partial tiles of 256 KB per layer: the read is the cost).
 struct ReduceDwJob {
     int chunks, db_rows, Kp, in_features, nblocks;
+    int dst_off;  // Kp == 256 jobs: first input feature the rows go to (the skip layer's trunk rows as a job of their own)
     const float* partial;
     const float* partial_db;
     float* dW;
     float* db;
 };
 struct ReduceDwBatch {
-    int emb_dim;
-    ReduceDwJob job[8];
-    // blockIdx.y == 8: the heads' partial sums (mlp_heads_bwd_kernel) ride along, see reduce_heads_body
+    int emb_dim, n_jobs;
+    ReduceDwJob job[9];
+    // blockIdx.y == n_jobs: the heads' partial sums (mlp_heads_bwd_kernel) ride along, see reduce_heads_body
     int h_chunks, h_bchunks, h_nout;  // (h_bchunks: rows of h_partial_b -- the plane path leaves one per 32-row tile)
     const float* h_partial_W;
     const float* h_partial_b;
@@ -421,7 +422,7 @@ mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
     constexpr int KT = RDW_KT, JT = RDW_JT, JQ = JT / 4, JB = MLP_W / JT;
     __shared__ float4 red[4][64];
     __shared__ float redb[32][8];
-    if (blockIdx.y == 8) {  // (workgroup-uniform branch)
+    if ((int)blockIdx.y == rb.n_jobs) {  // (workgroup-uniform branch)
         if ((int)blockIdx.x < 8 * rb.h_nout)
             reduce_heads_body(blockIdx.x & 7, blockIdx.x >> 3, rb.h_chunks, rb.h_bchunks, rb.h_partial_W, rb.h_partial_b, rb.h_dW, rb.h_db);
         return;
@@ -477,7 +478,7 @@ mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
         const float s = ((r[0] + r[256]) + r[512]) + r[768];
         const int k = k0 + kk;
         int dst;
-        if (Kp == MLP_W) dst = k;
+        if (Kp == MLP_W) dst = k + jb.dst_off;
         else if (k < MLP_EMB) dst = k < emb_dim ? k : -1;
         else dst = k - MLP_EMB + emb_dim;
         if (dst >= 0) dW[(size_t)(j0 + jj) * in_features + dst] = s;
@@ -1012,6 +1013,23 @@ typedef Gemm4Cfg<1, 128, 64, 1, false, 8> CfgG7;
 typedef Dw4Cfg<8, 8, 1024, 512, 1024, 512> CfgDw;
 typedef Dw4Cfg<3, 8, 384, 192, 1024, 512> CfgDwE;
 typedef Dw4Cfg<8, 1, 1024, 512, 128, 64> CfgDwH;
+#ifndef P4_PAIR_SHARE_NUM
+#define P4_PAIR_SHARE_NUM 128  // share of the CUs on the weight gradient in a paired backward launch: NUM / DEN (measured at N = 100 k: 96 -> 1.50, 112 -> 1.43, 128 -> 1.41, 144 -> 1.43, off -> 1.56 ms per network pass)
+#define P4_PAIR_SHARE_DEN 256
+#endif
+
+// workgroups of a backward launch that run the weight gradient (mlp_bwd_pair_kernel); 0 = two separate launches.
+// DGM_MLP_PAIR=<n> overrides (0 disables); default: a fixed share of the CUs, chosen by measurement at N = 100 k.
+int p4_pair_split(int ntiles, int gx) {
+    static int env = [] {
+        const char* e = getenv("DGM_MLP_PAIR");
+        return e ? atoi(e) : -1;
+    }();
+    if (gx < 64 || ntiles < 4 * gx) return 0;  // small problems: nothing to balance
+    int n = env >= 0 ? env : (gx * P4_PAIR_SHARE_NUM) / P4_PAIR_SHARE_DEN;
+    if (n >= gx) n = gx - 1;
+    return n;
+}
 
 int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* temb, const Ws& w, float* out, hipStream_t st) {
     const P4Plan pl = p4_plan(N);
@@ -1101,33 +1119,72 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     d.partial_db = nullptr;
     P4_LAUNCH((mlp_dw4_kernel<8, 1, 1024, 512, 128, 64>), CfgDwH::LDS, pl.chunks, st, d)
     ReduceDwBatch rb;
-    rb.emb_dim = p->emb_dim;
+    rb.emb_dim = p->emb_dim, rb.n_jobs = 8;
     int rb_blocks = 0;
+    auto add_job = [&](int slot, int chunks, int db_rows, int Kp, int in_features, int dst_off, const float* partial,
+                       const float* partial_db, float* dWp, float* dbp) {
+        ReduceDwJob& jb = rb.job[slot];
+        jb.chunks = chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = in_features, jb.nblocks = reduce_dw_blocks(Kp);
+        jb.dst_off = dst_off, jb.partial = partial, jb.partial_db = partial_db, jb.dW = dWp, jb.db = dbp;
+        if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;
+    };
+    // Layers 7 .. 1: backward data (G_l -> G_{l-1}) and the weight gradient of layer l both consume G_l and nothing of each
+    // other: ONE launch, the first n_dw workgroups on the weight gradient (n_dw row chunks), the rest on the layer GEMM
+    // (mlp_bwd_pair_kernel).  n_dw = 0 (DGM_MLP_PAIR=0) runs them as two launches over all CUs.  The embedding's rows of the
+    // skip layer's gradient stay a launch of their own over all CUs (own partial tiles, own reduction job).
+    const int n_dw = p4_pair_split(nt, gx);
     for (int l = 7; l >= 0; l--) {
-        if (l >= 1) {  // backward data first: G_{l-1} = (G_l W_l) masked, into the other buffer
-            a.A = G, a.Aexp = Ge, a.Bp = w.Wd3[l], a.b_inv = w.wsc_d[l], a.mask_in = w.mask[l - 1], a.C = Gn, a.Cexp = Gne;
-            dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
-            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
-            dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
-        }
         const int Kp = layer_kp(p, l);
-        d.G = G, d.Gexp = Ge, d.chunk_stride = (size_t)Kp * MLP_W;
+        const bool paired = n_dw > 0 && l >= 1;
+        const int chunks_l = paired ? n_dw : pl.chunks;
+        if (l >= 1) {  // backward data: G_{l-1} = (G_l W_l) masked, into the other buffer
+            a.A = G, a.Aexp = Ge, a.Bp = w.Wd3[l], a.b_inv = w.wsc_d[l], a.mask_in = w.mask[l - 1], a.C = Gn, a.Cexp = Gne;
+        }
+        d.G = G, d.Gexp = Ge;
+        // partial tiles of the layer: [chunk][Kp][256]; paired skip layer: trunk rows [n_dw][256][256], then embedding rows [chunks][96][256]
+        float* part_emb = w.partial_l[l];
+        float* part_trunk = w.partial_l[l] + (l == sk ? (size_t)MLP_EMB * MLP_W : 0);
+        size_t stride_emb = (size_t)Kp * MLP_W, stride_trunk = (size_t)Kp * MLP_W;
+        if (paired && l == sk) {
+            part_trunk = w.partial_l[l], stride_trunk = (size_t)MLP_W * MLP_W;
+            part_emb = w.partial_l[l] + (size_t)n_dw * MLP_W * MLP_W, stride_emb = (size_t)MLP_EMB * MLP_W;
+        }
         if (l == 0 || l == sk) {  // the embedding's rows of the gradient (rows 0 .. 95 of the K = 96 / 352 partial tile)
-            d.X = (const unsigned char*)w.emb, d.Xexp = w.Eexp, d.partial = w.partial_l[l], d.partial_db = w.partial_db_l[l];
+            d.tiles_per_chunk = pl.tiles_per_chunk;
+            d.X = (const unsigned char*)w.emb, d.Xexp = w.Eexp, d.partial = part_emb, d.chunk_stride = stride_emb, d.partial_db = w.partial_db_l[l];
             P4_LAUNCH((mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>), CfgDwE::LDS, pl.chunks, st, d)
         }
         if (l != 0) {
+            d.tiles_per_chunk = paired ? (nt + n_dw - 1) / n_dw : pl.tiles_per_chunk;
             d.X = (const unsigned char*)w.Y[l - 1], d.Xexp = w.Yexp[l - 1];
-            d.partial = w.partial_l[l] + (l == sk ? (size_t)MLP_EMB * MLP_W : 0);
+            d.partial = part_trunk, d.chunk_stride = stride_trunk;
             d.partial_db = l == sk ? nullptr : w.partial_db_l[l];  // (the skip layer's bias gradient came with its embedding half)
+        }
+        if (paired) {
+            dgm::prof_begin(DGM_STAGE_MLP_BWD_PAIR, st);
+            {
+                static bool done_[DGM_MAX_DEVICES] = {false};
+                constexpr int LDS_PAIR = CfgBwd::LDS > CfgDw::LDS ? CfgBwd::LDS : CfgDw::LDS;
+                if (p4_lds_attr(mlp_bwd_pair_kernel, LDS_PAIR, &done_[current_device_slot()]) != hipSuccess)
+                    return mlp_fail("mlp: cannot raise the LDS limit of mlp_bwd_pair_kernel");
+                const int grid = n_dw + (gx - n_dw > 0 ? gx - n_dw : 1);
+                hipLaunchKernelGGL(mlp_bwd_pair_kernel, dim3(grid), dim3(512), LDS_PAIR, st, a, d, n_dw);
+            }
+            dgm::prof_end(DGM_STAGE_MLP_BWD_PAIR, st);
+        } else if (l >= 1) {
+            dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
+            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
+            dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
             dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
-            P4_LAUNCH((mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>), CfgDw::LDS, pl.chunks, st, d)
+            P4_LAUNCH((mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>), CfgDw::LDS, chunks_l, st, d)
             dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
         }
-        ReduceDwJob& jb = rb.job[l];
-        jb.chunks = pl.chunks, jb.db_rows = 8 * pl.chunks, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = reduce_dw_blocks(Kp);
-        jb.partial = w.partial_l[l], jb.partial_db = w.partial_db_l[l], jb.dW = dW[l], jb.db = db[l];
-        if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;
+        if (paired && l == sk) {  // two reduction jobs: embedding rows (with the bias gradient), trunk rows
+            add_job(l, pl.chunks, 8 * pl.chunks, MLP_EMB, layer_in(p, l), 0, part_emb, w.partial_db_l[l], dW[l], db[l]);
+            add_job(8, n_dw, 0, MLP_W, layer_in(p, l), p->emb_dim, part_trunk, nullptr, dW[l], nullptr);
+            rb.n_jobs = 9;
+        } else
+            add_job(l, chunks_l, 8 * chunks_l, Kp, layer_in(p, l), 0, w.partial_l[l], w.partial_db_l[l], dW[l], db[l]);
         if (l >= 1) {
             unsigned char* t = G;
             G = Gn, Gn = t;
@@ -1137,7 +1194,7 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     }
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
     rb.h_dW = dWh, rb.h_db = dbh;
-    hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, 9), dim3(256), 0, st, rb);
+    hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, rb.n_jobs + 1), dim3(256), 0, st, rb);
     if (dtemb != nullptr)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
                            db[sk], p->W[sk], layer_in(p, sk), dtemb);
@@ -1346,7 +1403,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     float* Gn = w.Gb;
     const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
     ReduceDwBatch rb;
-    rb.emb_dim = p->emb_dim;
+    rb.emb_dim = p->emb_dim, rb.n_jobs = 8;
     int rb_blocks = 0;
     for (int l = 7; l >= 0; l--) {
         const float *X1, *X2 = nullptr;
@@ -1413,6 +1470,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
                 hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
                                    K2, G, w.partial_l[l], w.partial_db_l[l]);
             ReduceDwJob& jb = rb.job[l];
+            jb.dst_off = 0;
             jb.chunks = d.chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = reduce_dw_blocks(Kp);
             jb.partial = w.partial_l[l], jb.partial_db = w.partial_db_l[l], jb.dW = dW[l], jb.db = db[l];
             if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;

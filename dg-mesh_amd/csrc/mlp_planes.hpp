@@ -352,8 +352,7 @@ struct Gemm4Cfg {
 // shortage of bandwidth stalls the matrix cores; loads and stores may complete in any order (the counter is only ever
 // waited down to zero).
 template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
-__global__ void __launch_bounds__(512)
-mlp_gemm4_kernel(const Gemm4Args a) {
+__device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, const int G, unsigned char* smem) {
     using Cfg = Gemm4Cfg<KS, ROWB, PLANEB, EPI, DUAL, NCW>;
     constexpr int PITCH = Cfg::PITCH, ABYTES = Cfg::ABYTES;
     constexpr int LPR = ROWB / 16;                           // 16-byte pieces (lanes) per row
@@ -361,7 +360,6 @@ mlp_gemm4_kernel(const Gemm4Args a) {
     constexpr int NI = (32 + RPI - 1) / RPI;                 // copy instructions per tile
     constexpr int NCOLS = NCW * 32;
     static_assert(!DUAL || EPI == 0, "the second output rides along with a ReLU layer");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Abuf = smem;                                                  // [3][32][PITCH]
     unsigned char* Mibuf = smem + Cfg::A_END;                                    // [3][1024] mask blocks in (EPI 1)
     unsigned char* Obuf = smem + Cfg::A_END + Cfg::MI_BYTES;                     // [32][1024] staging of the output planes (swizzled)
@@ -371,8 +369,7 @@ mlp_gemm4_kernel(const Gemm4Args a) {
     float* biasl = reinterpret_cast<float*>(exps + Cfg::EXPS);                   // [256] (EPI 0: read per tile, not held in registers)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
-    const int G = gridDim.x;
-    const int my_tiles = (a.ntiles - (int)blockIdx.x + G - 1) / G;
+    const int my_tiles = (a.ntiles - bx + G - 1) / G;
     if (my_tiles <= 0) return;
     const bool computing = wv < NCW;
 #ifdef P4_TIMING
@@ -401,9 +398,9 @@ mlp_gemm4_kernel(const Gemm4Args a) {
     }
 
     // first the tiles (their latency is the longest), then the exponents and the stationary weights
-    G4_COPY(blockIdx.x, 0)
-    if (my_tiles > 1) G4_COPY(blockIdx.x + G, 1)
-    for (int t = tid; t < my_tiles && t < Cfg::EXPS; t += 512) exps[t] = a.Aexp[blockIdx.x + t * G];
+    G4_COPY(bx, 0)
+    if (my_tiles > 1) G4_COPY(bx + G, 1)
+    for (int t = tid; t < my_tiles && t < Cfg::EXPS; t += 512) exps[t] = a.Aexp[bx + t * G];
     if (EPI == 0 && tid < 256) biasl[tid] = a.bias[tid];
 #ifdef P4_TIMING
     const unsigned long long t_p1 = __builtin_amdgcn_s_memtime();
@@ -498,7 +495,7 @@ mlp_gemm4_kernel(const Gemm4Args a) {
         // ---- the heads: no output planes, no pipeline -- copy two tiles ahead, multiply (wave 0), store fp32
         int ab = 0;
         for (int j = 0; j < my_tiles; j++) {
-            const int tile = blockIdx.x + j * G;
+            const int tile = bx + j * G;
             if (j + 2 < my_tiles) G4_COPY(tile + 2 * G, ab == 0 ? 2 : ab - 1)
             if (computing) {
                 const int e_in = a.Aexp[tile];
@@ -563,7 +560,7 @@ mlp_gemm4_kernel(const Gemm4Args a) {
     constexpr int NIW = (NI + 7) / 8;  // copy instructions per wave and tile
     auto step = [&](auto HM, auto HE, auto HS, const int j, const int ab) __attribute__((always_inline)) {
         const int pb = j & 1;
-        const int tile = blockIdx.x + j * G;
+        const int tile = bx + j * G;
         const int abp = ab == 0 ? 2 : ab - 1;  // buffer of tile j-1 (= the one tile j+2 goes to)
         const int e_prev = e_next;
         const unsigned mh_prev = mh_next;
@@ -777,23 +774,30 @@ mlp_gemm4_kernel(const Gemm4Args a) {
     else step(F_{}, T_{}, F_{}, my_tiles, my_tiles % 3);
     step(F_{}, F_{}, T_{}, my_tiles + 1, (my_tiles + 1) % 3);
 #ifdef P4_TIMING
-    if (P4_TIME_ON && lane == 0 && blockIdx.x < 256) {
+    if (P4_TIME_ON && lane == 0 && bx < 256) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) g_p4_timing[(blockIdx.x * 8 + wv) * 16 + k] = tacc[k];
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 8] = t_loop - t_entry;
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 9] = __builtin_amdgcn_s_memtime() - t_entry;
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 10] = t_entry;
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 11] = __builtin_amdgcn_s_memtime();
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 12] = my_tiles;
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 13] = t_p1 - t_entry;
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 14] = t_p2 - t_p1;
-        g_p4_timing[(blockIdx.x * 8 + wv) * 16 + 15] = t_p3 - t_p2;
+        for (int k = 0; k < 8; k++) g_p4_timing[(bx * 8 + wv) * 16 + k] = tacc[k];
+        g_p4_timing[(bx * 8 + wv) * 16 + 8] = t_loop - t_entry;
+        g_p4_timing[(bx * 8 + wv) * 16 + 9] = __builtin_amdgcn_s_memtime() - t_entry;
+        g_p4_timing[(bx * 8 + wv) * 16 + 10] = t_entry;
+        g_p4_timing[(bx * 8 + wv) * 16 + 11] = __builtin_amdgcn_s_memtime();
+        g_p4_timing[(bx * 8 + wv) * 16 + 12] = my_tiles;
+        g_p4_timing[(bx * 8 + wv) * 16 + 13] = t_p1 - t_entry;
+        g_p4_timing[(bx * 8 + wv) * 16 + 14] = t_p2 - t_p1;
+        g_p4_timing[(bx * 8 + wv) * 16 + 15] = t_p3 - t_p2;
     }
 #endif
 #undef G4_COPY
 #undef G4_COPY1
 #undef G4_FRAG
 #undef G4_MFMA
+}
+
+template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
+__global__ void __launch_bounds__(512)
+mlp_gemm4_kernel(const Gemm4Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char p4_smem[];
+    gemm4_body<KS, ROWB, PLANEB, EPI, DUAL, NCW>(a, (int)blockIdx.x, (int)gridDim.x, p4_smem);
 }
 
 // ---- weight gradient on planes -----------------------------------------------------------------------------------------------
@@ -840,8 +844,7 @@ struct Dw4Cfg {
 };
 
 template <int MT, int NT, int XROWB, int XPLANEB, int GROWB, int GPLANEB>
-__global__ void __launch_bounds__(512)
-mlp_dw4_kernel(const Dw4Args a) {
+__device__ __forceinline__ void dw4_body(const Dw4Args& a, const int chunk, unsigned char* smem) {
     using Cfg = Dw4Cfg<MT, NT, XROWB, XPLANEB, GROWB, GPLANEB>;
     constexpr int XK = Cfg::XK, GK = Cfg::GK, XU = Cfg::XU, GU = Cfg::GU;
     constexpr int XCG = XK / 8, GCG = GK / 8;    // column groups
@@ -849,12 +852,11 @@ mlp_dw4_kernel(const Dw4Args a) {
     constexpr int MTW = NT == 8 ? MT : 1;        // m-tiles per wave
     static_assert(NT == 8 || (NT == 1 && MT == 8), "wave decomposition");
     static_assert(XB <= 256 && GB <= 256, "stager layout");
-    extern __shared__ __attribute__((aligned(16))) uint4 dw4_lds[];
+    uint4* const dw4_lds = reinterpret_cast<uint4*>(smem);
     uint4* Xs = dw4_lds;             // [2][XU]
     uint4* Gs = dw4_lds + 2 * XU;    // [2][GU]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
-    const int chunk = blockIdx.x;
     const int t0 = chunk * a.tiles_per_chunk, t1 = min(a.ntiles, t0 + a.tiles_per_chunk);
     const int nst = t1 - t0;
     if (nst <= 0) return;
@@ -868,7 +870,14 @@ mlp_dw4_kernel(const Dw4Args a) {
     const bool isX = tid < XB, isG = tid >= 256 && tid < 256 + GB;
     const int st = isG ? tid - 256 : tid;
     const int ncg = isG ? GCG : XCG;
-    const int cg = st % ncg, rg = (st / ncg) & 3, pl = st / (ncg * 4);
+#ifndef DW4_ROWMAJOR_STAGERS
+#define DW4_ROWMAJOR_STAGERS 1
+#endif
+    // stager -> (column group, plane, row group): plane next to the column group, so that a wave's load instruction covers whole
+    // rows ([h | l] = one contiguous 1 KiB at K = 256) instead of two half rows eight rows apart
+    const int cg = st % ncg;
+    const int pl = DW4_ROWMAJOR_STAGERS ? (st / ncg) & 1 : st / (ncg * 4);
+    const int rg = DW4_ROWMAJOR_STAGERS ? st / (ncg * 2) : (st / ncg) & 3;
     const unsigned char* src = isG ? a.G + (size_t)pl * GPLANEB + cg * 16 : a.X + (size_t)pl * XPLANEB + cg * 16;
     const int srow = isG ? GROWB : XROWB;
     uint4* sdst = (isG ? Gs : Xs) + (pl * 4 + rg) * (isG ? GK : XK) + cg * 8;
@@ -997,6 +1006,25 @@ mlp_dw4_kernel(const Dw4Args a) {
         *reinterpret_cast<float4*>(d) = make_float4(cs[0], cs[1], cs[2], cs[3]);
         *reinterpret_cast<float4*>(d + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
     }
+}
+
+template <int MT, int NT, int XROWB, int XPLANEB, int GROWB, int GPLANEB>
+__global__ void __launch_bounds__(512)
+mlp_dw4_kernel(const Dw4Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char p4_smem[];
+    dw4_body<MT, NT, XROWB, XPLANEB, GROWB, GPLANEB>(a, (int)blockIdx.x, p4_smem);
+}
+
+// ---- backward data of layer l and the weight gradient of layer l in ONE launch ------------------------------------------------
+// Both consume G_l and nothing of each other, and they stress different parts of the chip: the layer GEMM is limited by power
+// in the matrix cores at ~0.5 of the HBM roof, the weight gradient by HBM.  The first n_dw workgroups run the weight-gradient
+// body on n_dw row chunks, the others the layer GEMM on the remaining CUs.  Besides running a memory-bound and a compute-bound
+// stream side by side this cuts the per-chunk partial tiles (and the reduction that reads them) from one per CU to n_dw.
+__global__ void __launch_bounds__(512)
+mlp_bwd_pair_kernel(const Gemm4Args ga, const Dw4Args da, const int n_dw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char p4_smem[];
+    if ((int)blockIdx.x < n_dw) dw4_body<8, 8, 1024, 512, 1024, 512>(da, (int)blockIdx.x, p4_smem);
+    else gemm4_body<16, 1024, 512, 1, false, 8>(ga, (int)blockIdx.x - n_dw, (int)gridDim.x - n_dw, p4_smem);
 }
 
 }  // namespace dgm

@@ -175,6 +175,7 @@ enum {
     DGM_STAGE_MLP_LAYER_FWD, /* one 256 -> 256 trunk layer, forward GEMM launch (deferred mode only) */
     DGM_STAGE_MLP_LAYER_BWD, /* one 256 -> 256 backward-data GEMM launch */
     DGM_STAGE_MLP_LAYER_DW,  /* one 256 x 256 weight-gradient GEMM launch (without its reductions) */
+    DGM_STAGE_MLP_BWD_PAIR,  /* backward data + weight gradient of one 256-wide layer in one launch (plane arithmetic) */
     DGM_STAGE_COUNT
 };
 void dgm_set_profiling(int mode);

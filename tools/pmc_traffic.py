@@ -19,7 +19,7 @@ KERNELS = {"gemm3r_fwd": "mlp_gemm3p_kernel<0, false>", "gemm3r_bwd": "mlp_gemm3
            "gemm4_fwd": "mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>", "gemm4_bwd": "mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>",
            "dw4": "mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>", "gemm4_skip": "mlp_gemm4_kernel<16, 1024, 512, 2, false, 8>",
            "gemm4_l0": "mlp_gemm4_kernel<6, 384, 192, 0, true, 8>", "dw4_emb": "mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>",
-           "embed4": "mlp_embed4_kernel"}
+           "embed4": "mlp_embed4_kernel", "bwd_pair": "mlp_bwd_pair_kernel"}
 # kernels whose reads are gathers of short records: the x2 streaming-read correction of FETCH_SIZE is not calibrated for them
 GATHER = {"render_bwd3", "render_fwd", "preprocess_bwd", "tile_sort_radix", "scatter"}
 
