@@ -1192,6 +1192,8 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
             Ge = Gne, Gne = te;
         }
     }
+    // (tried: each layer's reduction on a side stream under the next layer's launch -- its small workgroups do fit beside a
+    // resident pair workgroup -- 265 vs 274 it/s: slower, the pair kernel's HBM-bound half gets the competition)
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
     rb.h_dW = dWh, rb.h_db = dbh;
     hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, rb.n_jobs + 1), dim3(256), 0, st, rb);
