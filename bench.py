@@ -26,6 +26,9 @@ carries the RCCL world size observed and the all-reduce of the step's gradient b
 region at N = 1.  `roofline_render_bwd_trained` = the rasterizer backward on SURVEY.md section 8(d)'s trained-like scene (the
 distribution on which north_star's HBM target is approachable), measured here with the library's stage timers; `frac_valu` of
 the blend kernels comes from the committed PMC pass (VALU lane operations / 78.6 T lane-op/s).
+`streams` = 2: the cycle branch (backward network) is issued on a second HIP stream beside the rasterizer (Trainer.side_stream);
+kernel durations in `roofline` / `kernels` are taken inside that region, `one_stream` repeats the step and the durations with
+one stream (`roofline.one_stream`: the dominant kernel with nothing beside it).
 `cpu_baseline` = the same step on the host cores (oracle rasterizer + PyTorch-CPU MLPs; a port of the reference's CPU
 path, not the reference itself, which is not on the GPU box), rank 0 at N=1 only, on a bounded sample.
 """
@@ -371,6 +374,21 @@ def main():
         finally:
             L.lib().dgm_mlp_set_gemm(prev)
 
+    # the same step with the cycle branch on the main stream (no kernels running side by side): the kernel durations the
+    # committed rocprofv3 / PMC passes of single kernels correspond to; N = 1, a short extra region
+    one_stream = None
+    if world == 1 and getattr(tr, "side_stream", None) is not None and not args.no_extras:
+        keep, tr.side_stream = tr.side_stream, None
+        try:
+            for i in range(5):
+                tr.step(it0 + i)
+            n1 = 60
+            o_dt, o_st, _, _ = timed(n1, it0 + 5)
+            one_stream = {"value": n1 / o_dt, "unit": "it/s", "ms_per_step": 1e3 * o_dt / n1, "steps": n1,
+                          "avg_ms": {k: round(v[0], 5) for k, v in o_st.items()}}
+        finally:
+            tr.side_stream = keep
+
     trained = None
     if rank == 0 and world == 1 and not args.no_extras and args.phase == "gs":
         try:
@@ -457,6 +475,12 @@ def main():
                                         "split once by the producer, 3 MFMAs per product" if planes else
                                         "f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
                                         if f16x3 else "bf16x6: 3 bf16 planes, 6 MFMAs per product")})
+            if one_stream is not None and one_stream["avg_ms"].get(best, 0) > 0:
+                # the same kernel with nothing beside it (in the timed region the backward network's launches share the chip
+                # with the rasterizer's: shorter step, longer launches)
+                ms1 = one_stream["avg_ms"][best]
+                roof["one_stream"] = {"avg_ms": ms1, "frac_hbm": round(by / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "step_value": round(one_stream["value"], 2)}
         rb_traffic, rb_src = pmc_traffic("pmc_render_bwd3.json")
         out = {
             "metric": ("train-step iters/sec (800x800, ~100k Gaussians)" if WORKLOAD == "cfg2"
@@ -495,6 +519,9 @@ def main():
             out["allreduce"] = allreduce
         if f32_mode is not None:
             out["mlp_f32_mode"] = f32_mode
+        if one_stream is not None:
+            out["one_stream"] = one_stream
+        out["streams"] = 2 if getattr(tr, "side_stream", None) is not None else 1
         if trained is not None:
             out["roofline_render_bwd_trained"] = trained
         fv = frac_valu_from_profiles()

@@ -30,6 +30,7 @@ ranks, every rank holds a full replica of the Gaussians and MLPs.
     GPU that is one kernel for all three optimizers (optim.MultiAdam).
   W ranks x 1 frame is therefore equivalent to 1 rank accumulating the same W frames before stepping.
 """
+import os
 import random
 
 import torch
@@ -130,7 +131,8 @@ class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
                  process_group=None, fused_loss=True, fused_glue=None, track_stats=True, densify=False,
-                 cameras_extent=1.0, prune_threshold=0.005, white_background=True, overlap=True, mesh=None):
+                 cameras_extent=1.0, prune_threshold=0.005, white_background=True, overlap=True, mesh=None,
+                 side_stream=None):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
         self.mesh = mesh
         self.cameras = cameras
@@ -167,6 +169,11 @@ class Trainer:
             from .optim import MultiAdam
             self.multi_adam = MultiAdam(self.optimizers)
         self.pack = self.multi_adam is not None
+        # second stream for the cycle branch (loss_terms); None = the DGM_SIDE_STREAM environment variable (default on)
+        if side_stream is None:
+            side_stream = os.environ.get("DGM_SIDE_STREAM", "1") == "1"
+        prio = int(os.environ.get("DGM_SIDE_PRIORITY", "0"))
+        self.side_stream = torch.cuda.Stream(device=dev, priority=prio) if side_stream and dev.type == "cuda" else None
         self._bind_parameters()
         # normal samples of densify_and_split: one generator per rank, seeded alike, advanced in lockstep
         self.densify_generator = None
@@ -279,7 +286,27 @@ class Trainer:
         if delta is not None:
             from .glue import cycle_loss
             lean = {"lean": True} if self.render_fn is S.render else {}
-            if self.world > 1 and self._early is not None:
+            if self.side_stream is not None:
+                # The cycle branch (the backward network, 1.3 ms of HBM- / power-bound GEMMs at cfg2) depends on the deformation
+                # only, not on the rasterizer (1 ms of VALU-bound blending and latency-bound binning): build it on a second
+                # stream.  Autograd runs every node's backward on its forward's stream and orders the two gradients of `delta`
+                # itself, so the branch's backward overlaps the rasterizer's as well.  (Also built BEFORE the render branch:
+                # see the data-parallel case below.)  Measured: 278 -> 296 it/s at cfg2; cutting the branch's graph at
+                # `delta` and differentiating it at once on the side stream -- no wait for the root's gradient -- was slower
+                # (292: its launches delay the rasterizer's on the host).
+                cur, side = torch.cuda.current_stream(), self.side_stream
+                means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
+                t_back = self.time_input(cam, N, iteration)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    back = self.deform_back.step_raw(means, t_back)
+                    cyc = cycle_loss(delta, back)
+                    cyc.record_stream(cur)       # (made on the side stream, read on this one)
+                    means.record_stream(side)    # (and the other way round)
+                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta, **lean)
+                cur.wait_stream(side)
+                losses["cycle_loss"] = cyc
+            elif self.world > 1 and self._early is not None:
                 # Data parallel with the early Gaussian-bucket all-reduce: build the cycle branch BEFORE the render branch.
                 # Autograd runs later-built branches first, so the rasterizer's backward -- after which the Gaussian
                 # gradients are final and their all-reduce starts -- then precedes BOTH MLP backward passes instead of only

@@ -1,9 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_mlp.py tests/test_trainer_dp_gpu.py -m gpu -q 2>&1 | tail -3
-for sd in 1 0; do
-  echo "side=$sd: $(DGM_MLP_SIDE=$sd python tools/mlp_bench.py 100000 30 2>&1 | grep impl=)"
-  DGM_MLP_SIDE=$sd timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > gpurun_out/side$sd.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/side$sd.json')); print('side=$sd bench', round(d['value'],1), round(d['ms_per_step'],3), d['host_ms_per_step'])"
-done
+b() { python bench.py --steps 100 --warmup 20 --no-extras --no-cpu-baseline 2>&1 | grep '^{' | python -c 'import json,sys; r=json.loads(sys.stdin.read()); print(r["value"], r["ms_per_step"])'; }
+echo "side=0: $(DGM_SIDE_STREAM=0 b)"
+for m in 1 2 3 1 3; do echo "mode=$m: $(DGM_SIDE_MODE=$m b)"; done
+echo "mode=3 prio-1: $(DGM_SIDE_MODE=3 DGM_SIDE_PRIORITY=-1 b)"
+echo "mode=1 prio-1: $(DGM_SIDE_MODE=1 DGM_SIDE_PRIORITY=-1 b)"

@@ -27,7 +27,7 @@ def test_build_and_exports():
         assert hasattr(lib, name), name
     assert lib.dgm_abi_version() == 1
     names = [lib.dgm_stage_name(i).decode() for i in range(L.STAGE_COUNT)]
-    assert names[0] == "preprocess_fwd" and names[7] == "preprocess_bwd" and names[-1] == "mlp_layer_dw"
+    assert names[0] == "preprocess_fwd" and names[7] == "preprocess_bwd" and names[-2] == "mlp_layer_dw" and names[-1] == "mlp_bwd_pair"
 
 
 def test_state_layout_is_pure_and_aligned():

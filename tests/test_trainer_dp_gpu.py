@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, pkg
 
 
-def make_trainer(rank, world, P=3000, W=160, H=128, n_frames=6, seed=0):
+def make_trainer(rank, world, P=3000, W=160, H=128, n_frames=6, seed=0, **kw):
     syn, S, D, T = pkg("synthetic"), pkg("scene"), pkg("deform"), pkg("trainer")
     dev = torch.device("cuda:0")
     g_np = syn.make_gaussians(P, seed=seed, kind="aniso", extent=0.7)
@@ -33,7 +33,7 @@ def make_trainer(rank, world, P=3000, W=160, H=128, n_frames=6, seed=0):
                 h.weight.mul_(0.05)
                 h.bias.mul_(0.05)
     bg = torch.tensor([1.0, 1.0, 1.0], device=dev)
-    return T.Trainer(g, deform, deform_back, cams, background=bg, rank=rank, world=world, seed=seed)
+    return T.Trainer(g, deform, deform_back, cams, background=bg, rank=rank, world=world, seed=seed, **kw)
 
 
 def snapshot(tr):
@@ -169,3 +169,21 @@ def test_mesh_phase_step_runs_the_dpsr_chain_and_moves_every_network():
         off += n
     assert moved[0] and moved[off] and moved[off + 1], "positions / normals / density threshold did not move"
     assert all(bool(torch.isfinite(p).all()) for p in a.params)
+
+
+@pytest.mark.gpu
+def test_cycle_branch_on_a_second_stream_is_bit_identical():
+    """Trainer(side_stream=True) runs the backward network's forward + backward on a second HIP stream beside the rasterizer
+    and joins the two gradients of the deformation in the main graph: same parameters, bit for bit, as the one-stream step."""
+    snaps, losses = [], []
+    for side in (False, True):
+        tr = make_trainer(0, 1, P=20000, W=320, H=256, side_stream=side)
+        assert (tr.side_stream is not None) == side
+        it = tr.opt.warm_up + 10
+        ls = [float(tr.step(it + s)[0]) for s in range(4)]
+        torch.cuda.synchronize()
+        snaps.append(snapshot(tr))
+        losses.append(ls)
+    assert losses[0] == losses[1], losses
+    for a, b in zip(*snaps):
+        assert torch.equal(a, b)
