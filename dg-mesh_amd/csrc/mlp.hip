@@ -1110,7 +1110,11 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     a.ntiles = nt, a.M = N;
     // G_7 = (dOut Wh) masked by layer 7's ReLU
     a.A = w.Dp, a.Aexp = w.Dexp, a.Bp = w.Wh4b, a.b_inv = w.wsc_hb, a.mask_in = w.mask[7], a.C = G, a.Cexp = Ge;
-    P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8>), CfgG7::LDS, gx, st, a)
+    {   // one K step per tile: nothing to hide the epilogue's barriers under, so two workgroups per CU (104 VGPRs, 54 KB of LDS)
+        static const int mult = [] { const char* e = getenv("DGM_P4_G7_MULT"); return e ? atoi(e) : 2; }();
+        const int g7 = nt < mult * num_cus() ? nt : mult * num_cus();
+        P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8>), CfgG7::LDS, g7, st, a)
+    }
     Dw4Args d;
     memset(&d, 0, sizeof(d));
     d.ntiles = nt, d.tiles_per_chunk = pl.tiles_per_chunk;

@@ -286,7 +286,8 @@ class Trainer:
         if delta is not None:
             from .glue import cycle_loss
             lean = {"lean": True} if self.render_fn is S.render else {}
-            if self.side_stream is not None:
+            mesh_on = self.mesh is not None and iteration >= opt.dpsr_iter
+            if self.side_stream is not None and not mesh_on:  # (mesh phase: measured slower with it, 49 vs 58 it/s at cfg2)
                 # The cycle branch (the backward network, 1.3 ms of HBM- / power-bound GEMMs at cfg2) depends on the deformation
                 # only, not on the rasterizer (1 ms of VALU-bound blending and latency-bound binning): build it on a second
                 # stream.  Autograd runs every node's backward on its forward's stream and orders the two gradients of `delta`
