@@ -383,8 +383,9 @@ def main():
             for i in range(5):
                 tr.step(it0 + i)
             n1 = 60
-            o_dt, o_st, _, _ = timed(n1, it0 + 5)
+            o_dt, o_st, o_bl, _ = timed(n1, it0 + 5)
             one_stream = {"value": n1 / o_dt, "unit": "it/s", "ms_per_step": 1e3 * o_dt / n1, "steps": n1,
+                          "host_ms_per_step": {"blocked_on_gpu": round(1e3 * o_bl / n1, 3), "busy": round(1e3 * (o_dt - o_bl) / n1, 3)},
                           "avg_ms": {k: round(v[0], 5) for k, v in o_st.items()}}
         finally:
             tr.side_stream = keep
