@@ -1196,6 +1196,8 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
             Ge = Gne, Gne = te;
         }
     }
+    // (tried: the previous layer's partial tiles summed by the GEMM workgroups of the next paired launch, before their weight
+    // prologue: the launch grows by 9 us (87 -> 96), six launches, while this reduction only shrinks 87 -> 52 us: a net loss)
     // (tried: each layer's reduction on a side stream under the next layer's launch -- its small workgroups do fit beside a
     // resident pair workgroup -- 265 vs 274 it/s: slower, the pair kernel's HBM-bound half gets the competition)
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
