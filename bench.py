@@ -378,7 +378,7 @@ def main():
     # committed rocprofv3 / PMC passes of single kernels correspond to; N = 1, a short extra region
     one_stream = None
     if world == 1 and getattr(tr, "side_stream", None) is not None and not args.no_extras:
-        keep, tr.side_stream = tr.side_stream, None
+        tr.set_streams(1)
         try:
             for i in range(5):
                 tr.step(it0 + i)
@@ -388,7 +388,7 @@ def main():
                           "host_ms_per_step": {"blocked_on_gpu": round(1e3 * o_bl / n1, 3), "busy": round(1e3 * (o_dt - o_bl) / n1, 3)},
                           "avg_ms": {k: round(v[0], 5) for k, v in o_st.items()}}
         finally:
-            tr.side_stream = keep
+            tr.set_streams(2)
 
     trained = None
     if rank == 0 and world == 1 and not args.no_extras and args.phase == "gs":

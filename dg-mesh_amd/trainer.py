@@ -85,6 +85,22 @@ class FlatGradBucket:
 _PERM_CACHE = {}
 
 
+class _JoinGrad(torch.autograd.Function):
+    """Identity on `x`; backward adds the gradient a backward pass on another stream left in `leaf.grad`, after making this
+    stream wait for `ready` (an event recorded behind that pass)."""
+
+    @staticmethod
+    def forward(ctx, x, leaf, ready):
+        ctx.leaf, ctx.ready = leaf, ready
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gx):
+        torch.cuda.current_stream().wait_event(ctx.ready)
+        extra, ctx.leaf.grad = ctx.leaf.grad, None
+        return (gx + extra if extra is not None else gx), None, None
+
+
 def frame_schedule(n_frames, step, rank, world, seed=0):
     """Index of the camera rank `rank` renders at `step`: a shared-seed shuffle per epoch, strided by rank."""
     per_epoch = max(n_frames // world, 1)
@@ -172,8 +188,7 @@ class Trainer:
         # second stream for the cycle branch (loss_terms); None = the DGM_SIDE_STREAM environment variable (default on)
         if side_stream is None:
             side_stream = os.environ.get("DGM_SIDE_STREAM", "1") == "1"
-        prio = int(os.environ.get("DGM_SIDE_PRIORITY", "0"))
-        self.side_stream = torch.cuda.Stream(device=dev, priority=prio) if side_stream and dev.type == "cuda" else None
+        self.set_streams(2 if side_stream and dev.type == "cuda" else 1)
         self._bind_parameters()
         # normal samples of densify_and_split: one generator per rank, seeded alike, advanced in lockstep
         self.densify_generator = None
@@ -183,6 +198,34 @@ class Trainer:
         self.time_interval = 1.0 / max(len(cameras), 1)
         from .deform import get_linear_noise_func
         self.smooth_term = get_linear_noise_func(lr_init=0.1, lr_final=1e-15, lr_delay_mult=0.01, max_steps=20000)
+
+    def set_streams(self, n):
+        """1: everything on the current stream.  2: the cycle branch (backward network) on a second HIP stream beside the
+        rasterizer (loss_terms).  With one rank, no mesh phase and the fused Adam, 2 also turns on the DEFERRED mode: the
+        backward network's BACKWARD pass produces parameter gradients only (its input is detached), so nothing in the step
+        waits for it but its own Adam update -- it is issued last, on the second stream, with an Adam launch of its own, and
+        runs under the deformation network's backward pass and the next step's forward pass; the cycle loss's own backward
+        (one small kernel) hands the deformation's gradient to the main graph through an event (_JoinGrad)."""
+        dev = self.g.get_xyz.device
+        if n == 2 and dev.type != "cuda":
+            raise ValueError("a second stream needs a GPU")
+        if n == 2 and getattr(self, "side_stream", None) is None:
+            self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("DGM_SIDE_PRIORITY", "0")))
+        elif n != 2:
+            if getattr(self, "side_stream", None) is not None:
+                torch.cuda.current_stream().wait_stream(self.side_stream)
+            self.side_stream = None
+        self._deferred = None
+        self.side_defer = (self.side_stream is not None and self.world == 1 and self.mesh is None and self.multi_adam is not None
+                           and self.fused_glue and os.environ.get("DGM_SIDE_DEFER", "1") == "1")
+        self.multi_adam_side = None
+        if self.multi_adam is not None:
+            from .optim import MultiAdam
+            if self.side_defer:
+                self.multi_adam = MultiAdam([self.g.optimizer, self.deform.optimizer])
+                self.multi_adam_side = MultiAdam([self.deform_back.optimizer])
+            else:
+                self.multi_adam = MultiAdam(self.optimizers)
 
     def _bind_parameters(self):
         """(Re)collect the parameters that receive gradients and (re)build the flat gradient bucket; called at start and
@@ -287,7 +330,29 @@ class Trainer:
             from .glue import cycle_loss
             lean = {"lean": True} if self.render_fn is S.render else {}
             mesh_on = self.mesh is not None and iteration >= opt.dpsr_iter
-            if self.side_stream is not None and not mesh_on:  # (mesh phase: measured slower with it, 49 vs 58 it/s at cfg2)
+            if self.side_defer:
+                cur, side = torch.cuda.current_stream(), self.side_stream
+                means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
+                t_back = self.time_input(cam, N, iteration)
+                delta_c = delta.detach().requires_grad_(True)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    back = self.deform_back.step_raw(means, t_back)
+                    back_c = back.detach().requires_grad_(True)
+                    cyc = cycle_loss(delta_c, back_c)
+                    cyc.backward()  # (the loss terms are summed with weight 1)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                    self._deferred = (back, back_c.grad)
+                    cyc = cyc.detach()
+                    cyc.record_stream(cur)         # (made on the side stream, read on this one)
+                    delta_c.grad.record_stream(cur)
+                    means.record_stream(side)      # (and the other way round)
+                    delta_c.record_stream(side)
+                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof,
+                                     delta=_JoinGrad.apply(delta, delta_c, ready), **lean)
+                losses["cycle_loss"] = cyc  # (value only: its gradient is already out)
+            elif self.side_stream is not None and not mesh_on:  # (mesh phase: measured slower with it, 49 vs 58 it/s at cfg2)
                 # The cycle branch (the backward network, 1.3 ms of HBM- / power-bound GEMMs at cfg2) depends on the deformation
                 # only, not on the rasterizer (1 ms of VALU-bound blending and latency-bound binning): build it on a second
                 # stream.  Autograd runs every node's backward on its forward's stream and orders the two gradients of `delta`
@@ -426,6 +491,12 @@ class Trainer:
             self.bucket.all_reduce(self.group)
         if self.multi_adam is not None:
             self.multi_adam.step(grads)
+            if self._deferred is not None:  # the backward network's backward pass and update, last and on the second stream
+                back, g_back = self._deferred
+                self._deferred = None
+                with torch.cuda.stream(self.side_stream):
+                    back.backward(g_back)
+                    self.multi_adam_side.step()
         else:
             for o in self.optimizers:
                 o.step()

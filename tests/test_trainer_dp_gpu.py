@@ -70,7 +70,7 @@ def test_dp2_pack_mode_on_gpu():
     for a, b in zip(r0, r1):
         assert torch.equal(a, b)                               # replicas stay bit-identical
     # one rank, gradients of the same two frames summed by hand, then the same one-launch Adam
-    tr = make_trainer(0, 1)
+    tr = make_trainer(0, 1, side_stream=False)  # (driven by hand below: one stream, one Adam launch for everything)
     it = tr.opt.warm_up + 10
     n = len(tr.cameras)
     for s in range(2):
