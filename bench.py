@@ -374,21 +374,24 @@ def main():
         finally:
             L.lib().dgm_mlp_set_gemm(prev)
 
-    # the same step with the cycle branch on the main stream (no kernels running side by side): the kernel durations the
-    # committed rocprofv3 / PMC passes of single kernels correspond to; N = 1, a short extra region
+    # the same step with everything on one stream (no kernels running side by side): the kernel durations the committed
+    # rocprofv3 / PMC passes of single kernels correspond to.  N = 1; a fresh process (DGM_SIDE_STREAM=0), because a trainer
+    # switched back to one stream after using two was seen to stall ~1.3 ms per step in its Adam launch in two runs out of three.
     one_stream = None
     if world == 1 and getattr(tr, "side_stream", None) is not None and not args.no_extras:
-        tr.set_streams(1)
+        import subprocess
+        env = dict(os.environ, DGM_SIDE_STREAM="0", DGM_BENCH_STEADY_STEPS="0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "60", "--warmup", "10", "--no-extras", "--no-cpu-baseline",
+               "--workload", WORKLOAD, "--mlp", mlp_impl]
         try:
-            for i in range(5):
-                tr.step(it0 + i)
-            n1 = 60
-            o_dt, o_st, o_bl, _ = timed(n1, it0 + 5)
-            one_stream = {"value": n1 / o_dt, "unit": "it/s", "ms_per_step": 1e3 * o_dt / n1, "steps": n1,
-                          "host_ms_per_step": {"blocked_on_gpu": round(1e3 * o_bl / n1, 3), "busy": round(1e3 * (o_dt - o_bl) / n1, 3)},
-                          "avg_ms": {k: round(v[0], 5) for k, v in o_st.items()}}
-        finally:
-            tr.set_streams(2)
+            torch.cuda.synchronize()
+            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+            o = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+            one_stream = {"value": o["value"], "unit": "it/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                          "host_ms_per_step": o["host_ms_per_step"],
+                          "avg_ms": {k: v["avg_ms"] for k, v in o["kernels"].items()}}
+        except Exception as ex:  # an extra must never take the headline down
+            one_stream = {"error": str(ex), "avg_ms": {}}
 
     trained = None
     if rank == 0 and world == 1 and not args.no_extras and args.phase == "gs":
@@ -476,7 +479,7 @@ def main():
                                         "split once by the producer, 3 MFMAs per product" if planes else
                                         "f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
                                         if f16x3 else "bf16x6: 3 bf16 planes, 6 MFMAs per product")})
-            if one_stream is not None and one_stream["avg_ms"].get(best, 0) > 0:
+            if one_stream is not None and one_stream.get("avg_ms", {}).get(best, 0) > 0:
                 # the same kernel with nothing beside it (in the timed region the backward network's launches share the chip
                 # with the rasterizer's: shorter step, longer launches)
                 ms1 = one_stream["avg_ms"][best]

@@ -188,7 +188,9 @@ class Trainer:
         # second stream for the cycle branch (loss_terms); None = the DGM_SIDE_STREAM environment variable (default on)
         if side_stream is None:
             side_stream = os.environ.get("DGM_SIDE_STREAM", "1") == "1"
-        self.set_streams(2 if side_stream and dev.type == "cuda" else 1)
+        # (trainers with a mesh phase stay on one stream: nothing gained there -- 51.7 vs 49.2 it/s at cfg2, box noise -- and
+        # steps that go back to one stream after a second one was in use were seen to stall in the Adam launch)
+        self.set_streams(2 if side_stream and dev.type == "cuda" and mesh is None else 1)
         self._bind_parameters()
         # normal samples of densify_and_split: one generator per rank, seeded alike, advanced in lockstep
         self.densify_generator = None
@@ -313,7 +315,10 @@ class Trainer:
             t = t + torch.randn(1, 1, device=t.device) * self.time_interval * self.smooth_term(iteration)
         return t.expand(N, -1)
 
-    def loss_terms(self, cam, iteration):
+    def loss_terms(self, cam, iteration, defer=False):
+        """The iteration's loss terms and the render package.  `defer` (step() passes it in the deferred mode, see set_streams):
+        the backward network's backward pass is NOT part of the returned graph -- it waits in `self._deferred` for step() to
+        issue it; by default the graph is complete."""
         g, opt = self.g, self.opt
         delta = None
         if iteration < opt.warm_up:
@@ -329,8 +334,7 @@ class Trainer:
         if delta is not None:
             from .glue import cycle_loss
             lean = {"lean": True} if self.render_fn is S.render else {}
-            mesh_on = self.mesh is not None and iteration >= opt.dpsr_iter
-            if self.side_defer:
+            if defer and self.side_defer:
                 cur, side = torch.cuda.current_stream(), self.side_stream
                 means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
                 t_back = self.time_input(cam, N, iteration)
@@ -352,7 +356,7 @@ class Trainer:
                 pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof,
                                      delta=_JoinGrad.apply(delta, delta_c, ready), **lean)
                 losses["cycle_loss"] = cyc  # (value only: its gradient is already out)
-            elif self.side_stream is not None and not mesh_on:  # (mesh phase: measured slower with it, 49 vs 58 it/s at cfg2)
+            elif self.side_stream is not None:
                 # The cycle branch (the backward network, 1.3 ms of HBM- / power-bound GEMMs at cfg2) depends on the deformation
                 # only, not on the rasterizer (1 ms of VALU-bound blending and latency-bound binning): build it on a second
                 # stream.  Autograd runs every node's backward on its forward's stream and orders the two gradients of `delta`
@@ -460,7 +464,7 @@ class Trainer:
                 p.grad = None
         else:
             self.bucket.zero()
-        losses, pkg = self.loss_terms(cam, iteration)
+        losses, pkg = self.loss_terms(cam, iteration, defer=self.side_defer)
         terms = list(losses.values())
         loss = terms[0]
         for t in terms[1:]:  # (not sum(): its 0 + ... start is one more launch)
