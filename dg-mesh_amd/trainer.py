@@ -229,6 +229,14 @@ class Trainer:
             else:
                 self.multi_adam = MultiAdam(self.optimizers)
 
+    def join(self):
+        """Makes the current stream wait for everything step() left on the second stream.  In the deferred mode the backward
+        network's parameter update of the LAST step may still be in flight when step() returns: call this (or
+        torch.cuda.synchronize()) before reading `deform_back`'s parameters or optimizer state on another stream --
+        evaluation, checkpoints (DeformModel.save_weights synchronizes by itself)."""
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+
     def _bind_parameters(self):
         """(Re)collect the parameters that receive gradients and (re)build the flat gradient bucket; called at start and
         after every change of the Gaussian set (densify / prune / opacity reset replace Parameter objects)."""
