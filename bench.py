@@ -305,6 +305,7 @@ def main():
 
     for i in range(10):  # allocator / code-object / clock priming (untimed, not part of the W warm-up steps requested below)
         tr.step(it0)
+    tr.freeze_gc()  # (a full cyclic-GC pass costs ~80 ms here: keep the set-up's 267 k objects out of later collections)
     for i in range(args.warmup):
         tr.step(it0 + i)
     RZ = importlib.import_module("dg-mesh_amd.rasterizer")
@@ -376,8 +377,8 @@ def main():
             L.lib().dgm_mlp_set_gemm(prev)
 
     # the same step with everything on one stream (no kernels running side by side): the kernel durations the committed
-    # rocprofv3 / PMC passes of single kernels correspond to.  N = 1; a fresh process (DGM_SIDE_STREAM=0), because a trainer
-    # switched back to one stream after using two was seen to stall ~1.3 ms per step in its Adam launch in two runs out of three.
+    # rocprofv3 / PMC passes of single kernels correspond to.  N = 1; a fresh process (DGM_SIDE_STREAM=0) with its own priming
+    # and warm-up, the configuration the one-stream profiles were taken in.
     one_stream = None
     if world == 1 and getattr(tr, "side_stream", None) is not None and not args.no_extras:
         import subprocess

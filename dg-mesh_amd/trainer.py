@@ -188,8 +188,7 @@ class Trainer:
         # second stream for the cycle branch (loss_terms); None = the DGM_SIDE_STREAM environment variable (default on)
         if side_stream is None:
             side_stream = os.environ.get("DGM_SIDE_STREAM", "1") == "1"
-        # (trainers with a mesh phase stay on one stream: nothing gained there -- 51.7 vs 49.2 it/s at cfg2, box noise -- and
-        # steps that go back to one stream after a second one was in use were seen to stall in the Adam launch)
+        # (trainers with a mesh phase stay on one stream: nothing gained there -- 51.7 vs 49.2 it/s at cfg2, box noise)
         self.set_streams(2 if side_stream and dev.type == "cuda" and mesh is None else 1)
         self._bind_parameters()
         # normal samples of densify_and_split: one generator per rank, seeded alike, advanced in lockstep
@@ -228,6 +227,17 @@ class Trainer:
                 self.multi_adam_side = MultiAdam([self.deform_back.optimizer])
             else:
                 self.multi_adam = MultiAdam(self.optimizers)
+
+    @staticmethod
+    def freeze_gc():
+        """Call once after set-up, before a long run of step().  A full pass of Python's cyclic collector walks every tracked
+        object of the process -- 267 k with torch imported: ~80 ms, measured -- and a training loop allocates enough containers
+        to trigger one every few hundred steps (25 steps' worth of time; one landing in a 60-step timed region turned 275 it/s
+        into 200).  `gc.freeze()` moves everything alive now into the permanent generation: later collections only look at
+        what the loop itself creates."""
+        import gc
+        gc.collect()
+        gc.freeze()
 
     def join(self):
         """Makes the current stream wait for everything step() left on the second stream.  In the deferred mode the backward
