@@ -202,11 +202,12 @@ class Trainer:
 
     def set_streams(self, n):
         """1: everything on the current stream.  2: the cycle branch (backward network) on a second HIP stream beside the
-        rasterizer (loss_terms).  With one rank, no mesh phase and the fused Adam, 2 also turns on the DEFERRED mode: the
+        rasterizer (loss_terms).  With no mesh phase and the fused Adam, 2 also turns on the DEFERRED mode: the
         backward network's BACKWARD pass produces parameter gradients only (its input is detached), so nothing in the step
         waits for it but its own Adam update -- it is issued last, on the second stream, with an Adam launch of its own, and
         runs under the deformation network's backward pass and the next step's forward pass; the cycle loss's own backward
-        (one small kernel) hands the deformation's gradient to the main graph through an event (_JoinGrad)."""
+        (one small kernel) hands the deformation's gradient to the main graph through an event (_JoinGrad).  With N > 1 ranks the
+        backward network's gradients travel in a bucket of their own, all-reduced on the second stream before that Adam launch."""
         dev = self.g.get_xyz.device
         if n == 2 and dev.type != "cuda":
             raise ValueError("a second stream needs a GPU")
@@ -217,8 +218,9 @@ class Trainer:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
             self.side_stream = None
         self._deferred = None
-        self.side_defer = (self.side_stream is not None and self.world == 1 and self.mesh is None and self.multi_adam is not None
-                           and self.fused_glue and os.environ.get("DGM_SIDE_DEFER", "1") == "1")
+        self.side_defer = (self.side_stream is not None and self.mesh is None and self.multi_adam is not None
+                           and self.fused_glue and os.environ.get("DGM_SIDE_DEFER", "1") == "1"
+                           and (self.world == 1 or self.overlap))
         self.multi_adam_side = None
         if self.multi_adam is not None:
             from .optim import MultiAdam
@@ -227,6 +229,8 @@ class Trainer:
                 self.multi_adam_side = MultiAdam([self.deform_back.optimizer])
             else:
                 self.multi_adam = MultiAdam(self.optimizers)
+        if hasattr(self, "params"):  # (called again after construction: the buckets follow the mode)
+            self._bind_parameters()
 
     @staticmethod
     def freeze_gc():
@@ -274,8 +278,13 @@ class Trainer:
         if self.pack and self.world > 1 and self.overlap:
             gp = [p for p in params[:6] if p.requires_grad]
             mp = [p for p in params[6:] if p.requires_grad]
+            sp = []
+            if self.side_defer:  # the backward network's gradients: a bucket of their own, exchanged on the second stream
+                back_ids = {id(p) for p in deform_back.net.parameters()}
+                sp = [p for p in mp if id(p) in back_ids]
+                mp = [p for p in mp if id(p) not in back_ids]
             self._early = {"g": FlatGradBucket(gp, attach=False), "m": FlatGradBucket(mp, attach=False), "left": 0, "work": None,
-                           "views": None, "n": len(gp), "armed": False}
+                           "views": None, "n": len(gp), "armed": False, "s": FlatGradBucket(sp, attach=False) if sp else None}
             for p in gp:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._gaussian_grad_ready))
 
@@ -317,7 +326,7 @@ class Trainer:
     def bucket_bytes(self):
         """Byte sizes of the flat buckets one step all-reduces (Gaussian bucket, MLP bucket; or the single bucket)."""
         if self._early is not None:
-            return [self._early["g"].nbytes(), self._early["m"].nbytes()]
+            return [self._early[k].nbytes() for k in ("g", "m", "s") if self._early.get(k) is not None]
         return [self.bucket.nbytes()] if self.bucket is not None else [self.grad_bytes()]
 
     def grad_bytes(self):
@@ -518,7 +527,11 @@ class Trainer:
                 self._deferred = None
                 with torch.cuda.stream(self.side_stream):
                     back.backward(g_back)
-                    self.multi_adam_side.step()
+                    sg = None
+                    if self.world > 1:  # (same order of collectives on every rank: Gaussian bucket, MLP bucket, this one)
+                        sg = self._early["s"].pack()
+                        dist.all_reduce(self._early["s"].flat, op=dist.ReduceOp.SUM, group=self.group)
+                    self.multi_adam_side.step(sg)
         else:
             for o in self.optimizers:
                 o.step()

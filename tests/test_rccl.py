@@ -82,7 +82,7 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert out.returncode == 0, out.stdout[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
-    assert rec["allreduce"]["world_size_observed"] == 2 and len(rec["allreduce"]["bucket_bytes"]) == 2
+    assert rec["allreduce"]["world_size_observed"] == 2 and len(rec["allreduce"]["bucket_bytes"]) in (2, 3)
 
 
 def test_bench_gpus_flag_refuses_too_few_devices():
