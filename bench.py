@@ -303,8 +303,16 @@ def main():
     if args.phase == "mesh":     # every network on, positions unfrozen (it >= dpsr_iter + max(normal_warm_up, 2000))
         it0 = tr.opt.dpsr_iter + tr.opt.normal_deform_delay + 1000
 
-    for i in range(10):  # allocator / code-object / clock priming (untimed, not part of the W warm-up steps requested below)
+    calibration = None
+    if getattr(tr, "_auto", None) is not None:
+        # allocator / code-object / clock priming (untimed, not part of the W warm-up steps requested below), used to pick the
+        # faster of the two-stream and the one-stream form of the step for this workload (Trainer.calibrate_streams)
         tr.step(it0)
+        tr.calibrate_streams(it0)
+        calibration = dict(tr.stream_calibration)
+    else:
+        for i in range(10):  # allocator / code-object / clock priming (untimed)
+            tr.step(it0)
     tr.freeze_gc()  # (a full cyclic-GC pass costs ~80 ms here: keep the set-up's 267 k objects out of later collections)
     for i in range(args.warmup):
         tr.step(it0 + i)
@@ -535,6 +543,8 @@ def main():
         if one_stream is not None:
             out["one_stream"] = one_stream
         out["streams"] = 2 if getattr(tr, "side_stream", None) is not None else 1
+        if calibration is not None:
+            out["stream_calibration"] = {k: round(v, 4) for k, v in calibration.items()}
         if trained is not None:
             out["roofline_render_bwd_trained"] = trained
         fv = frac_valu_from_profiles()

@@ -1140,7 +1140,10 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     for (int l = 7; l >= 0; l--) {
         const int Kp = layer_kp(p, l);
         const bool paired = n_dw > 0 && l >= 1;
-        const int chunks_l = paired ? n_dw : pl.chunks;
+        // (the paired launch gives each of its n_dw weight-gradient workgroups ceil(nt / n_dw) tiles: the last few may get none
+        // and write no partial tile -- the reduction must only read the ones that exist)
+        const int tpc_pair = paired ? (nt + n_dw - 1) / n_dw : 0;
+        const int chunks_l = paired ? (nt + tpc_pair - 1) / tpc_pair : pl.chunks;
         if (l >= 1) {  // backward data: G_{l-1} = (G_l W_l) masked, into the other buffer
             a.A = G, a.Aexp = Ge, a.Bp = w.Wd3[l], a.b_inv = w.wsc_d[l], a.mask_in = w.mask[l - 1], a.C = Gn, a.Cexp = Gne;
         }
@@ -1159,7 +1162,7 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
             P4_LAUNCH((mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>), CfgDwE::LDS, pl.chunks, st, d)
         }
         if (l != 0) {
-            d.tiles_per_chunk = paired ? (nt + n_dw - 1) / n_dw : pl.tiles_per_chunk;
+            d.tiles_per_chunk = paired ? tpc_pair : pl.tiles_per_chunk;
             d.X = (const unsigned char*)w.Y[l - 1], d.Xexp = w.Yexp[l - 1];
             d.partial = part_trunk, d.chunk_stride = stride_trunk;
             d.partial_db = l == sk ? nullptr : w.partial_db_l[l];  // (the skip layer's bias gradient came with its embedding half)
@@ -1185,7 +1188,7 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
         }
         if (paired && l == sk) {  // two reduction jobs: embedding rows (with the bias gradient), trunk rows
             add_job(l, pl.chunks, 8 * pl.chunks, MLP_EMB, layer_in(p, l), 0, part_emb, w.partial_db_l[l], dW[l], db[l]);
-            add_job(8, n_dw, 0, MLP_W, layer_in(p, l), p->emb_dim, part_trunk, nullptr, dW[l], nullptr);
+            add_job(8, chunks_l, 0, MLP_W, layer_in(p, l), p->emb_dim, part_trunk, nullptr, dW[l], nullptr);
             rb.n_jobs = 9;
         } else
             add_job(l, chunks_l, 8 * chunks_l, Kp, layer_in(p, l), 0, w.partial_l[l], w.partial_db_l[l], dW[l], db[l]);

@@ -186,8 +186,15 @@ class Trainer:
             self.multi_adam = MultiAdam(self.optimizers)
         self.pack = self.multi_adam is not None
         # second stream for the cycle branch (loss_terms); None = the DGM_SIDE_STREAM environment variable (default on)
+        # side_stream: True / False, or None = the DGM_SIDE_STREAM environment variable: "1", "0" or "auto" (default): start with
+        # two streams and let the first steps that run the networks time both forms (calibrate_streams below) -- the second
+        # stream pays at cfg2 / cfg3 / cfg5 (+6..8 %) and costs at the host-bound cfg1 (-19 %) and at cfg4 (-12 %)
+        self._auto = None
         if side_stream is None:
-            side_stream = os.environ.get("DGM_SIDE_STREAM", "1") == "1"
+            env = os.environ.get("DGM_SIDE_STREAM", "auto")
+            side_stream = env != "0"
+            if env == "auto" and dev.type == "cuda" and mesh is None:
+                self._auto = {"P": 0}
         # (trainers with a mesh phase stay on one stream: nothing gained there -- 51.7 vs 49.2 it/s at cfg2, box noise)
         self.set_streams(2 if side_stream and dev.type == "cuda" and mesh is None else 1)
         self._bind_parameters()
@@ -231,6 +238,46 @@ class Trainer:
                 self.multi_adam = MultiAdam(self.optimizers)
         if hasattr(self, "params"):  # (called again after construction: the buckets follow the mode)
             self._bind_parameters()
+
+    def calibrate_streams(self, iteration, steps=6, warm=4):
+        """Times real training steps with two streams and with one -- after `warm` untimed steps, two blocks of `steps`, the
+        faster block counts -- and keeps the faster form; the parameters are bit-identical in both forms, so these are ordinary
+        steps of the run, except that both forms are given the SAME frames (the per-frame cost varies by 2x and more along an
+        orbit): the frame schedule is rewound once.  Every rank of a data-parallel run takes the same decision (the slowest
+        rank's times).  Returns the seconds per step (two streams, one stream).  bench.py calls it during its untimed priming;
+        a Trainer left on "auto" calls it at the first step that runs the networks, and again when the number of Gaussians has
+        changed by more than 1.5x."""
+        import time
+        out, first = [], self.step_count
+        busy, self._calibrating = getattr(self, "_calibrating", False), True
+        try:
+            for n in (2, 1):
+                self.set_streams(n)
+                self.step_count = first
+                for i in range(warm):
+                    self.step(iteration)
+                best = None
+                for blk in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(steps):
+                        self.step(iteration)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / steps
+                    best = dt if best is None else min(best, dt)
+                out.append(best)
+        finally:
+            self._calibrating = busy
+        t_two, t_one = out
+        if self.world > 1:
+            t = torch.tensor([t_two, t_one], dtype=torch.float64, device=self.g.get_xyz.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            t_two, t_one = float(t[0]), float(t[1])
+        self.set_streams(2 if t_two < t_one else 1)
+        self.stream_calibration = {"two_streams_ms": 1e3 * t_two, "one_stream_ms": 1e3 * t_one, "P": int(self.g.get_xyz.shape[0])}
+        if self._auto is not None:
+            self._auto["P"] = int(self.g.get_xyz.shape[0])
+        return t_two, t_one
 
     @staticmethod
     def freeze_gc():
@@ -477,6 +524,10 @@ class Trainer:
 
     def step(self, iteration):
         g = self.g
+        if self._auto is not None and iteration >= self.opt.warm_up and not getattr(self, "_calibrating", False):
+            P_now = int(g.get_xyz.shape[0])
+            if max(P_now, self._auto["P"]) > 1.5 * min(P_now, self._auto["P"]):  # (first such step: P = 0 on record)
+                self.calibrate_streams(iteration)  # (32 ordinary steps at this iteration's learning rates, then this one)
         g.update_learning_rate(iteration)
         self.deform.update_learning_rate(iteration)
         self.deform_back.update_learning_rate(iteration)
@@ -492,6 +543,9 @@ class Trainer:
         else:
             self.bucket.zero()
         losses, pkg = self.loss_terms(cam, iteration, defer=self.side_defer)
+        # deferred mode: the cycle term was computed on the second stream and carries no graph; this stream has only waited for
+        # it once the backward pass is through _JoinGrad -- it joins the reported value there, not the sum that is differentiated
+        late = losses.pop("cycle_loss") if self._deferred is not None else None
         terms = list(losses.values())
         loss = terms[0]
         for t in terms[1:]:  # (not sum(): its 0 + ... start is one more launch)
@@ -538,4 +592,4 @@ class Trainer:
         if rebound:
             self._bind_parameters()
         self.step_count += 1
-        return loss.detach(), pkg
+        return (loss.detach() if late is None else late + loss.detach()), pkg

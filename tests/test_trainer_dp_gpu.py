@@ -187,3 +187,34 @@ def test_cycle_branch_on_a_second_stream_is_bit_identical():
     assert losses[0] == losses[1], losses
     for a, b in zip(*snaps):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_stream_calibration_picks_a_form_and_keeps_the_parameters():
+    """Trainer on "auto" (DGM_SIDE_STREAM=auto, the default outside the tests): the first step that runs the networks times both
+    forms on the same frames and keeps one; a second trainer given the same number of steps in a fixed form ends with the same
+    parameters bit for bit (the calibration's steps are ordinary training steps on a once-rewound frame schedule)."""
+    old = os.environ.get("DGM_SIDE_STREAM")
+    os.environ["DGM_SIDE_STREAM"] = "auto"
+    try:
+        a = make_trainer(0, 1, P=20000, W=320, H=256)
+    finally:
+        os.environ["DGM_SIDE_STREAM"] = old if old is not None else "1"
+    assert a._auto is not None
+    it = a.opt.warm_up + 10
+    a.step(it)
+    cal = a.stream_calibration
+    assert cal["two_streams_ms"] > 0 and cal["one_stream_ms"] > 0 and cal["P"] == 20000
+    assert (a.side_stream is not None) == (cal["two_streams_ms"] < cal["one_stream_ms"])
+    n_cal = a.step_count - 1                      # steps the calibration took (both passes, same frames)
+    assert n_cal == 16
+    b = make_trainer(0, 1, P=20000, W=320, H=256, side_stream=False)
+    for k in (0, 1):                              # replay: the calibration ran frames [0, 16) twice, then the step itself
+        b.step_count = 0
+        for s in range(16):
+            b.step(it)
+    b.step_count = 16
+    b.step(it)
+    torch.cuda.synchronize()
+    for x, y in zip(snapshot(a), snapshot(b)):
+        assert torch.equal(x, y)
