@@ -196,7 +196,9 @@ class Trainer:
             if env == "auto" and dev.type == "cuda" and mesh is None:
                 self._auto = {"P": 0}
         # (trainers with a mesh phase stay on one stream: nothing gained there -- 51.7 vs 49.2 it/s at cfg2, box noise)
-        self.set_streams(2 if side_stream and dev.type == "cuda" and mesh is None else 1)
+        self.set_streams(2 if side_stream and dev.type == "cuda" else 1)
+        if self.side_stream is None:
+            self._auto = None  # (nothing to choose between)
         self._bind_parameters()
         # normal samples of densify_and_split: one generator per rank, seeded alike, advanced in lockstep
         self.densify_generator = None
@@ -208,26 +210,31 @@ class Trainer:
         self.smooth_term = get_linear_noise_func(lr_init=0.1, lr_final=1e-15, lr_delay_mult=0.01, max_steps=20000)
 
     def set_streams(self, n):
-        """1: everything on the current stream.  2: the cycle branch (backward network) on a second HIP stream beside the
-        rasterizer (loss_terms).  With no mesh phase and the fused Adam, 2 also turns on the DEFERRED mode: the
-        backward network's BACKWARD pass produces parameter gradients only (its input is detached), so nothing in the step
-        waits for it but its own Adam update -- it is issued last, on the second stream, with an Adam launch of its own, and
-        runs under the deformation network's backward pass and the next step's forward pass; the cycle loss's own backward
-        (one small kernel) hands the deformation's gradient to the main graph through an event (_JoinGrad).  With N > 1 ranks the
-        backward network's gradients travel in a bucket of their own, all-reduced on the second stream before that Adam launch."""
+        """1: everything on the current stream.  2: the cycle branch (the backward network) on a second HIP stream:
+
+            main stream : deform fwd | rasterizer fwd, loss |<wait>| rasterizer bwd, deform bwd, Adam (Gaussians, deform) |
+            side stream :            | deform_back bwd of the LAST step, its Adam, deform_back fwd, cycle loss + its bwd | idle |
+
+        The backward network's BACKWARD pass produces parameter gradients only (its input is detached), so nothing in the step
+        waits for it but its own Adam update: it is issued last, with an Adam launch of its own, and runs under the NEXT step's
+        forward pass; the cycle loss's own backward (one small kernel) hands the deformation's gradient to the main graph
+        (_JoinGrad).  The second stream is kept IDLE while this stream runs its backward pass: two-stream forms that let MLP
+        kernels share the chip with the rasterizer's backward were not bit-reproducible -- this one is.
+        With N > 1 ranks the backward network's gradients travel in a bucket of their own, all-reduced on the second stream
+        before that Adam launch.  Needs the fused Adam and glue, no mesh phase, and (N > 1) the overlap buckets; a trainer
+        without them stays on one stream."""
         dev = self.g.get_xyz.device
         if n == 2 and dev.type != "cuda":
             raise ValueError("a second stream needs a GPU")
-        if n == 2 and getattr(self, "side_stream", None) is None:
-            self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("DGM_SIDE_PRIORITY", "0")))
-        elif n != 2:
+        able = (self.mesh is None and self.multi_adam is not None and self.fused_glue and (self.world == 1 or self.overlap))
+        if n == 2 and able and getattr(self, "side_stream", None) is None:
+            self.side_stream = torch.cuda.Stream(device=dev)
+        elif n != 2 or not able:
             if getattr(self, "side_stream", None) is not None:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
             self.side_stream = None
         self._deferred = None
-        self.side_defer = (self.side_stream is not None and self.mesh is None and self.multi_adam is not None
-                           and self.fused_glue and os.environ.get("DGM_SIDE_DEFER", "1") == "1"
-                           and (self.world == 1 or self.overlap))
+        self.side_defer = self.side_stream is not None
         self.multi_adam_side = None
         if self.multi_adam is not None:
             from .optim import MultiAdam
@@ -430,26 +437,6 @@ class Trainer:
                 pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof,
                                      delta=_JoinGrad.apply(delta, delta_c, ready), **lean)
                 losses["cycle_loss"] = cyc  # (value only: its gradient is already out)
-            elif self.side_stream is not None:
-                # The cycle branch (the backward network, 1.3 ms of HBM- / power-bound GEMMs at cfg2) depends on the deformation
-                # only, not on the rasterizer (1 ms of VALU-bound blending and latency-bound binning): build it on a second
-                # stream.  Autograd runs every node's backward on its forward's stream and orders the two gradients of `delta`
-                # itself, so the branch's backward overlaps the rasterizer's as well.  (Also built BEFORE the render branch:
-                # see the data-parallel case below.)  Measured: 278 -> 296 it/s at cfg2; cutting the branch's graph at
-                # `delta` and differentiating it at once on the side stream -- no wait for the root's gradient -- was slower
-                # (292: its launches delay the rasterizer's on the host).
-                cur, side = torch.cuda.current_stream(), self.side_stream
-                means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
-                t_back = self.time_input(cam, N, iteration)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    back = self.deform_back.step_raw(means, t_back)
-                    cyc = cycle_loss(delta, back)
-                    cyc.record_stream(cur)       # (made on the side stream, read on this one)
-                    means.record_stream(side)    # (and the other way round)
-                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta, **lean)
-                cur.wait_stream(side)
-                losses["cycle_loss"] = cyc
             elif self.world > 1 and self._early is not None:
                 # Data parallel with the early Gaussian-bucket all-reduce: build the cycle branch BEFORE the render branch.
                 # Autograd runs later-built branches first, so the rasterizer's backward -- after which the Gaussian
@@ -550,6 +537,10 @@ class Trainer:
         loss = terms[0]
         for t in terms[1:]:  # (not sum(): its 0 + ... start is one more launch)
             loss = loss + t
+        if self._deferred is not None:
+            # nothing of the second stream may run beside the rasterizer's backward pass (see set_streams): its forward part
+            # (backward network forward, cycle loss and its backward) ends here; it usually has, this stream's forward is longer
+            torch.cuda.current_stream().wait_stream(self.side_stream)
         if self._early is not None:
             self._early.update(left=self._early["n"], work=None, views=None, armed=True)
         loss.backward()
@@ -579,6 +570,8 @@ class Trainer:
             if self._deferred is not None:  # the backward network's backward pass and update, last and on the second stream
                 back, g_back = self._deferred
                 self._deferred = None
+                # (the second stream stays idle while this one runs its backward pass and Adam launch -- see set_streams)
+                self.side_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.side_stream):
                     back.backward(g_back)
                     sg = None

@@ -17,19 +17,66 @@ it = tr.opt.warm_up + 10
 names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"] + [f"deform.{n}" for n, _ in tr.deform.net.named_parameters()] + \
         [f"deform_back.{n}" for n, _ in tr.deform_back.net.named_parameters()]
 params = tr.g.parameters()[:6] + list(tr.deform.net.parameters()) + list(tr.deform_back.net.parameters())
+from conftest import pkg as _pkg0
+_G = _pkg0("glue")
+_orig_apply = _G.gaussian_apply
+_cap = {}
+
+
+def _capturing_apply(*a):
+    outs = _orig_apply(*a)
+    for n_, o_ in zip(("means3D", "scales", "rotations", "opacity"), outs):
+        o_.retain_grad()
+        _cap[n_] = o_
+    return outs
+
+
+_G.gaussian_apply = _capturing_apply   # (scene.render imports it at call time): the rasterizer's own gradient outputs
+ADV = int(os.environ.get("CHECK_ADVANCE", "0"))      # train this many steps first (the state the stress runs deviate in)
+for s_ in range(ADV):
+    tr.step(it + s_)
+it += ADV
+MLPNOISE = os.environ.get("CHECK_NOISE") == "mlp"   # the second stream runs another network's forward + backward passes
+NOISE = os.environ.get("CHECK_NOISE") == "1"          # a second stream kept busy with unrelated GEMMs of varying size
+noise_stream = torch.cuda.Stream() if NOISE else None
+na = torch.randn(4096, 4096, device="cuda") if NOISE else None
+cam_i = ADV % len(tr.cameras)
+if MLPNOISE:
+    from conftest import pkg as _pkg
+    D = _pkg("deform")
+    noise_stream = torch.cuda.Stream()
+    noise_net = D.DeformModelNormal(is_blender=True, model_name="noise", device=torch.device("cuda:0"), trunk_impl="hip")
+    noise_x = torch.randn(P, 3, device="cuda")
+    noise_t = torch.tensor([[0.3]], device="cuda").expand(P, -1)
 ref = None
 bad = {}
 for k in range(K):
+    if NOISE:
+        with torch.cuda.stream(noise_stream):
+            for j in range(3 + 2 * k):
+                n = 512 * (1 + (j + k) % 7)
+                na[:n, :n] @ na[:n, :n]
     for p in tr.params:
         p.grad = None
-    losses, pkg = tr.loss_terms(tr.cameras[1], it)
+    if MLPNOISE:
+        torch.cuda.synchronize()
+        noise_stream.wait_stream(torch.cuda.current_stream())
+    losses, pkg = tr.loss_terms(tr.cameras[cam_i], it)
     total = None
     for v in losses.values():
         total = v if total is None else total + v
+    if MLPNOISE:  # queued now: runs beside the backward pass below
+        with torch.cuda.stream(noise_stream):
+            for j in range(1 + k % 3):
+                o = noise_net.step_raw(noise_x, noise_t)
+                o.sum().backward()
     total.backward()
     torch.cuda.synchronize()
     cur = {"image": pkg["render"].detach().clone(), "radii": pkg["radii"].clone()}
     cur.update({"loss." + n: v.detach().clone() for n, v in losses.items()})
+    cur.update({"rast.d_" + n: v.grad.clone() for n, v in _cap.items() if v.grad is not None})
+    if pkg.get("viewspace_points") is not None and pkg["viewspace_points"].grad is not None:
+        cur["rast.d_mean2D"] = pkg["viewspace_points"].grad.clone()
     cur.update({"grad." + n: (p.grad.clone() if p.grad is not None else torch.zeros(1)) for n, p in zip(names, params)})
     if ref is None:
         ref = cur
