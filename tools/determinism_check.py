@@ -58,6 +58,13 @@ for k in range(K):
                 na[:n, :n] @ na[:n, :n]
     for p in tr.params:
         p.grad = None
+    if os.environ.get("CHECK_POISON") == "1":  # every free block holds NaN patterns: a stale read shows as NaN, not as 1e-8
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        junk = [torch.full((1 << 30,), 255, dtype=torch.uint8, device="cuda") for _ in range(6)]
+        junk += [torch.full((8 << 20,), 255, dtype=torch.uint8, device="cuda") for _ in range(48)]
+        junk += [torch.full((1 << 20,), 255, dtype=torch.uint8, device="cuda") for _ in range(64)]
+        del junk
     if MLPNOISE:
         torch.cuda.synchronize()
         noise_stream.wait_stream(torch.cuda.current_stream())
@@ -84,6 +91,8 @@ for k in range(K):
     for n in cur:
         if not torch.equal(cur[n], ref[n]):
             d = (cur[n].float() - ref[n].float()).abs()
+            if not torch.isfinite(cur[n].float()).all():
+                bad.setdefault(n + " NON-FINITE", []).append((k, int((~torch.isfinite(cur[n].float())).sum())))
             bad.setdefault(n, []).append((k, float(d.max()), int((d > 0).sum())))
 print(f"P={P} {W}x{Hh}, {K} evaluations: {'all bit-identical' if not bad else 'DIFFERENCES'}")
 for n, v in list(bad.items())[:20]:
