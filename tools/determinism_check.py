@@ -93,7 +93,14 @@ for k in range(K):
             d = (cur[n].float() - ref[n].float()).abs()
             if not torch.isfinite(cur[n].float()).all():
                 bad.setdefault(n + " NON-FINITE", []).append((k, int((~torch.isfinite(cur[n].float())).sum())))
-            bad.setdefault(n, []).append((k, float(d.max()), int((d > 0).sum())))
+            idx = (d > 0).nonzero()[:8].tolist()
+            rel = float((d / (ref[n].float().abs() + 1e-30))[d > 0].max())
+            bad.setdefault(n, []).append((k, float(d.max()), int((d > 0).sum()), "rel %.2e" % rel, idx))
+            if n.startswith("rast.") and len(bad[n]) == 1:
+                gids = sorted({i[0] for i in (d > 0).nonzero().tolist()})[:6]
+                for gi in gids:
+                    print(f"      [{n}] gaussian {gi}: ref {ref[n][gi].tolist()} now {cur[n][gi].tolist()} | radii {int(cur['radii'][gi])}"
+                          f" d_mean2D {ref['rast.d_mean2D'][gi].tolist()} d_opacity {ref['rast.d_opacity'][gi].tolist()}")
 print(f"P={P} {W}x{Hh}, {K} evaluations: {'all bit-identical' if not bad else 'DIFFERENCES'}")
 for n, v in list(bad.items())[:20]:
-    print("  ", n, v[:3])
+    print("  ", n, v[:2])
