@@ -26,7 +26,9 @@ carries the RCCL world size observed and the all-reduce of the step's gradient b
 region at N = 1.  `roofline_render_bwd_trained` = the rasterizer backward on SURVEY.md section 8(d)'s trained-like scene (the
 distribution on which north_star's HBM target is approachable), measured here with the library's stage timers; `frac_valu` of
 the blend kernels comes from the committed PMC pass (VALU lane operations / 78.6 T lane-op/s).
-`streams` = 2: the cycle branch (backward network) is issued on a second HIP stream beside the rasterizer (Trainer.side_stream);
+`streams` = 1 by default.  `two_streams` (informational, a fresh process with DGM_SIDE_STREAM=1): the backward network's branch on a
+second HIP stream -- faster, not the default because that step is not bit-reproducible here.  When a run
+itself uses two streams (`streams` = 2: DGM_SIDE_STREAM=1 or auto),
 a launch's event-to-event time then includes waiting for CUs the other stream holds, so `roofline` / `kernels` / `roofline_render_bwd`
 come from the same bench region run with ONE stream in a fresh process (`one_stream`: its it/s), and the in-region numbers of the
 headline run are kept as `roofline_two_streams` / `kernels_two_streams` / `roofline_render_bwd_two_streams`.
@@ -403,6 +405,23 @@ def main():
         except Exception as ex:  # an extra must never take the headline down
             one_stream = {"error": str(ex)}
 
+    # informational: the same workload with the backward network's branch on a second HIP stream (DGM_SIDE_STREAM=1, a fresh
+    # process) -- faster, NOT the default: with two queues active the step is not bit-reproducible
+    two_streams = None
+    if world == 1 and getattr(tr, "side_stream", None) is None and not args.no_extras and args.phase == "gs":
+        import subprocess
+        env = dict(os.environ, DGM_SIDE_STREAM="1", DGM_BENCH_STEADY_STEPS="0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "10", "--no-extras", "--no-cpu-baseline",
+               "--workload", WORKLOAD, "--mlp", mlp_impl]
+        try:
+            torch.cuda.synchronize()
+            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+            o = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+            two_streams = {"value": o["value"], "unit": "it/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                           "note": "DGM_SIDE_STREAM=1; not the default: two-stream steps are not bit-reproducible on this platform"}
+        except Exception as ex:  # an extra must never take the headline down
+            two_streams = {"error": str(ex)}
+
     trained = None
     if rank == 0 and world == 1 and not args.no_extras and args.phase == "gs":
         try:
@@ -542,6 +561,8 @@ def main():
             out["roofline_render_bwd"] = one_stream.pop("roofline_render_bwd")
         if one_stream is not None:
             out["one_stream"] = one_stream
+        if two_streams is not None:
+            out["two_streams"] = two_streams
         out["streams"] = 2 if getattr(tr, "side_stream", None) is not None else 1
         if calibration is not None:
             out["stream_calibration"] = {k: round(v, 4) for k, v in calibration.items()}

@@ -186,12 +186,15 @@ class Trainer:
             self.multi_adam = MultiAdam(self.optimizers)
         self.pack = self.multi_adam is not None
         # second stream for the cycle branch (loss_terms); None = the DGM_SIDE_STREAM environment variable (default on)
-        # side_stream: True / False, or None = the DGM_SIDE_STREAM environment variable: "1", "0" or "auto" (default): start with
-        # two streams and let the first steps that run the networks time both forms (calibrate_streams below) -- the second
-        # stream pays at cfg2 / cfg3 / cfg5 (+6..8 %) and costs at the host-bound cfg1 (-19 %) and at cfg4 (-12 %)
+        # side_stream: True / False, or None = the DGM_SIDE_STREAM environment variable: "0" (default), "1", or "auto" (start
+        # with two streams and let the first steps that run the networks time both forms, calibrate_streams below -- the second
+        # stream pays at cfg2 / cfg3 / cfg5 (+4..7 %) and costs at the host-bound cfg1 and at cfg4).  ONE stream is the default:
+        # with this library's MLP kernels running beside them on a second queue, the rasterizer's kernels were seen to read stale
+        # cache lines of arrays written by earlier kernels of their own stream -- rarely, within the parity
+        # tolerance, but not reproducibly; the one-stream step is bit-reproducible.
         self._auto = None
         if side_stream is None:
-            env = os.environ.get("DGM_SIDE_STREAM", "auto")
+            env = os.environ.get("DGM_SIDE_STREAM", "0")
             side_stream = env != "0"
             if env == "auto" and dev.type == "cuda" and mesh is None:
                 self._auto = {"P": 0}

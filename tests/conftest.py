@@ -7,9 +7,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# Trainers built by the tests run a fixed form of the step (two streams on a GPU) unless a test says otherwise: the default "auto"
-# inserts timed calibration steps, which hand-driven comparisons do not replay (test_trainer_dp_gpu.py covers it explicitly)
-os.environ.setdefault("DGM_SIDE_STREAM", "1")
+# Trainers built by the tests run the product's default form of the step (one stream) unless a test says otherwise
+os.environ.setdefault("DGM_SIDE_STREAM", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -75,7 +75,7 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     one-GPU box through DGM_BENCH_SHARE_GPU=1 (both ranks on cuda:0, gloo), which runs the same self-launch, rendezvous,
     barrier / max-over-ranks timing and reporting code as the RCCL configuration; cfg1 keeps it short."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(DGM_BENCH_SHARE_GPU="1", DGM_BENCH_STEADY_STEPS="0")
+    env.update(DGM_BENCH_SHARE_GPU="1", DGM_BENCH_STEADY_STEPS="0", DGM_SIDE_STREAM="1")  # (two streams: the three-bucket exchange)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload",
                           "cfg1", "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=900)

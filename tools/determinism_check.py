@@ -53,9 +53,10 @@ bad = {}
 for k in range(K):
     if NOISE:
         with torch.cuda.stream(noise_stream):
-            for j in range(3 + 2 * k):
+            for j in range(6 + k % 5):
                 n = 512 * (1 + (j + k) % 7)
-                na[:n, :n] @ na[:n, :n]
+                nb = na[:n, :n] @ na[:n, :n]
+                nb = torch.relu(nb) * 0.5 + na[:n, :n]          # (GEMMs and streaming elementwise kernels)
     for p in tr.params:
         p.grad = None
     if os.environ.get("CHECK_POISON") == "1":  # every free block holds NaN patterns: a stale read shows as NaN, not as 1e-8
@@ -68,11 +69,19 @@ for k in range(K):
     if MLPNOISE:
         torch.cuda.synchronize()
         noise_stream.wait_stream(torch.cuda.current_stream())
+    NOISE_FWD = os.environ.get("CHECK_NOISE_AT") == "fwd"
+    if MLPNOISE and NOISE_FWD:  # the other stream's passes run beside the FORWARD pass only (joined before the backward pass)
+        with torch.cuda.stream(noise_stream):
+            for j in range(1 + k % 3):
+                o = noise_net.step_raw(noise_x, noise_t)
+                o.sum().backward()
     losses, pkg = tr.loss_terms(tr.cameras[cam_i], it)
+    if MLPNOISE and NOISE_FWD:
+        torch.cuda.current_stream().wait_stream(noise_stream)
     total = None
     for v in losses.values():
         total = v if total is None else total + v
-    if MLPNOISE:  # queued now: runs beside the backward pass below
+    if MLPNOISE and not NOISE_FWD:  # queued now: runs beside the backward pass below
         with torch.cuda.stream(noise_stream):
             for j in range(1 + k % 3):
                 o = noise_net.step_raw(noise_x, noise_t)
