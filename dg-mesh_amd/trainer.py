@@ -185,7 +185,6 @@ class Trainer:
             from .optim import MultiAdam
             self.multi_adam = MultiAdam(self.optimizers)
         self.pack = self.multi_adam is not None
-        # second stream for the cycle branch (loss_terms); None = the DGM_SIDE_STREAM environment variable (default on)
         # side_stream: True / False, or None = the DGM_SIDE_STREAM environment variable: "0" (default), "1", or "auto" (start
         # with two streams and let the first steps that run the networks time both forms, calibrate_streams below -- the second
         # stream pays at cfg2 / cfg3 / cfg5 (+4..7 %) and costs at the host-bound cfg1 and at cfg4).  ONE stream is the default:
@@ -222,7 +221,9 @@ class Trainer:
         waits for it but its own Adam update: it is issued last, with an Adam launch of its own, and runs under the NEXT step's
         forward pass; the cycle loss's own backward (one small kernel) hands the deformation's gradient to the main graph
         (_JoinGrad).  The second stream is kept IDLE while this stream runs its backward pass: two-stream forms that let MLP
-        kernels share the chip with the rasterizer's backward were not bit-reproducible -- this one is.
+        kernels share the chip with the rasterizer's backward were not bit-reproducible; this one was in
+        every run of the trainer, but the same stale reads can be provoked beside the forward pass too, so two streams are an
+        OPT-IN (DGM_SIDE_STREAM=1 / side_stream=True), not the default.
         With N > 1 ranks the backward network's gradients travel in a bucket of their own, all-reduced on the second stream
         before that Adam launch.  Needs the fused Adam and glue, no mesh phase, and (N > 1) the overlap buckets; a trainer
         without them stays on one stream."""
