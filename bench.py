@@ -26,12 +26,6 @@ carries the RCCL world size observed and the all-reduce of the step's gradient b
 region at N = 1.  `roofline_render_bwd_trained` = the rasterizer backward on SURVEY.md section 8(d)'s trained-like scene (the
 distribution on which north_star's HBM target is approachable), measured here with the library's stage timers; `frac_valu` of
 the blend kernels comes from the committed PMC pass (VALU lane operations / 78.6 T lane-op/s).
-`streams` = 1 by default.  `two_streams` (informational, a fresh process with DGM_SIDE_STREAM=1): the backward network's branch on a
-second HIP stream -- faster, not the default because that step is not bit-reproducible here.  When a run
-itself uses two streams (`streams` = 2: DGM_SIDE_STREAM=1 or auto),
-a launch's event-to-event time then includes waiting for CUs the other stream holds, so `roofline` / `kernels` / `roofline_render_bwd`
-come from the same bench region run with ONE stream in a fresh process (`one_stream`: its it/s), and the in-region numbers of the
-headline run are kept as `roofline_two_streams` / `kernels_two_streams` / `roofline_render_bwd_two_streams`.
 `cpu_baseline` = the same step on the host cores (oracle rasterizer + PyTorch-CPU MLPs; a port of the reference's CPU
 path, not the reference itself, which is not on the GPU box), rank 0 at N=1 only, on a bounded sample.
 """
@@ -305,16 +299,8 @@ def main():
     if args.phase == "mesh":     # every network on, positions unfrozen (it >= dpsr_iter + max(normal_warm_up, 2000))
         it0 = tr.opt.dpsr_iter + tr.opt.normal_deform_delay + 1000
 
-    calibration = None
-    if getattr(tr, "_auto", None) is not None:
-        # allocator / code-object / clock priming (untimed, not part of the W warm-up steps requested below), used to pick the
-        # faster of the two-stream and the one-stream form of the step for this workload (Trainer.calibrate_streams)
+    for i in range(10):  # allocator / code-object / clock priming (untimed)
         tr.step(it0)
-        tr.calibrate_streams(it0)
-        calibration = dict(tr.stream_calibration)
-    else:
-        for i in range(10):  # allocator / code-object / clock priming (untimed)
-            tr.step(it0)
     tr.freeze_gc()  # (a full cyclic-GC pass costs ~80 ms here: keep the set-up's 267 k objects out of later collections)
     for i in range(args.warmup):
         tr.step(it0 + i)
@@ -385,42 +371,6 @@ def main():
                         "arithmetic": "v_mfma_f32_32x32x2_f32 (native fp32 MFMA) in every MLP GEMM"}
         finally:
             L.lib().dgm_mlp_set_gemm(prev)
-
-    # the same step with everything on one stream (no kernels running side by side): the kernel durations the committed
-    # rocprofv3 / PMC passes of single kernels correspond to.  N = 1; a fresh process (DGM_SIDE_STREAM=0) with its own priming
-    # and warm-up, the configuration the one-stream profiles were taken in.
-    one_stream = None
-    if world == 1 and getattr(tr, "side_stream", None) is not None and not args.no_extras:
-        import subprocess
-        env = dict(os.environ, DGM_SIDE_STREAM="0", DGM_BENCH_STEADY_STEPS="0")
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "60", "--warmup", "10", "--no-extras", "--no-cpu-baseline",
-               "--workload", WORKLOAD, "--mlp", mlp_impl]
-        try:
-            torch.cuda.synchronize()
-            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
-            o = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-            one_stream = {"value": o["value"], "unit": "it/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"],
-                          "host_ms_per_step": o["host_ms_per_step"], "roofline": o["roofline"], "kernels": o["kernels"],
-                          "roofline_render_bwd": o["roofline_render_bwd"]}
-        except Exception as ex:  # an extra must never take the headline down
-            one_stream = {"error": str(ex)}
-
-    # informational: the same workload with the backward network's branch on a second HIP stream (DGM_SIDE_STREAM=1, a fresh
-    # process) -- faster, NOT the default: with two queues active the step is not bit-reproducible
-    two_streams = None
-    if world == 1 and getattr(tr, "side_stream", None) is None and not args.no_extras and args.phase == "gs":
-        import subprocess
-        env = dict(os.environ, DGM_SIDE_STREAM="1", DGM_BENCH_STEADY_STEPS="0")
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "10", "--no-extras", "--no-cpu-baseline",
-               "--workload", WORKLOAD, "--mlp", mlp_impl]
-        try:
-            torch.cuda.synchronize()
-            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
-            o = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-            two_streams = {"value": o["value"], "unit": "it/s", "ms_per_step": o["ms_per_step"], "steps": o["steps"],
-                           "note": "DGM_SIDE_STREAM=1; not the default: two-stream steps are not bit-reproducible on this platform"}
-        except Exception as ex:  # an extra must never take the headline down
-            two_streams = {"error": str(ex)}
 
     trained = None
     if rank == 0 and world == 1 and not args.no_extras and args.phase == "gs":
@@ -546,26 +496,6 @@ def main():
             out["allreduce"] = allreduce
         if f32_mode is not None:
             out["mlp_f32_mode"] = f32_mode
-        if one_stream is not None and "roofline" in one_stream:
-            # Kernel durations are a property of the kernel only when nothing shares the chip: with two streams a launch's
-            # event-to-event time includes waiting for CUs the other stream's workgroups hold (a 25 us kernel shows 330 us
-            # behind render_bwd3).  `roofline` / `kernels` are therefore the ONE-STREAM process's (same workload, same
-            # bench.py region, hipEvents on the launch stream; rocprofv3 summary of that configuration:
-            # profiles/r03_d_bench_kernel_stats.txt); the in-region numbers of the two-stream headline run follow as
-            # `roofline_two_streams` / `kernels_two_streams` (rocprofv3: profiles/r03_e_bench_kernel_stats.txt).
-            out["roofline_two_streams"], out["kernels_two_streams"] = out["roofline"], out["kernels"]
-            out["roofline"] = dict(one_stream.pop("roofline"), regime="one stream (fresh process, DGM_SIDE_STREAM=0): "
-                                   f"{one_stream['value']:.1f} it/s; the headline value runs two streams")
-            out["kernels"] = one_stream.pop("kernels")
-            out["roofline_render_bwd_two_streams"] = out["roofline_render_bwd"]
-            out["roofline_render_bwd"] = one_stream.pop("roofline_render_bwd")
-        if one_stream is not None:
-            out["one_stream"] = one_stream
-        if two_streams is not None:
-            out["two_streams"] = two_streams
-        out["streams"] = 2 if getattr(tr, "side_stream", None) is not None else 1
-        if calibration is not None:
-            out["stream_calibration"] = {k: round(v, 4) for k, v in calibration.items()}
         if trained is not None:
             out["roofline_render_bwd_trained"] = trained
         fv = frac_valu_from_profiles()

@@ -278,8 +278,6 @@ class _ModelWrapper:
     def save_weights(self, model_path, iteration):
         out = os.path.join(model_path, f"{self.model_name}/iteration_{iteration}")
         os.makedirs(out, exist_ok=True)
-        if next(self.net.parameters()).is_cuda:
-            torch.cuda.synchronize()  # (a Trainer may still be updating this network on its second stream, Trainer.join())
         torch.save(self.net.state_dict(), os.path.join(out, f"{self.model_name}.pth"))
 
     def load_weights(self, model_path, iteration=-1):

@@ -21,11 +21,14 @@ Data parallelism (absent in the reference; BASELINE.json north_star): one proces
 ranks, every rank holds a full replica of the Gaussians and MLPs.
   * all ranks derive the same shuffled camera order from a shared seed; rank r takes entries r, r+W, ... so one
     step consumes W frames (effective batch W);
-  * gradients are exchanged as flat fp32 buckets over RCCL/xGMI: on the GPU two of them -- the Gaussian gradients
-    (25 MB at P=100k), whose all-reduce is launched from an autograd hook as soon as they are final and runs under the
-    two MLP backward passes, and the MLP gradients (4 MB) after backward; on the CPU test path one.  On the GPU the step's fresh gradients are packed into the
-    bucket by one multi-tensor copy ("pack" mode; no per-tensor accumulate kernels, no zero-fill), on the CPU test
-    path every .grad is a view into the bucket ("views" mode, which also supports accumulating several frames);
+  * gradients are exchanged as flat fp32 buckets over RCCL/xGMI.  Default: ONE bucket (Gaussian + MLP gradients, 35 MB at
+    P=100k) all-reduced after backward on the current stream.  `overlap=True` (opt-in): two buckets -- the Gaussian gradients
+    (25 MB), whose all-reduce is launched from an autograd hook as soon as they are final and runs (on RCCL's own queue) under
+    the two MLP backward passes, and the MLP gradients after backward.  It is opt-in until a multi-GPU run has shown the
+    replicas bit-identical with it on (bench.py prints `replicas_identical` for both forms); DESIGN.md section 6.
+    On the GPU the step's fresh gradients are packed into the bucket by one multi-tensor copy ("pack" mode; no per-tensor
+    accumulate kernels, no zero-fill), on the CPU test path every .grad is a view into the bucket ("views" mode, which also
+    supports accumulating several frames);
   * every rank then applies the identical Adam update, so replicas stay bit-identical without broadcasting.  On the
     GPU that is one kernel for all three optimizers (optim.MultiAdam).
   W ranks x 1 frame is therefore equivalent to 1 rank accumulating the same W frames before stepping.
@@ -85,22 +88,6 @@ class FlatGradBucket:
 _PERM_CACHE = {}
 
 
-class _JoinGrad(torch.autograd.Function):
-    """Identity on `x`; backward adds the gradient a backward pass on another stream left in `leaf.grad`, after making this
-    stream wait for `ready` (an event recorded behind that pass)."""
-
-    @staticmethod
-    def forward(ctx, x, leaf, ready):
-        ctx.leaf, ctx.ready = leaf, ready
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, gx):
-        torch.cuda.current_stream().wait_event(ctx.ready)
-        extra, ctx.leaf.grad = ctx.leaf.grad, None
-        return (gx + extra if extra is not None else gx), None, None
-
-
 def frame_schedule(n_frames, step, rank, world, seed=0):
     """Index of the camera rank `rank` renders at `step`: a shared-seed shuffle per epoch, strided by rank."""
     per_epoch = max(n_frames // world, 1)
@@ -147,8 +134,7 @@ class Trainer:
     def __init__(self, gaussians, deform, deform_back, cameras, opt=None, pipe=None, background=None,
                  is_blender=True, is_6dof=False, rank=0, world=1, seed=0, render_fn=None, fused_adam=None,
                  process_group=None, fused_loss=True, fused_glue=None, track_stats=True, densify=False,
-                 cameras_extent=1.0, prune_threshold=0.005, white_background=True, overlap=True, mesh=None,
-                 side_stream=None):
+                 cameras_extent=1.0, prune_threshold=0.005, white_background=True, overlap=False, mesh=None):
         self.g, self.deform, self.deform_back = gaussians, deform, deform_back
         self.mesh = mesh
         self.cameras = cameras
@@ -185,22 +171,6 @@ class Trainer:
             from .optim import MultiAdam
             self.multi_adam = MultiAdam(self.optimizers)
         self.pack = self.multi_adam is not None
-        # side_stream: True / False, or None = the DGM_SIDE_STREAM environment variable: "0" (default), "1", or "auto" (start
-        # with two streams and let the first steps that run the networks time both forms, calibrate_streams below -- the second
-        # stream pays at cfg2 / cfg3 / cfg5 (+4..7 %) and costs at the host-bound cfg1 and at cfg4).  ONE stream is the default:
-        # with this library's MLP kernels running beside them on a second queue, the rasterizer's kernels were seen to read stale
-        # cache lines of arrays written by earlier kernels of their own stream -- rarely, within the parity
-        # tolerance, but not reproducibly; the one-stream step is bit-reproducible.
-        self._auto = None
-        if side_stream is None:
-            env = os.environ.get("DGM_SIDE_STREAM", "0")
-            side_stream = env != "0"
-            if env == "auto" and dev.type == "cuda" and mesh is None:
-                self._auto = {"P": 0}
-        # (trainers with a mesh phase stay on one stream: nothing gained there -- 51.7 vs 49.2 it/s at cfg2, box noise)
-        self.set_streams(2 if side_stream and dev.type == "cuda" else 1)
-        if self.side_stream is None:
-            self._auto = None  # (nothing to choose between)
         self._bind_parameters()
         # normal samples of densify_and_split: one generator per rank, seeded alike, advanced in lockstep
         self.densify_generator = None
@@ -210,85 +180,6 @@ class Trainer:
         self.time_interval = 1.0 / max(len(cameras), 1)
         from .deform import get_linear_noise_func
         self.smooth_term = get_linear_noise_func(lr_init=0.1, lr_final=1e-15, lr_delay_mult=0.01, max_steps=20000)
-
-    def set_streams(self, n):
-        """1: everything on the current stream.  2: the cycle branch (the backward network) on a second HIP stream:
-
-            main stream : deform fwd | rasterizer fwd, loss |<wait>| rasterizer bwd, deform bwd, Adam (Gaussians, deform) |
-            side stream :            | deform_back bwd of the LAST step, its Adam, deform_back fwd, cycle loss + its bwd | idle |
-
-        The backward network's BACKWARD pass produces parameter gradients only (its input is detached), so nothing in the step
-        waits for it but its own Adam update: it is issued last, with an Adam launch of its own, and runs under the NEXT step's
-        forward pass; the cycle loss's own backward (one small kernel) hands the deformation's gradient to the main graph
-        (_JoinGrad).  The second stream is kept IDLE while this stream runs its backward pass: two-stream forms that let MLP
-        kernels share the chip with the rasterizer's backward were not bit-reproducible; this one was in
-        every run of the trainer, but the same stale reads can be provoked beside the forward pass too, so two streams are an
-        OPT-IN (DGM_SIDE_STREAM=1 / side_stream=True), not the default.
-        With N > 1 ranks the backward network's gradients travel in a bucket of their own, all-reduced on the second stream
-        before that Adam launch.  Needs the fused Adam and glue, no mesh phase, and (N > 1) the overlap buckets; a trainer
-        without them stays on one stream."""
-        dev = self.g.get_xyz.device
-        if n == 2 and dev.type != "cuda":
-            raise ValueError("a second stream needs a GPU")
-        able = (self.mesh is None and self.multi_adam is not None and self.fused_glue and (self.world == 1 or self.overlap))
-        if n == 2 and able and getattr(self, "side_stream", None) is None:
-            self.side_stream = torch.cuda.Stream(device=dev)
-        elif n != 2 or not able:
-            if getattr(self, "side_stream", None) is not None:
-                torch.cuda.current_stream().wait_stream(self.side_stream)
-            self.side_stream = None
-        self._deferred = None
-        self.side_defer = self.side_stream is not None
-        self.multi_adam_side = None
-        if self.multi_adam is not None:
-            from .optim import MultiAdam
-            if self.side_defer:
-                self.multi_adam = MultiAdam([self.g.optimizer, self.deform.optimizer])
-                self.multi_adam_side = MultiAdam([self.deform_back.optimizer])
-            else:
-                self.multi_adam = MultiAdam(self.optimizers)
-        if hasattr(self, "params"):  # (called again after construction: the buckets follow the mode)
-            self._bind_parameters()
-
-    def calibrate_streams(self, iteration, steps=6, warm=4):
-        """Times real training steps with two streams and with one -- after `warm` untimed steps, two blocks of `steps`, the
-        faster block counts -- and keeps the faster form; the parameters are bit-identical in both forms, so these are ordinary
-        steps of the run, except that both forms are given the SAME frames (the per-frame cost varies by 2x and more along an
-        orbit): the frame schedule is rewound once.  Every rank of a data-parallel run takes the same decision (the slowest
-        rank's times).  Returns the seconds per step (two streams, one stream).  bench.py calls it during its untimed priming;
-        a Trainer left on "auto" calls it at the first step that runs the networks, and again when the number of Gaussians has
-        changed by more than 1.5x."""
-        import time
-        out, first = [], self.step_count
-        busy, self._calibrating = getattr(self, "_calibrating", False), True
-        try:
-            for n in (2, 1):
-                self.set_streams(n)
-                self.step_count = first
-                for i in range(warm):
-                    self.step(iteration)
-                best = None
-                for blk in range(2):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for i in range(steps):
-                        self.step(iteration)
-                    torch.cuda.synchronize()
-                    dt = (time.perf_counter() - t0) / steps
-                    best = dt if best is None else min(best, dt)
-                out.append(best)
-        finally:
-            self._calibrating = busy
-        t_two, t_one = out
-        if self.world > 1:
-            t = torch.tensor([t_two, t_one], dtype=torch.float64, device=self.g.get_xyz.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            t_two, t_one = float(t[0]), float(t[1])
-        self.set_streams(2 if t_two < t_one else 1)
-        self.stream_calibration = {"two_streams_ms": 1e3 * t_two, "one_stream_ms": 1e3 * t_one, "P": int(self.g.get_xyz.shape[0])}
-        if self._auto is not None:
-            self._auto["P"] = int(self.g.get_xyz.shape[0])
-        return t_two, t_one
 
     @staticmethod
     def freeze_gc():
@@ -300,14 +191,6 @@ class Trainer:
         import gc
         gc.collect()
         gc.freeze()
-
-    def join(self):
-        """Makes the current stream wait for everything step() left on the second stream.  In the deferred mode the backward
-        network's parameter update of the LAST step may still be in flight when step() returns: call this (or
-        torch.cuda.synchronize()) before reading `deform_back`'s parameters or optimizer state on another stream --
-        evaluation, checkpoints (DeformModel.save_weights synchronizes by itself)."""
-        if self.side_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     def _bind_parameters(self):
         """(Re)collect the parameters that receive gradients and (re)build the flat gradient bucket; called at start and
@@ -336,13 +219,8 @@ class Trainer:
         if self.pack and self.world > 1 and self.overlap:
             gp = [p for p in params[:6] if p.requires_grad]
             mp = [p for p in params[6:] if p.requires_grad]
-            sp = []
-            if self.side_defer:  # the backward network's gradients: a bucket of their own, exchanged on the second stream
-                back_ids = {id(p) for p in deform_back.net.parameters()}
-                sp = [p for p in mp if id(p) in back_ids]
-                mp = [p for p in mp if id(p) not in back_ids]
             self._early = {"g": FlatGradBucket(gp, attach=False), "m": FlatGradBucket(mp, attach=False), "left": 0, "work": None,
-                           "views": None, "n": len(gp), "armed": False, "s": FlatGradBucket(sp, attach=False) if sp else None}
+                           "views": None, "n": len(gp), "armed": False}
             for p in gp:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._gaussian_grad_ready))
 
@@ -384,7 +262,7 @@ class Trainer:
     def bucket_bytes(self):
         """Byte sizes of the flat buckets one step all-reduces (Gaussian bucket, MLP bucket; or the single bucket)."""
         if self._early is not None:
-            return [self._early[k].nbytes() for k in ("g", "m", "s") if self._early.get(k) is not None]
+            return [self._early[k].nbytes() for k in ("g", "m")]
         return [self.bucket.nbytes()] if self.bucket is not None else [self.grad_bytes()]
 
     def grad_bytes(self):
@@ -400,10 +278,8 @@ class Trainer:
             t = t + torch.randn(1, 1, device=t.device) * self.time_interval * self.smooth_term(iteration)
         return t.expand(N, -1)
 
-    def loss_terms(self, cam, iteration, defer=False):
-        """The iteration's loss terms and the render package.  `defer` (step() passes it in the deferred mode, see set_streams):
-        the backward network's backward pass is NOT part of the returned graph -- it waits in `self._deferred` for step() to
-        issue it; by default the graph is complete."""
+    def loss_terms(self, cam, iteration):
+        """The iteration's loss terms and the render package."""
         g, opt = self.g, self.opt
         delta = None
         if iteration < opt.warm_up:
@@ -419,29 +295,7 @@ class Trainer:
         if delta is not None:
             from .glue import cycle_loss
             lean = {"lean": True} if self.render_fn is S.render else {}
-            if defer and self.side_defer:
-                cur, side = torch.cuda.current_stream(), self.side_stream
-                means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
-                t_back = self.time_input(cam, N, iteration)
-                delta_c = delta.detach().requires_grad_(True)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    back = self.deform_back.step_raw(means, t_back)
-                    back_c = back.detach().requires_grad_(True)
-                    cyc = cycle_loss(delta_c, back_c)
-                    cyc.backward()  # (the loss terms are summed with weight 1)
-                    ready = torch.cuda.Event()
-                    ready.record(side)
-                    self._deferred = (back, back_c.grad)
-                    cyc = cyc.detach()
-                    cyc.record_stream(cur)         # (made on the side stream, read on this one)
-                    delta_c.grad.record_stream(cur)
-                    means.record_stream(side)      # (and the other way round)
-                    delta_c.record_stream(side)
-                pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof,
-                                     delta=_JoinGrad.apply(delta, delta_c, ready), **lean)
-                losses["cycle_loss"] = cyc  # (value only: its gradient is already out)
-            elif self.world > 1 and self._early is not None:
+            if self.world > 1 and self._early is not None:
                 # Data parallel with the early Gaussian-bucket all-reduce: build the cycle branch BEFORE the render branch.
                 # Autograd runs later-built branches first, so the rasterizer's backward -- after which the Gaussian
                 # gradients are final and their all-reduce starts -- then precedes BOTH MLP backward passes instead of only
@@ -515,10 +369,6 @@ class Trainer:
 
     def step(self, iteration):
         g = self.g
-        if self._auto is not None and iteration >= self.opt.warm_up and not getattr(self, "_calibrating", False):
-            P_now = int(g.get_xyz.shape[0])
-            if max(P_now, self._auto["P"]) > 1.5 * min(P_now, self._auto["P"]):  # (first such step: P = 0 on record)
-                self.calibrate_streams(iteration)  # (32 ordinary steps at this iteration's learning rates, then this one)
         g.update_learning_rate(iteration)
         self.deform.update_learning_rate(iteration)
         self.deform_back.update_learning_rate(iteration)
@@ -533,18 +383,11 @@ class Trainer:
                 p.grad = None
         else:
             self.bucket.zero()
-        losses, pkg = self.loss_terms(cam, iteration, defer=self.side_defer)
-        # deferred mode: the cycle term was computed on the second stream and carries no graph; this stream has only waited for
-        # it once the backward pass is through _JoinGrad -- it joins the reported value there, not the sum that is differentiated
-        late = losses.pop("cycle_loss") if self._deferred is not None else None
+        losses, pkg = self.loss_terms(cam, iteration)
         terms = list(losses.values())
         loss = terms[0]
         for t in terms[1:]:  # (not sum(): its 0 + ... start is one more launch)
             loss = loss + t
-        if self._deferred is not None:
-            # nothing of the second stream may run beside the rasterizer's backward pass (see set_streams): its forward part
-            # (backward network forward, cycle loss and its backward) ends here; it usually has, this stream's forward is longer
-            torch.cuda.current_stream().wait_stream(self.side_stream)
         if self._early is not None:
             self._early.update(left=self._early["n"], work=None, views=None, armed=True)
         loss.backward()
@@ -571,22 +414,10 @@ class Trainer:
             self.bucket.all_reduce(self.group)
         if self.multi_adam is not None:
             self.multi_adam.step(grads)
-            if self._deferred is not None:  # the backward network's backward pass and update, last and on the second stream
-                back, g_back = self._deferred
-                self._deferred = None
-                # (the second stream stays idle while this one runs its backward pass and Adam launch -- see set_streams)
-                self.side_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.side_stream):
-                    back.backward(g_back)
-                    sg = None
-                    if self.world > 1:  # (same order of collectives on every rank: Gaussian bucket, MLP bucket, this one)
-                        sg = self._early["s"].pack()
-                        dist.all_reduce(self._early["s"].flat, op=dist.ReduceOp.SUM, group=self.group)
-                    self.multi_adam_side.step(sg)
         else:
             for o in self.optimizers:
                 o.step()
         if rebound:
             self._bind_parameters()
         self.step_count += 1
-        return (loss.detach() if late is None else late + loss.detach()), pkg
+        return loss.detach(), pkg

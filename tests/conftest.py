@@ -7,8 +7,6 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# Trainers built by the tests run the product's default form of the step (one stream) unless a test says otherwise
-os.environ.setdefault("DGM_SIDE_STREAM", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

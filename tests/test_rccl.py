@@ -25,7 +25,7 @@ def test_rccl_world1_allreduce_of_the_gradient_bucket():
     assert rec["world"] == 1 and rec["ms"] > 0
 
 
-def _rccl_worker(rank, world, port, out_dir):
+def _rccl_worker(rank, world, port, out_dir, overlap):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -37,10 +37,10 @@ def _rccl_worker(rank, world, port, out_dir):
     real = torch.device
     tdp.torch.device = lambda *a, **k: real("cuda", rank) if a and str(a[0]).startswith("cuda") else real(*a, **k)  # one GPU per rank
     try:
-        tr = tdp.make_trainer(rank, world)
+        tr = tdp.make_trainer(rank, world, overlap=overlap)
     finally:
         tdp.torch.device = real
-    assert tr.pack and tr._early is not None and dist.get_backend() == "nccl" and dist.get_world_size() == world
+    assert tr.pack and (tr._early is not None) == overlap and dist.get_backend() == "nccl" and dist.get_world_size() == world
     it = tr.opt.warm_up + 10
     for s in range(3):
         tr.step(it + s)
@@ -51,9 +51,10 @@ def _rccl_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_rccl_world2_step():
-    """Two ranks, one GPU each, backend nccl (= RCCL over xGMI): three data-parallel train steps with the early Gaussian-bucket
-    all-reduce; the replicas must stay bit-identical.  Skips on boxes with fewer than two GPUs (gpurun's have one; the
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_world2_step(overlap):
+    """Two ranks, one GPU each, backend nccl (= RCCL over xGMI): three data-parallel train steps, with the single bucket after
+    backward (the default) and with the early Gaussian-bucket all-reduce (overlap=True); the replicas must stay bit-identical.  Skips on boxes with fewer than two GPUs (gpurun's have one; the
     multi-rank logic is also covered over gloo by test_trainer_dp*.py)."""
     import tempfile
 
@@ -63,7 +64,7 @@ def test_rccl_world2_step():
         pytest.skip("needs two GPUs")
     with tempfile.TemporaryDirectory() as d:
         port = 29400 + (os.getpid() % 400)
-        mp.start_processes(_rccl_worker, args=(2, port, d), nprocs=2, join=True, start_method="spawn")
+        mp.start_processes(_rccl_worker, args=(2, port + (1 if overlap else 0), d, overlap), nprocs=2, join=True, start_method="spawn")
         r0, r1 = torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
     for a, b in zip(r0, r1):
         assert torch.equal(a, b)
@@ -75,7 +76,7 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     one-GPU box through DGM_BENCH_SHARE_GPU=1 (both ranks on cuda:0, gloo), which runs the same self-launch, rendezvous,
     barrier / max-over-ranks timing and reporting code as the RCCL configuration; cfg1 keeps it short."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(DGM_BENCH_SHARE_GPU="1", DGM_BENCH_STEADY_STEPS="0", DGM_SIDE_STREAM="1")  # (two streams: the three-bucket exchange)
+    env.update(DGM_BENCH_SHARE_GPU="1", DGM_BENCH_STEADY_STEPS="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload",
                           "cfg1", "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=900)

@@ -41,14 +41,14 @@ def snapshot(tr):
     return [p.detach().cpu().clone() for p in ps]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tr = make_trainer(rank, world)
-    assert tr.pack and tr.multi_adam is not None and tr.bucket is not None
+    tr = make_trainer(rank, world, overlap=overlap)
+    assert tr.pack and tr.multi_adam is not None and tr.bucket is not None and (tr._early is not None) == overlap
     it = tr.opt.warm_up + 10
     for s in range(2):
         tr.step(it + s)
@@ -59,18 +59,21 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_dp2_pack_mode_on_gpu():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_dp2_pack_mode_on_gpu(overlap):
+    """overlap=False (the default): one flat bucket after backward.  overlap=True: the Gaussian bucket's all-reduce is launched
+    from an autograd hook under the MLP backward passes, the MLP bucket follows.  Either way the replicas are bit-identical."""
     world = 2
     T = pkg("trainer")
     with tempfile.TemporaryDirectory() as d:
-        port = 29700 + (os.getpid() % 2000)
-        mp.start_processes(_worker, args=(world, port, d), nprocs=world, join=True, start_method="spawn")
+        port = 29700 + (os.getpid() % 2000) + (7 if overlap else 0)
+        mp.start_processes(_worker, args=(world, port, d, overlap), nprocs=world, join=True, start_method="spawn")
         r0 = torch.load(os.path.join(d, "rank0.pt"))
         r1 = torch.load(os.path.join(d, "rank1.pt"))
     for a, b in zip(r0, r1):
         assert torch.equal(a, b)                               # replicas stay bit-identical
     # one rank, gradients of the same two frames summed by hand, then the same one-launch Adam
-    tr = make_trainer(0, 1, side_stream=False)  # (driven by hand below: one stream, one Adam launch for everything)
+    tr = make_trainer(0, 1)  # (driven by hand below)
     it = tr.opt.warm_up + 10
     n = len(tr.cameras)
     for s in range(2):
@@ -169,65 +172,3 @@ def test_mesh_phase_step_runs_the_dpsr_chain_and_moves_every_network():
         off += n
     assert moved[0] and moved[off] and moved[off + 1], "positions / normals / density threshold did not move"
     assert all(bool(torch.isfinite(p).all()) for p in a.params)
-
-
-def _same_up_to_rare_rows(snap_a, snap_b, n_gauss=6, max_rows=2e-3):
-    """Two-stream steps compute the same arithmetic as one-stream steps, but on this platform a kernel running beside another
-    queue's kernels may be served a stale cache line: a handful of Gaussians per step can differ.  Equal =
-    all but a few rows of the per-Gaussian tensors bit-identical, the networks' weights equal to 1e-3 (a logic error moves
-    everything)."""
-    for k, (a, b) in enumerate(zip(snap_a, snap_b)):
-        if k < n_gauss:
-            rows = (a.reshape(a.shape[0], -1) != b.reshape(b.shape[0], -1)).any(dim=1).float().mean().item()
-            assert rows <= max_rows, (k, rows)
-        else:
-            assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), (k, (a - b).abs().max())
-
-
-@pytest.mark.gpu
-def test_cycle_branch_on_a_second_stream_matches_the_one_stream_step():
-    """Trainer(side_stream=True) runs the backward network's forward + backward on a second HIP stream beside the rasterizer
-    and joins the two gradients of the deformation in the main graph: the same arithmetic as the one-stream step (bit for bit
-    in almost every run; see _same_up_to_rare_rows for the exception this platform makes)."""
-    snaps, losses = [], []
-    for side in (False, True):
-        tr = make_trainer(0, 1, P=20000, W=320, H=256, side_stream=side)
-        assert (tr.side_stream is not None) == side
-        it = tr.opt.warm_up + 10
-        ls = [float(tr.step(it + s)[0]) for s in range(4)]
-        torch.cuda.synchronize()
-        snaps.append(snapshot(tr))
-        losses.append(ls)
-    for x, y in zip(*losses):
-        assert abs(x - y) <= 1e-4 * abs(x), losses
-    _same_up_to_rare_rows(*snaps)
-
-
-@pytest.mark.gpu
-def test_stream_calibration_picks_a_form_and_keeps_the_parameters():
-    """Trainer on "auto" (DGM_SIDE_STREAM=auto, the default outside the tests): the first step that runs the networks times both
-    forms on the same frames and keeps one; a second trainer given the same number of steps in a fixed form ends with the same
-    parameters bit for bit (the calibration's steps are ordinary training steps on a once-rewound frame schedule)."""
-    old = os.environ.get("DGM_SIDE_STREAM")
-    os.environ["DGM_SIDE_STREAM"] = "auto"
-    try:
-        a = make_trainer(0, 1, P=20000, W=320, H=256)
-    finally:
-        os.environ["DGM_SIDE_STREAM"] = old if old is not None else "1"
-    assert a._auto is not None
-    it = a.opt.warm_up + 10
-    a.step(it)
-    cal = a.stream_calibration
-    assert cal["two_streams_ms"] > 0 and cal["one_stream_ms"] > 0 and cal["P"] == 20000
-    assert (a.side_stream is not None) == (cal["two_streams_ms"] < cal["one_stream_ms"])
-    n_cal = a.step_count - 1                      # steps the calibration took (both passes, same frames)
-    assert n_cal == 16
-    b = make_trainer(0, 1, P=20000, W=320, H=256, side_stream=False)
-    for k in (0, 1):                              # replay: the calibration ran frames [0, 16) twice, then the step itself
-        b.step_count = 0
-        for s in range(16):
-            b.step(it)
-    b.step_count = 16
-    b.step(it)
-    torch.cuda.synchronize()
-    _same_up_to_rare_rows(snapshot(a), snapshot(b))

@@ -8,11 +8,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["DGM_SIDE_STREAM"] = "0"
 import test_trainer_dp_gpu as H  # noqa: E402
 
 P, W, Hh, K = (int(x) for x in (sys.argv[1:5] + ["60000", "640", "512", "6"][len(sys.argv) - 1:]))
-tr = H.make_trainer(0, 1, P=P, W=W, H=Hh, side_stream=False)
+tr = H.make_trainer(0, 1, P=P, W=W, H=Hh)
 it = tr.opt.warm_up + 10
 names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"] + [f"deform.{n}" for n, _ in tr.deform.net.named_parameters()] + \
         [f"deform_back.{n}" for n, _ in tr.deform_back.net.named_parameters()]

@@ -9,7 +9,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["DGM_SIDE_STREAM"] = "0"
 import test_trainer_dp_gpu as H  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
@@ -26,7 +25,7 @@ def poison(fill):
 
 
 def run(fill):
-    tr = H.make_trainer(0, 1, P=P, W=W, H=Hh, side_stream=False)
+    tr = H.make_trainer(0, 1, P=P, W=W, H=Hh)
     it = tr.opt.warm_up + 10
     names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
     for s in range(steps):
