@@ -333,7 +333,34 @@ def main():
             dt = float(tmax.item())
         return dt, st, blocked, pk
 
+    def exchange_ms(events):
+        """Mean device time of the gradient exchange section of a step (pack, all-reduce(s), wait) on the compute stream."""
+        return sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+
+    if world > 1:
+        tr.exchange_events = []
     elapsed, stages, blocked_s, pkg = timed(args.steps, it0 + args.warmup)
+    dp = None
+    if world > 1:
+        # Self-verification of the data-parallel run: every rank must hold bit-identical parameters and Adam moments after the
+        # timed region (64-bit hash per tensor, all-gathered).  Then the same region with the Gaussian bucket's all-reduce
+        # launched early from an autograd hook (Trainer(overlap=True): RCCL's queue runs beside the MLP backward passes).
+        dp = {"overlap": False, "replicas_identical": bool(tr.replicas_identical()),
+              "exchange_ms_per_step": round(exchange_ms(tr.exchange_events), 4)}
+        tr.overlap = True
+        tr._bind_parameters()
+        for i in range(5):
+            tr.step(it0 + i)
+        tr.exchange_events = []
+        n_ov = max(args.steps, 20)
+        o_dt, _, _, _ = timed(n_ov, it0 + args.warmup)
+        dp["overlap_on"] = {"value": n_ov * world / o_dt, "unit": "it/s", "ms_per_step": 1e3 * o_dt / n_ov, "steps": n_ov,
+                            "replicas_identical": bool(tr.replicas_identical()),
+                            "exchange_ms_per_step": round(exchange_ms(tr.exchange_events), 4),
+                            "note": "Gaussian bucket all-reduced on RCCL's queue under the MLP backward passes; opt-in"}
+        tr.exchange_events = None
+        tr.overlap = False
+        tr._bind_parameters()
     steady = None
     if args.steps < STEADY_STEPS:
         s_dt, _, _, _ = timed(STEADY_STEPS, it0 + args.warmup + args.steps)
@@ -492,6 +519,9 @@ def main():
                                  "busy": round(1e3 * (elapsed - blocked_s) / args.steps, 3)},
         }
         out["rccl_world_size"] = dist.get_world_size() if world > 1 else 1
+        if dp is not None:
+            out["replicas_identical"] = dp["replicas_identical"]
+            out["data_parallel"] = dp
         if allreduce is not None:
             out["allreduce"] = allreduce
         if f32_mode is not None:

@@ -22,8 +22,8 @@ class StateLayout(_c.Structure):
     _fields_ = [(n, _c.c_size_t) for n in (
         "rec", "depth", "radii", "tiles_touched", "offs", "cov3D", "clamped", "block_sums", "block_offs", "hist",
         "tile_count", "tile_offset", "big_list", "counters", "geometry_bytes",
-        "inst", "point_list", "upos", "slab", "ckpt", "binning_bytes",
-        "final_T", "n_contrib", "ranges", "nproc", "cfin", "image_bytes")] + [
+        "inst", "point_list", "upos", "slab", "live", "ckpt", "binning_bytes",
+        "final_T", "n_contrib", "ranges", "nproc", "cfin", "ckpt64", "image_bytes")] + [
         (n, _c.c_int) for n in ("tiles_x", "tiles_y", "n_chunks", "chunk_size")]
 
 
@@ -120,8 +120,8 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header and library out of sync
             fn.restype = res
             fn.argtypes = args
-        if handle.dgm_abi_version() != 1:
-            raise RuntimeError("libdgmesh_hip.so ABI version mismatch")
+        if handle.dgm_abi_version() != 2 and not (os.environ.get("DGM_LIB_PATH") and os.environ.get("DGM_ABI_ANY") == "1"):
+            raise RuntimeError("libdgmesh_hip.so ABI version mismatch")  # (DGM_ABI_ANY: A/B timing of an older build, tools/ only)
         _LIB = handle
     return _LIB
 

@@ -40,11 +40,12 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib, float4* ckpt, float4* cfin, unsigned* nproc);
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc);
 // render_bwd3.hip
-void launch_render_bwd3(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
+void launch_render_bwd4(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
-                        const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc, const unsigned* upos, float* slab);
+                        const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc,
+                        const unsigned* upos, float* slab, uint8_t* live);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
                            const float* shs, const float* shs_rest, const uint8_t* clamped, const float* scales,
@@ -52,7 +53,7 @@ void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
                            const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
                            const float* rec, const unsigned* tiles_touched, const unsigned* offs, const float* slab,
-                           float* dL_dmean2D,
+                           const uint8_t* live, float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                            float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot);
 // knn.hip
@@ -321,6 +322,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     uint2* ranges = (uint2*)(img + L.ranges);
     unsigned* nproc = (unsigned*)(img + L.nproc);
     float4* cfin = (float4*)(img + L.cfin);
+    float4* ckpt64 = (float4*)(img + L.ckpt64);
 
     if (P == 0) {  // reference: kernels skipped, rendered = 0, out_color stays 0 (rasterize_points.cu:68,81)
         DGM_HIP(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), st));
@@ -408,7 +410,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
 
         tm.begin(DGM_STAGE_TILE_SORT);
         // (segments beyond 4096 entries sort in global memory: their pair buffers are carved from the backward's row slab,
-        // 48 bytes per entry and idle during the forward pass)
+        // 36 bytes per entry -- they need 16 -- and idle during the forward pass)
         DGM_HIP(launch_tile_sort(st, tiles, ranges, inst, (uint2*)(bin + L.slab), (size_t)R, point_list, upos, big_list,
                                  counters + 2));
         DGM_CHECK("tile_sort");
@@ -417,7 +419,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
 
     tm.begin(DGM_STAGE_RENDER_FWD);
     launch_render_fwd(st, tiles, ranges, point_list, width, height, gridx, rec, background, out_color, final_T,
-                      n_contrib, ckpt, cfin, nproc);
+                      n_contrib, ckpt, cfin, ckpt64, nproc);
     DGM_CHECK("render_fwd");
     tm.end(DGM_STAGE_RENDER_FWD);
     tm.finish();
@@ -474,11 +476,13 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
     const unsigned* point_list = (const unsigned*)(bin + L.point_list);
     const unsigned* upos = (const unsigned*)(bin + L.upos);
     float* slab = (float*)(bin + L.slab);
+    uint8_t* live = (uint8_t*)(bin + L.live);
     const unsigned* n_contrib = (const unsigned*)(img + L.n_contrib);
     const uint2* ranges = (const uint2*)(img + L.ranges);
     const unsigned* nproc = (const unsigned*)(img + L.nproc);
     const float4* cfin = (const float4*)(img + L.cfin);
     const float4* ckpt = (const float4*)(bin + L.ckpt);
+    const float4* ckpt64 = (const float4*)(img + L.ckpt64);
     if (!radii) radii = radii_int;  // rasterizer_impl.cu:375-378
 
     const float focal_y = height / (2.0f * tan_fovy);
@@ -486,8 +490,8 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
 
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
-    launch_render_bwd3(st, tiles, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, n_contrib,
-                       dL_dpix, nproc, upos, slab);
+    launch_render_bwd4(st, tiles, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, ckpt64, n_contrib,
+                       dL_dpix, nproc, upos, slab, live);
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);
 
@@ -497,7 +501,7 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
     launch_preprocess_bwd(st, P, D, M, gridx, means3D, radii, colors_precomp ? nullptr : shs,
                           colors_precomp ? nullptr : shs_rest, clamped, scales, rotations,
                           scale_modifier, cov3D_ptr, viewmatrix, projmatrix, campos, focal_x, focal_y, tan_fovx,
-                          tan_fovy, width, height, rec, tiles_touched, offs, slab, dL_dmean2D, dL_dconic,
+                          tan_fovy, width, height, rec, tiles_touched, offs, slab, live, dL_dmean2D, dL_dconic,
                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, colors_precomp ? nullptr : dL_dsh_rest, dL_dscale,
                           dL_drot);
     DGM_CHECK("preprocess_bwd");

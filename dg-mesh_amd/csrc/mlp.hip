@@ -831,7 +831,8 @@ int g_gemm_mode = [] {
     if (strcmp(e, "bf16x6") == 0) return 0;
     if (strcmp(e, "f32") == 0) return 1;
     if (strcmp(e, "f16x3") == 0) return 2;
-    return 3;  // "f16x3p"
+    if (strcmp(e, "f16x3p") != 0) fprintf(stderr, "libdgmesh_hip: unknown DGM_MLP_GEMM=\"%s\" (f16x3p | f16x3 | bf16x6 | f32): using f16x3p\n", e);
+    return 3;
 }();
 // (the plane kernels keep a workgroup's tile exponents in a 512-entry LDS table: beyond 512 tiles per workgroup -- N > 4 M
 // rows on 256 CUs -- the call runs mode 2 as well)
@@ -1136,7 +1137,8 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     // other: ONE launch, the first n_dw workgroups on the weight gradient (n_dw row chunks), the rest on the layer GEMM
     // (mlp_bwd_pair_kernel).  n_dw = 0 (DGM_MLP_PAIR=0) runs them as two launches over all CUs.  The embedding's rows of the
     // skip layer's gradient stay a launch of their own over all CUs (own partial tiles, own reduction job).
-    const int n_dw = p4_pair_split(nt, gx);
+    int n_dw = p4_pair_split(nt, gx);
+    if (n_dw > pl.chunks) n_dw = pl.chunks;  // (the skip layer's partial buffer is carved for pl.chunks tiles of 352 rows)
     for (int l = 7; l >= 0; l--) {
         const int Kp = layer_kp(p, l);
         const bool paired = n_dw > 0 && l >= 1;
@@ -1175,7 +1177,10 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
                 if (p4_lds_attr(mlp_bwd_pair_kernel, LDS_PAIR, &done_[current_device_slot()]) != hipSuccess)
                     return mlp_fail("mlp: cannot raise the LDS limit of mlp_bwd_pair_kernel");
                 const int grid = n_dw + (gx - n_dw > 0 ? gx - n_dw : 1);
-                hipLaunchKernelGGL(mlp_bwd_pair_kernel, dim3(grid), dim3(512), LDS_PAIR, st, a, d, n_dw);
+                // chunked: the GEMM role walks the weight-gradient role's row chunks (needs as many GEMM workgroups as chunks)
+                static const int chunk_env = [] { const char* e = getenv("DGM_MLP_PAIR_CHUNKED"); return e ? atoi(e) : 1; }();
+                const int chunked = (chunk_env && grid - n_dw == n_dw && (n_dw % 8) == 0) ? 1 : 0;
+                hipLaunchKernelGGL(mlp_bwd_pair_kernel, dim3(grid), dim3(512), LDS_PAIR, st, a, d, n_dw, chunked);
             }
             dgm::prof_end(DGM_STAGE_MLP_BWD_PAIR, st);
         } else if (l >= 1) {

@@ -352,7 +352,7 @@ struct Gemm4Cfg {
 // shortage of bandwidth stalls the matrix cores; loads and stores may complete in any order (the counter is only ever
 // waited down to zero).
 template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
-__device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, const int G, unsigned char* smem) {
+__device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, const int G, unsigned char* smem, const int tiles_in = -1) {
     using Cfg = Gemm4Cfg<KS, ROWB, PLANEB, EPI, DUAL, NCW>;
     constexpr int PITCH = Cfg::PITCH, ABYTES = Cfg::ABYTES;
     constexpr int LPR = ROWB / 16;                           // 16-byte pieces (lanes) per row
@@ -369,7 +369,8 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
     float* biasl = reinterpret_cast<float*>(exps + Cfg::EXPS);                   // [256] (EPI 0: read per tile, not held in registers)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
-    const int my_tiles = (a.ntiles - bx + G - 1) / G;
+    // tiles bx, bx + G, ... (tiles_in < 0: all of them up to a.ntiles; else exactly tiles_in of them)
+    const int my_tiles = tiles_in >= 0 ? tiles_in : (a.ntiles - bx + G - 1) / G;
     if (my_tiles <= 0) return;
     const bool computing = wv < NCW;
 #ifdef P4_TIMING
@@ -1021,10 +1022,21 @@ mlp_dw4_kernel(const Dw4Args a) {
 // body on n_dw row chunks, the others the layer GEMM on the remaining CUs.  Besides running a memory-bound and a compute-bound
 // stream side by side this cuts the per-chunk partial tiles (and the reduction that reads them) from one per CU to n_dw.
 __global__ void __launch_bounds__(512)
-mlp_bwd_pair_kernel(const Gemm4Args ga, const Dw4Args da, const int n_dw) {
+mlp_bwd_pair_kernel(const Gemm4Args ga, const Dw4Args da, const int n_dw, const int chunked) {
     extern __shared__ __attribute__((aligned(16))) unsigned char p4_smem[];
-    if ((int)blockIdx.x < n_dw) dw4_body<8, 8, 1024, 512, 1024, 512>(da, (int)blockIdx.x, p4_smem);
-    else gemm4_body<16, 1024, 512, 1, false, 8>(ga, (int)blockIdx.x - n_dw, (int)gridDim.x - n_dw, p4_smem);
+    if ((int)blockIdx.x < n_dw) {
+        dw4_body<8, 8, 1024, 512, 1024, 512>(da, (int)blockIdx.x, p4_smem);
+    } else if (chunked) {
+        // The GEMM workgroup w takes the SAME run of tiles as weight-gradient workgroup w (blockIdx w and n_dw + w land on the
+        // same XCD when n_dw is a multiple of 8): both stream the same rows of G_l at about the same time, so the second
+        // reader can be served by that XCD's L2 instead of the fabric.
+        const int w = (int)blockIdx.x - n_dw;
+        const int first = w * da.tiles_per_chunk;
+        const int cnt = min(da.tiles_per_chunk, ga.ntiles - first);
+        gemm4_body<16, 1024, 512, 1, false, 8>(ga, first, 1, p4_smem, cnt > 0 ? cnt : 0);
+    } else {
+        gemm4_body<16, 1024, 512, 1, false, 8>(ga, (int)blockIdx.x - n_dw, (int)gridDim.x - n_dw, p4_smem);
+    }
 }
 
 }  // namespace dgm

@@ -8,14 +8,17 @@
 // :278-341 cov3D, auxiliary.h:107-117 dnormvdv).
 //
 // Gather: Gaussian g owns instances k = 0..tiles_touched-1 (row-major over its tile rectangle); render_bwd wrote
-// the row of instance k at slab row offs[g] + k (zeros where no pixel reached it), so the rows of a Gaussian -- and of
-// neighbouring Gaussians -- are adjacent.  Rows are summed in ascending k (fixed order => reproducible grads).
+// live[offs[g] + k] for every one of them and, where that is 1, the 36-byte row of instance k at slab row offs[g] + k, so
+// the rows and flags of a workgroup's Gaussians are one contiguous span, streamed through LDS (see the kernel).  Only live
+// rows are added (instances no pixel blended have none), in ascending k (fixed order => reproducible grads).
 //
 // The SH block (192 B in, 192 B out per Gaussian) goes through LDS both ways so that global traffic is
 // coalesced 16-byte accesses (same scheme as preprocess.hip).
 #include "dgm_common.hpp"
 
 namespace dgm {
+
+static constexpr int PBW_CHUNK = 1024;  // slab rows staged per round of the gather: 36 KB + 1 KB of flags in LDS
 
 __constant__ float kbSH_C0 = 0.28209479177387814f;
 __constant__ float kbSH_C1 = 0.4886025119029199f;
@@ -31,7 +34,8 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
                       const float* __restrict__ cov3Ds, const float* __restrict__ vm, const float* __restrict__ proj,
                       const float* __restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, int W, int H,
                       const float* __restrict__ rec, const unsigned* __restrict__ tiles_touched,
-                      const unsigned* __restrict__ offs, const float* __restrict__ slab, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                      const unsigned* __restrict__ offs, const float* __restrict__ slab, const uint8_t* __restrict__ live,
+                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
                       float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
@@ -43,6 +47,44 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
     const bool use_sh = shs != nullptr && M > 0;
     const int L = 3 * M;            // full row: gradients of unused coefficients are written as zeros
     const int stride = L | 1;
+
+    // ---- gather: this Gaussian's gradient rows, summed ---------------------------------------------------------------------
+    // Gaussian g owns slab rows offs[g] .. offs[g] + tiles_touched[g] - 1, so the rows of the workgroup's 256 Gaussians are ONE
+    // contiguous span.  It is streamed through LDS in chunks of PBW_CHUNK rows with coalesced 16-byte loads (rows + their
+    // liveness bytes; a thread-per-Gaussian gather touches 64 cache lines per load instruction and was address-unit bound),
+    // and every thread adds the live rows of its own Gaussian out of LDS, in ascending order (fixed order => reproducible).
+    // Rows whose flag is 0 were not written by this backward: their stale bytes are staged like the others and skipped.
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        const bool vis0 = idx < P && radii[idx] > 0;
+        const unsigned my_n = vis0 ? tiles_touched[idx] : 0u;
+        const unsigned my_first = idx < P ? offs[idx] : 0u;
+        __shared__ unsigned span[2];
+        if (threadIdx.x == 0) span[0] = offs[base];
+        if (threadIdx.x == cnt - 1) span[1] = offs[idx] + tiles_touched[idx];
+        __syncthreads();
+        const unsigned span_end = span[1];
+        unsigned char* lflag = reinterpret_cast<unsigned char*>(lds + PBW_CHUNK * DGM_SLAB_STRIDE);
+        for (unsigned c0 = span[0] & ~3u; c0 < span_end; c0 += PBW_CHUNK) {  // (chunks start on a multiple of 4 rows = 144 B: 16-byte aligned)
+            const unsigned rows = min((unsigned)PBW_CHUNK, span_end - c0);
+            const float4* src = reinterpret_cast<const float4*>(slab + (size_t)c0 * DGM_SLAB_STRIDE);
+            const unsigned n4 = (rows * DGM_SLAB_STRIDE + 3) >> 2;
+            for (unsigned i = threadIdx.x; i < n4; i += DGM_PRE_BLOCK) reinterpret_cast<float4*>(lds)[i] = src[i];
+            const unsigned* fsrc = reinterpret_cast<const unsigned*>(live + c0);
+            for (unsigned i = threadIdx.x; i < ((rows + 3) >> 2); i += DGM_PRE_BLOCK) reinterpret_cast<unsigned*>(lflag)[i] = fsrc[i];
+            __syncthreads();
+            const unsigned k_lo = max(my_first, c0), k_hi = min(my_first + my_n, c0 + rows);
+            for (unsigned k = k_lo; k < k_hi; k++) {
+                if (lflag[k - c0]) {
+                    const float* r = lds + (size_t)(k - c0) * DGM_SLAB_STRIDE;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) acc[i] += r[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
     if (use_sh) {
         // stage the whole (cnt, M, 3) block, coalesced
         const int total = cnt * L;
@@ -94,40 +136,9 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
     __syncthreads();
 
     if (idx < P) {
-        const bool live = radii[idx] > 0;
-        float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (live) {
-            // The rows of this Gaussian's instances are adjacent (render_bwd3 writes row upos[slot] = offs[g] + k, zeros for
-            // instances no pixel reached), and the Gaussians of a wave are adjacent too: the gather is a contiguous
-            // stream.  Rows are summed in ascending k, eight loads in flight.
-            const unsigned n = tiles_touched[idx];
-            const float4* row = reinterpret_cast<const float4*>(slab + (size_t)offs[idx] * DGM_SLAB_STRIDE);
-            for (unsigned k0 = 0; k0 < n; k0 += 8) {
-                float4 ra[8], rb[8];
-                float rc[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float4* r = row + (size_t)(k0 + j < n ? k0 + j : k0) * (DGM_SLAB_STRIDE / 4);
-                    ra[j] = r[0], rb[j] = r[1], rc[j] = r[2].x;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (k0 + j < n) {
-                        acc[0] += ra[j].x;
-                        acc[1] += ra[j].y;
-                        acc[2] += ra[j].z;
-                        acc[3] += ra[j].w;
-                        acc[4] += rb[j].x;
-                        acc[5] += rb[j].y;
-                        acc[6] += rb[j].z;
-                        acc[7] += rb[j].w;
-                        acc[8] += rc[j];
-                    }
-                }
-            }
-        }
-        if (live) {
-            // render_bwd3 rows hold colour sums and the moments of g = G dL/dalpha about the splat centre
+        const bool vis = radii[idx] > 0;
+        if (vis) {
+            // render_bwd4 rows hold colour sums and the moments of g = G dL/dalpha about the splat centre
             // (d = xy - pixel): acc[3..8] = sum g dx, g dy, g dx^2, g dx dy, g dy^2, g.  The gradients of
             // backward.cu:536-554 are linear in them with per-Gaussian coefficients (dL/dG = opacity dL/dalpha):
             //   dL/dmean2D = -o (a Mx + b My) W/2,  -o (c My + b Mx) H/2        (dG/ddel = -G (a dx + b dy), ...)
@@ -157,7 +168,7 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
         float dscale[3] = {0.f, 0.f, 0.f};
         float drot[4] = {0.f, 0.f, 0.f, 0.f};
         float* my_sh = lds + threadIdx.x * stride;
-        if (live) {
+        if (vis) {
             const float m0 = means3D[3 * idx], m1 = means3D[3 * idx + 1], m2 = means3D[3 * idx + 2];
             // ---- computeCov2DCUDA (backward.cu:144-274) ----
             {
@@ -436,14 +447,16 @@ void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const
                            float scale_modifier, const float* cov3Ds, const float* viewmatrix, const float* projmatrix,
                            const float* campos, float focal_x, float focal_y, float tan_fovx, float tan_fovy, int W, int H,
                            const float* rec, const unsigned* tiles_touched, const unsigned* offs, const float* slab,
-                           float* dL_dmean2D,
+                           const uint8_t* live, float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                            float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot) {
-    const size_t lds_bytes = (shs != nullptr && M > 0) ? (size_t)DGM_PRE_BLOCK * ((3 * M) | 1) * sizeof(float) : 16;
+    const size_t sh_bytes = (shs != nullptr && M > 0) ? (size_t)DGM_PRE_BLOCK * ((3 * M) | 1) * sizeof(float) : 16;
+    const size_t gather_bytes = (size_t)PBW_CHUNK * DGM_SLAB_STRIDE * sizeof(float) + PBW_CHUNK + 16;  // (the two uses of LDS follow each other)
+    const size_t lds_bytes = sh_bytes > gather_bytes ? sh_bytes : gather_bytes;
     const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, gridx, means3D,
                        radii, shs, shs_rest, clamped, scales, rotations, scale_modifier, cov3Ds, viewmatrix, projmatrix, campos,
-                       focal_x, focal_y, tan_fovx, tan_fovy, W, H, rec, tiles_touched, offs, slab,
+                       focal_x, focal_y, tan_fovx, tan_fovy, W, H, rec, tiles_touched, offs, slab, live,
                        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot);
 }
 

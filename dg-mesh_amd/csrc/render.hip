@@ -1,4 +1,4 @@
-// Tile alpha-compositing for gfx950: the forward blend (the backward replay lives in render_bwd3.hip).
+// Tile alpha-compositing for gfx950: the forward blend (the backward replay lives in render_bwd4.hip).
 //
 // Replaces FORWARD::render / renderCUDA<3> (DGR/cuda_rasterizer/forward.cu:263-374).  Same tile size (16x16), same
 // per-pixel arithmetic (power, alpha = min(.99, o*exp(power)), 1/255 and 1e-4 thresholds, n_contrib / final_T
@@ -10,9 +10,9 @@
 //    16): the 64 lanes of a wave are spatially compact, which makes wave-uniform decisions (early exit, culling)
 //    effective;
 //  * splats are staged 256 at a time into LDS from ONE 48-byte record per Gaussian (3 x 16 B gathers);
-//  * while staging, each thread computes the exact screen-space bounding box of "alpha >= 1/255" for its
-//    splat (half-extent sqrt(2 ln(255 o) * Sigma_xx|yy)) and tests it against the four quadrants; four
-//    wave ballots turn that into one 64-bit mask per (staging wave, quadrant).  The blend loop of a wave is a
+//  * while staging, each thread tests the ellipse {alpha >= 1/255} of its splat (q(d) <= 2 ln(255 o)) against the
+//    four quadrants -- the minimum of the quadric over each quadrant's 8 x 8 block of pixel centres, not a bounding
+//    box -- and four wave ballots turn that into one 64-bit mask per (staging wave, quadrant).  The blend loop of a wave is a
 //    SCALAR loop over the set bits of its masks (s_ff1 / s_andn2), so pairs that the reference would discard
 //    with `alpha < 1/255` after evaluating exp() are never issued.  The test is conservative (inflated box;
 //    NaN => keep), hence results are unchanged.
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
-                  float4* __restrict__ cfin, unsigned* __restrict__ nproc_out) {
+                  float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out) {
     __shared__ float4 sA[256];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
     __shared__ float4 sB[256];  // conic c * -log2(e)/2, opacity, r, g
     __shared__ float sC[256];   // b
@@ -42,6 +42,11 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int rounds = (n + 255) >> 8;
+    // short lists: the blend state is also left after every 64 entries (slot s = after 64 s entries, s = 1..7), so that the
+    // backward can replay such a tile in 64-entry units on several waves (render_bwd4.hip)
+    const bool shortlist = n <= DGM_SHORT_LIST;
+    const int lxy = (((wv >> 1) * 8 + (lane >> 3)) >> 2) * 64 + ((((wv >> 1) * 8 + (lane >> 3)) & 3) << 4) + (wv & 1) * 8 + (lane & 7);
+    float4* const c64 = ckpt64 + (size_t)tile * 8 * 256 + lxy;
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     unsigned last_contributor = 0;
@@ -49,8 +54,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
     for (int i = 0; i < rounds; i++) {
         if (__syncthreads_and(done)) break;  // also orders the previous round's LDS reads before the refill
-        if (i > 0) {
-            // state after the first 256 i list entries, for the segment-parallel backward (render_bwd3.hip): slot
+        if (i > 0 && !shortlist) {
+            // state after the first 256 i list entries, for the segment-parallel backward (render_bwd4.hip): slot
             // floor((range.x + 256 i) / 256) is unique per (tile, i); pixel order = the backward's lane mapping
             // (row = 4 j + (l >> 4), column = l & 15  ->  index 64 j + l)
             const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
@@ -65,7 +70,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             const float4 r0 = r4[0], r1 = r4[1];
             const float cb = r4[2].x;
             // the conic is staged pre-multiplied so that the exponent below comes out times log2(e), ready for v_exp_f32
-            // (same sign as the reference's `power`; render_bwd3 stages the same way)
+            // (same sign as the reference's `power`; render_bwd4 stages the same way)
             const float l2e = 1.4426950408889634f;
             sA[threadIdx.x] = make_float4(r0.x, r0.y, -0.5f * l2e * r0.z, -l2e * r0.w);
             sB[threadIdx.x] = make_float4(-0.5f * l2e * r1.x, r1.y, r1.z, r1.w);
@@ -78,8 +83,15 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             if (lane == 0) sMask[wv][q] = bal;
         }
         __syncthreads();
-        if (__ballot(!done) == 0ull) continue;  // whole quadrant finished: keep helping with staging only
         const unsigned base = (unsigned)(i << 8);
+        if (__ballot(!done) == 0ull) {  // whole quadrant finished: keep helping with staging only
+            if (shortlist)
+                for (int sw = 0; sw < 4; sw++) {
+                    const int s = 4 * i + sw + 1;
+                    if (s < 8 && 64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+                }
+            continue;
+        }
 #pragma unroll 1
         for (int sw = 0; sw < 4; sw++) {
             unsigned long long m = sMask[sw][wv];
@@ -107,6 +119,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                 T = valid ? test_T : T;
                 last_contributor = valid ? base + (unsigned)j + 1u : last_contributor;
             }
+            if (shortlist) {
+                const int s = 4 * i + sw + 1;
+                if (s < 8 && 64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+            }
         }
     }
     {   // per-tile bound of the backward replay: the deepest contributor index of any pixel
@@ -132,9 +148,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib, float4* ckpt, float4* cfin, unsigned* nproc) {
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc) {
     hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                       out_color, final_T, n_contrib, ckpt, cfin, nproc);
+                       out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc);
 }
 
 }  // namespace dgm

@@ -1,4 +1,4 @@
-// Device helpers shared by the blend kernels (render.hip, render_bwd2.hip).
+// Device helpers shared by the blend kernels (render.hip, render_bwd4.hip).
 #pragma once
 #include "dgm_common.hpp"
 
@@ -12,26 +12,64 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return (unsigned long long)lo | ((unsigned long long)hi << 32);
 }
 
+// Minimum of q(d) = a dx^2 + 2 b dx dy + c dy^2, d = (x, y) - p, over the rectangle of points p in [X0, X1] x [Y0, Y1]
+// (a convex quadric: zero if the centre is inside, otherwise attained on an edge; along an edge the unconstrained
+// minimiser is clamped to the edge).  NaN inputs give NaN, which the callers keep.
+__device__ __forceinline__ float rect_min_q(float x, float y, float a, float b, float c, float ra, float rc, float X0, float X1,
+                                            float Y0, float Y1) {
+    const bool inside = x >= X0 && x <= X1 && y >= Y0 && y <= Y1;
+    float best;
+    {
+        const float dx = x - X0;
+        const float py = fminf(fmaxf(y + b * dx * rc, Y0), Y1), dy = y - py;
+        best = (a * dx + 2.f * b * dy) * dx + c * dy * dy;
+    }
+    {
+        const float dx = x - X1;
+        const float py = fminf(fmaxf(y + b * dx * rc, Y0), Y1), dy = y - py;
+        best = fminf(best, (a * dx + 2.f * b * dy) * dx + c * dy * dy);
+    }
+    {
+        const float dy = y - Y0;
+        const float px = fminf(fmaxf(x + b * dy * ra, X0), X1), dx = x - px;
+        best = fminf(best, (a * dx + 2.f * b * dy) * dx + c * dy * dy);
+    }
+    {
+        const float dy = y - Y1;
+        const float px = fminf(fmaxf(x + b * dy * ra, X0), X1), dx = x - px;
+        best = fminf(best, (a * dx + 2.f * b * dy) * dx + c * dy * dy);
+    }
+    return inside ? 0.f : best;
+}
+
 // Which of the tile's four 8x8 quadrants can receive alpha >= 1/255 from this splat?
-// alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o);  the ellipse {q <= tau} has the
-// axis-aligned half extents sqrt(tau * Sxx), sqrt(tau * Syy) with S = conic^-1.  Inflated by 0.1 % + 0.01 px
-// and written as "not provably outside" so that rounding or NaN can only keep a splat, never drop one.
+// alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o): the quadrant is kept unless the minimum of q
+// over its block of pixel centres provably exceeds tau (inflated by 0.1 % + 0.01; "not provably outside", so that rounding or
+// NaN can only keep a splat, never drop one).
 __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float a, float b, float c, float o, float tx0,
                                                   float ty0) {
     const float o255 = o * 255.0f;
     if (o255 < 1.0f) return 0u;  // alpha = min(.99, o*G) <= o < 1/255 for every pixel (G <= 1 where power <= 0)
     const float tau = 2.0f * __logf(o255) * 1.001f + 0.01f;
-    const float det = a * c - b * b;
-    const float inv = 1.0f / det;
-    const float ex = sqrtf(tau * c * inv) * 1.001f + 0.01f;
-    const float ey = sqrtf(tau * a * inv) * 1.001f + 0.01f;
+    const float ra = __builtin_amdgcn_rcpf(a), rc = __builtin_amdgcn_rcpf(c);
     unsigned m = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
-        const bool outside = (x + ex < qx0) || (x - ex > qx0 + 7.0f) || (y + ey < qy0) || (y - ey > qy0 + 7.0f);
-        if (!outside) m |= 1u << q;
+        if (!(rect_min_q(x, y, a, b, c, ra, rc, qx0, qx0 + 7.0f, qy0, qy0 + 7.0f) > tau)) m |= 1u << q;
     }
+    return m;
+}
+
+// The same test for the two 16 x 8 half tiles (bit 0: rows 0..7, bit 1: rows 8..15): the backward's culling unit.
+__device__ __forceinline__ unsigned half_mask(float x, float y, float a, float b, float c, float o, float tx0, float ty0) {
+    const float o255 = o * 255.0f;
+    if (o255 < 1.0f) return 0u;
+    const float tau = 2.0f * __logf(o255) * 1.001f + 0.01f;
+    const float ra = __builtin_amdgcn_rcpf(a), rc = __builtin_amdgcn_rcpf(c);
+    unsigned m = 0;
+    if (!(rect_min_q(x, y, a, b, c, ra, rc, tx0, tx0 + 15.0f, ty0, ty0 + 7.0f) > tau)) m |= 1u;
+    if (!(rect_min_q(x, y, a, b, c, ra, rc, tx0, tx0 + 15.0f, ty0 + 8.0f, ty0 + 15.0f) > tau)) m |= 2u;
     return m;
 }
 
@@ -87,6 +125,47 @@ __device__ __forceinline__ float wave_reduce8t(float v0, float v1, float v2, flo
     return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
 }
 
+// The same sums with the butterfly's stages in the order that needs NO selects: the stages that still carry several values run
+// along lane bits 2 and 3 (row_shl / row_shr by 4 and 8, where DPP's bank mask picks the half of the lanes that keeps each
+// value of a pair) and along bits 4 and 5 (v_permlane16_swap / v_permlane32_swap exchange the halves of a PAIR of registers,
+// so one swap + one add reduces two values), and only the last two stages -- one register left -- run inside the quads.
+// 14 DPP adds + 2 swaps + 2 adds + 1 copy (wave_reduce8t: 14 selects + 10 DPP adds + 2 swaps + 2 adds + 2 copies).
+// On return every lane l holds the wave total of value number (l >> 2) & 7.
+__device__ __forceinline__ float wave_reduce8m(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                               float v7) {
+    float k0, k1, k2, k3, m0, m1;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        // k0: values {0,1} by lane bit 2, k1: {2,3}, k2: {4,5}, k3: {6,7}
+        "v_add_f32_dpp %4, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %2, %2 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(m0), "=&v"(m1)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
+    // m0: values {0..3} by lane bits (2, 3), m1: {4..7}; every lane holds the sum over its row of 16 lanes' matching quarter
+    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m0), __float_as_uint(m1), false, false);
+    const float c = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);  // rows 0, 2: m0's sums over a row pair; rows 1, 3: m1's
+    const unsigned cb = __float_as_uint(c);
+    auto s32 = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);
+    float x = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(x));
+    return x;
+}
+
 // In-place inclusive-scan style reduction of ONE value: the wave total ends up in lane 63.
 __device__ __forceinline__ float wave_reduce1_lane63(float v) {
     asm volatile(
@@ -105,18 +184,6 @@ __device__ __forceinline__ float wave_reduce1_lane63(float v) {
         "s_nop 1"
         : "+v"(v));
     return v;
-}
-
-// Half extents (inflated, conservative) of the screen-space box outside of which alpha < 1/255 for this splat;
-// returns false when the splat can never reach 1/255 (opacity too low).  See quadrant_mask for the derivation.
-__device__ __forceinline__ bool alpha_extent(float a, float b, float c, float o, float& ex, float& ey) {
-    const float o255 = o * 255.0f;
-    if (o255 < 1.0f) return false;
-    const float tau = 2.0f * __logf(o255) * 1.001f + 0.01f;
-    const float inv = 1.0f / (a * c - b * b);
-    ex = sqrtf(tau * c * inv) * 1.001f + 0.01f;
-    ey = sqrtf(tau * a * inv) * 1.001f + 0.01f;
-    return true;
 }
 
 }  // namespace dgm

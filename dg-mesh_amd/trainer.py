@@ -259,6 +259,36 @@ class Trainer:
             dist.all_reduce(self.g.denom, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self.g.max_radii2D, op=dist.ReduceOp.MAX, group=self.group)
 
+    def state_hash(self):
+        """One 64-bit word per state tensor -- every parameter in `self.params` and its two Adam moments -- computed on the
+        device: the bit patterns as int32, weighted by (position-dependent odd multipliers) and summed with wrap-around.
+        Equal tensors give equal words; a single differing bit changes the word (weights are odd)."""
+        dev = self.g.get_xyz.device
+        words = []
+        for p in self.params:
+            st = None
+            for o in self.optimizers:
+                if p in o.state:
+                    st = o.state[p]
+                    break
+            for t in (p.detach(), st.get("exp_avg") if st else None, st.get("exp_avg_sq") if st else None):
+                if t is None or t.numel() == 0:
+                    words.append(torch.zeros((), dtype=torch.int64, device=dev))
+                    continue
+                bits = t.contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+                w = (torch.arange(bits.numel(), device=dev, dtype=torch.int64) * 2654435761 + 0x1E3779B97F4A7C15) | 1
+                words.append((bits * w).sum())
+        return torch.stack(words)
+
+    def replicas_identical(self):
+        """All ranks hold bit-identical parameters and Adam moments (all-gather of state_hash()); True on one rank."""
+        h = self.state_hash()
+        if self.world == 1:
+            return True
+        parts = [torch.empty_like(h) for _ in range(self.world)]
+        dist.all_gather(parts, h, group=self.group)
+        return all(bool(torch.equal(parts[0], q)) for q in parts[1:])
+
     def bucket_bytes(self):
         """Byte sizes of the flat buckets one step all-reduces (Gaussian bucket, MLP bucket; or the single bucket)."""
         if self._early is not None:
@@ -399,6 +429,10 @@ class Trainer:
             if self.densify:
                 rebound = self.maybe_densify(iteration)
         grads = None
+        ev = getattr(self, "exchange_events", None)  # bench.py: [(start, end), ...] hipEvents around the exchange on this stream
+        if ev is not None and self.world > 1:
+            ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            ev[-1][0].record()
         if self.world > 1 and self._early is not None:
             e = self._early
             if e["work"] is None:  # (a step in which some Gaussian tensor got no gradient: exchange it now)
@@ -412,6 +446,8 @@ class Trainer:
             if self.pack:
                 grads = self.bucket.pack()  # replaced Parameters are not in this (old) bucket: no update for them
             self.bucket.all_reduce(self.group)
+        if ev is not None and self.world > 1:
+            ev[-1][1].record()
         if self.multi_adam is not None:
             self.multi_adam.step(grads)
         else:

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define DGM_ABI_VERSION 1
+#define DGM_ABI_VERSION 2
 
 /* Allocator callback: must return a device pointer to at least `bytes` bytes (128-byte aligned),
  * valid until the matching backward has run.  Mirrors resizeFunctional, rasterize_points.cu:27-33. */
@@ -136,9 +136,11 @@ typedef struct {
                           order within a tile (the tile sort's input) */
     size_t point_list; /* u32[R]  gaussian ids, by tile then depth then id: identical to the reference's */
     size_t upos;       /* u32[R]  upos[slot] = offs[g] + k for the point_list entry at `slot`: g's k-th tile instance */
-    size_t slab;       /* float[R][12] per-instance gradient rows written by backward AT ROW upos[slot] (grouped by
+    size_t slab;       /* float[R][9] per-instance gradient rows written by backward AT ROW upos[slot] (grouped by
                           Gaussian, so the per-Gaussian sum reads them contiguously): colour r,g,b | moments of
-                          g = G dL/dalpha about the splat centre: 1, dx, dy, dx^2, dx dy, dy^2 | 3 pad */
+                          g = G dL/dalpha about the splat centre: dx, dy, dx^2, dx dy, dy^2, 1.  Only rows with live[row] != 0
+                          are written */
+    size_t live;       /* u8[R] live[row] = 1 iff some pixel blended the instance, i.e. slab[row] was written by this backward */
     size_t ckpt;       /* float4[R/256 + 1][256]: (T, C.rgb) of a tile's pixels after each 256 list entries (forward ->
                           segment-parallel backward) */
     size_t binning_bytes;
@@ -148,6 +150,8 @@ typedef struct {
     size_t ranges;    /* uint2[tiles] */
     size_t nproc;     /* u32[tiles] list entries the backward has to replay (deepest contributor of the tile) */
     size_t cfin;      /* float4[tiles][256]: final (T, C.rgb without background) per pixel, backward lane order */
+    size_t ckpt64;    /* float4[tiles][8][256]: tiles with <= 512 list entries also leave (T, C.rgb) after each 64 entries
+                         (slot i = state after 64 i entries, i = 1..7), so that the backward replays them in 64-entry units */
     size_t image_bytes;
     int tiles_x, tiles_y, n_chunks, chunk_size;
 } dgm_state_layout;

@@ -83,7 +83,12 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert out.returncode == 0, out.stdout[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
-    assert rec["allreduce"]["world_size_observed"] == 2 and len(rec["allreduce"]["bucket_bytes"]) in (2, 3)
+    assert rec["allreduce"]["world_size_observed"] == 2 and len(rec["allreduce"]["bucket_bytes"]) == 1  # (default: one flat bucket)
+    # the line vouches for itself: parameter + Adam-moment hashes of all ranks compared after the timed region, both exchange forms
+    assert rec["replicas_identical"] is True
+    dp = rec["data_parallel"]
+    assert dp["overlap"] is False and dp["exchange_ms_per_step"] > 0
+    assert dp["overlap_on"]["replicas_identical"] is True and dp["overlap_on"]["value"] > 0
 
 
 def test_bench_gpus_flag_refuses_too_few_devices():
