@@ -8,8 +8,10 @@
 
 #define DGM_TILE 16          // BLOCK_X = BLOCK_Y of the reference (config.h:16-17): keeps tile ids / ranges identical
 #define DGM_REC_STRIDE 12    // floats per splat record (48 B = 3 x float4)
-#define DGM_SLAB_STRIDE 9    // floats per per-instance gradient row (36 B, dword-aligned)
-#define DGM_SHORT_LIST 512   // tiles with at most this many list entries get 64-entry checkpoints / backward units
+#ifndef DGM_SLAB_STRIDE
+#define DGM_SLAB_STRIDE 9    // floats per per-instance gradient row (36 B, dword-aligned); 12 = padded to 48 B, 16-byte aligned
+#endif
+#define DGM_SHORT_LIST 4096  // tiles with at most this many list entries get 64-entry checkpoints / backward units
 #define DGM_PRE_BLOCK 256    // Gaussians per preprocess workgroup (also the granularity of block_sums)
 #define DGM_BIN_THREADS 512  // threads of a binning chunk workgroup
 #define DGM_MAX_CHUNKS 256   // chunk workgroups = rows of the per-chunk tile histogram
@@ -63,8 +65,9 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->point_list = take(Rz * 4);
     L->upos = take(Rz * 4);
     L->slab = take(Rz * (DGM_SLAB_STRIDE * 4 > 16 ? DGM_SLAB_STRIDE * 4 : 16));  // (>= 16 B per entry: the tile sort's scratch)
-    L->live = take(Rz);
+    L->live = take(Rz + 8);  // (+8: flags are read eight at a time)
     L->ckpt = take((Rz / 256 + 1) * 256 * 16);  // per (tile, 256-entry round boundary): (T, C) of the tile's 256 pixels
+    L->ckpt64 = take((Rz / 64 + 1) * 256 * 16);  // short tiles: per (tile, 64-entry boundary) instead
     L->binning_bytes = o + A;
     o = 0;
     L->final_T = take((size_t)W * H * 4);
@@ -72,7 +75,6 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->ranges = take(tiles * 8);
     L->nproc = take(tiles * 4);
     L->cfin = take(tiles * 256 * 16);  // final (T, C) per pixel, tile-major in the backward's lane order
-    L->ckpt64 = take(tiles * 8 * 256 * 16);  // short tiles: (T, C) after each 64 entries
     L->image_bytes = o + A;
 }
 
@@ -125,6 +127,7 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 // 36-byte gradient rows are dword-aligned only: 16-byte accesses to them go through this type (gfx950 runs in unaligned access
 // mode: a global_load/store_dwordx4 needs 4-byte alignment)
 typedef float dgm_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned long long dgm_u64u __attribute__((aligned(1)));
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

@@ -9,16 +9,14 @@
 //
 // Gather: Gaussian g owns instances k = 0..tiles_touched-1 (row-major over its tile rectangle); render_bwd wrote
 // live[offs[g] + k] for every one of them and, where that is 1, the 36-byte row of instance k at slab row offs[g] + k, so
-// the rows and flags of a workgroup's Gaussians are one contiguous span, streamed through LDS (see the kernel).  Only live
-// rows are added (instances no pixel blended have none), in ascending k (fixed order => reproducible grads).
+// the rows and flags of a Gaussian -- and of neighbouring Gaussians -- are adjacent.  Only live rows are read (instances no
+// pixel blended have none); they are summed in ascending k (fixed order => reproducible grads).
 //
 // The SH block (192 B in, 192 B out per Gaussian) goes through LDS both ways so that global traffic is
 // coalesced 16-byte accesses (same scheme as preprocess.hip).
 #include "dgm_common.hpp"
 
 namespace dgm {
-
-static constexpr int PBW_CHUNK = 1024;  // slab rows staged per round of the gather: 36 KB + 1 KB of flags in LDS
 
 __constant__ float kbSH_C0 = 0.28209479177387814f;
 __constant__ float kbSH_C1 = 0.4886025119029199f;
@@ -49,39 +47,45 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
     const int stride = L | 1;
 
     // ---- gather: this Gaussian's gradient rows, summed ---------------------------------------------------------------------
-    // Gaussian g owns slab rows offs[g] .. offs[g] + tiles_touched[g] - 1, so the rows of the workgroup's 256 Gaussians are ONE
-    // contiguous span.  It is streamed through LDS in chunks of PBW_CHUNK rows with coalesced 16-byte loads (rows + their
-    // liveness bytes; a thread-per-Gaussian gather touches 64 cache lines per load instruction and was address-unit bound),
-    // and every thread adds the live rows of its own Gaussian out of LDS, in ascending order (fixed order => reproducible).
-    // Rows whose flag is 0 were not written by this backward: their stale bytes are staged like the others and skipped.
+    // Gaussian g owns slab rows offs[g] .. offs[g] + tiles_touched[g] - 1 and their liveness bytes: one thread walks them eight at
+    // a time -- ONE 8-byte load for the flags, then 16-byte loads for the rows render_bwd wrote (a row whose flag is 0 holds stale
+    // bytes and is never read), summed in ascending order (fixed order => reproducible).
+    // Measured at cfg2 (3.0 M rows, about half of them dead), same kernel otherwise: this form 0.084 ms; flags read as eight
+    // byte loads 0.106; every row read and dead ones dropped by a select 0.118; 48-byte aligned rows with the dead ones written
+    // as zeros (round 3's form, no flags) 0.069 in round 3's library and 0.110 here with the flag loads added; the workgroup's
+    // row span streamed through LDS in 1024-row chunks (coalesced, nine loads in flight) 0.126 -- only ~34 of the 256 threads
+    // own rows of a given chunk.  The kernel is bound by the number of load instructions whose lanes touch 64 different
+    // cache lines, so the byte loads of the flags cost as much as the rows' 16-byte loads.
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
-        const bool vis0 = idx < P && radii[idx] > 0;
-        const unsigned my_n = vis0 ? tiles_touched[idx] : 0u;
-        const unsigned my_first = idx < P ? offs[idx] : 0u;
-        __shared__ unsigned span[2];
-        if (threadIdx.x == 0) span[0] = offs[base];
-        if (threadIdx.x == cnt - 1) span[1] = offs[idx] + tiles_touched[idx];
-        __syncthreads();
-        const unsigned span_end = span[1];
-        unsigned char* lflag = reinterpret_cast<unsigned char*>(lds + PBW_CHUNK * DGM_SLAB_STRIDE);
-        for (unsigned c0 = span[0] & ~3u; c0 < span_end; c0 += PBW_CHUNK) {  // (chunks start on a multiple of 4 rows = 144 B: 16-byte aligned)
-            const unsigned rows = min((unsigned)PBW_CHUNK, span_end - c0);
-            const float4* src = reinterpret_cast<const float4*>(slab + (size_t)c0 * DGM_SLAB_STRIDE);
-            const unsigned n4 = (rows * DGM_SLAB_STRIDE + 3) >> 2;
-            for (unsigned i = threadIdx.x; i < n4; i += DGM_PRE_BLOCK) reinterpret_cast<float4*>(lds)[i] = src[i];
-            const unsigned* fsrc = reinterpret_cast<const unsigned*>(live + c0);
-            for (unsigned i = threadIdx.x; i < ((rows + 3) >> 2); i += DGM_PRE_BLOCK) reinterpret_cast<unsigned*>(lflag)[i] = fsrc[i];
-            __syncthreads();
-            const unsigned k_lo = max(my_first, c0), k_hi = min(my_first + my_n, c0 + rows);
-            for (unsigned k = k_lo; k < k_hi; k++) {
-                if (lflag[k - c0]) {
-                    const float* r = lds + (size_t)(k - c0) * DGM_SLAB_STRIDE;
+    if (idx < P && radii[idx] > 0) {
+        const unsigned n = tiles_touched[idx];
+        const size_t first = offs[idx];
+        const uint8_t* fl = live + first;
+        const float* row = slab + first * DGM_SLAB_STRIDE;
+        for (unsigned k0 = 0; k0 < n; k0 += 8) {
+            // eight flags in ONE load (byte-aligned 8-byte access; up to 7 bytes past the Gaussian's own flags, inside the array's padding)
+            const unsigned long long f8 = *reinterpret_cast<const dgm_u64u*>(fl + k0);
+            bool on[8];
 #pragma unroll
-                    for (int i = 0; i < 9; i++) acc[i] += r[i];
+            for (int j = 0; j < 8; j++) on[j] = k0 + j < n && ((f8 >> (8 * j)) & 0xffull) != 0;
+            float r[8][9];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) r[j][i] = 0.f;
+                if (on[j]) {
+                    const float* rp = row + (size_t)(k0 + j) * DGM_SLAB_STRIDE;
+                    const dgm_f4u a0 = *reinterpret_cast<const dgm_f4u*>(rp), a1 = *reinterpret_cast<const dgm_f4u*>(rp + 4);
+                    r[j][0] = a0.x, r[j][1] = a0.y, r[j][2] = a0.z, r[j][3] = a0.w;
+                    r[j][4] = a1.x, r[j][5] = a1.y, r[j][6] = a1.z, r[j][7] = a1.w;
+                    r[j][8] = rp[8];
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) acc[i] += r[j][i];
+            }
         }
     }
 
@@ -450,9 +454,7 @@ void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const
                            const uint8_t* live, float* dL_dmean2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                            float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot) {
-    const size_t sh_bytes = (shs != nullptr && M > 0) ? (size_t)DGM_PRE_BLOCK * ((3 * M) | 1) * sizeof(float) : 16;
-    const size_t gather_bytes = (size_t)PBW_CHUNK * DGM_SLAB_STRIDE * sizeof(float) + PBW_CHUNK + 16;  // (the two uses of LDS follow each other)
-    const size_t lds_bytes = sh_bytes > gather_bytes ? sh_bytes : gather_bytes;
+    const size_t lds_bytes = (shs != nullptr && M > 0) ? (size_t)DGM_PRE_BLOCK * ((3 * M) | 1) * sizeof(float) : 16;
     const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, gridx, means3D,
                        radii, shs, shs_rest, clamped, scales, rotations, scale_modifier, cov3Ds, viewmatrix, projmatrix, campos,

@@ -25,13 +25,15 @@ __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
-                  float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out) {
+                  float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out, const unsigned tile_mul) {
     __shared__ float4 sA[256];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
     __shared__ float4 sB[256];  // conic c * -log2(e)/2, opacity, r, g
     __shared__ float sC[256];   // b
     __shared__ unsigned long long sMask[4][4];  // [staging wave][quadrant]
     __shared__ unsigned sMaxC[4];               // per-wave maximum of last_contributor
-    const int tile = blockIdx.x;
+    // workgroup -> tile through a fixed permutation (tile_mul coprime to the tile count; 1 = identity): long lists are
+    // neighbours on screen, and neighbours in launch order share CUs
+    const int tile = (int)(((unsigned long long)blockIdx.x * tile_mul) % gridDim.x);
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tile_x * DGM_TILE + (wv & 1) * 8 + (lane & 7);
@@ -42,11 +44,11 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int rounds = (n + 255) >> 8;
-    // short lists: the blend state is also left after every 64 entries (slot s = after 64 s entries, s = 1..7), so that the
-    // backward can replay such a tile in 64-entry units on several waves (render_bwd4.hip)
+    // short lists: the blend state is left after every 64 entries (slot (first + 64 s) / 64: unique per (tile, s)) instead of
+    // every 256, so that the backward can replay such a tile in 64-entry units on several waves (render_bwd4.hip)
     const bool shortlist = n <= DGM_SHORT_LIST;
     const int lxy = (((wv >> 1) * 8 + (lane >> 3)) >> 2) * 64 + ((((wv >> 1) * 8 + (lane >> 3)) & 3) << 4) + (wv & 1) * 8 + (lane & 7);
-    float4* const c64 = ckpt64 + (size_t)tile * 8 * 256 + lxy;
+    float4* const c64 = ckpt64 + (size_t)(range.x >> 6) * 256 + lxy;  // + s * 256: (range.x + 64 s) >> 6 = (range.x >> 6) + s
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     unsigned last_contributor = 0;
@@ -88,7 +90,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             if (shortlist)
                 for (int sw = 0; sw < 4; sw++) {
                     const int s = 4 * i + sw + 1;
-                    if (s < 8 && 64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+                    if (64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
                 }
             continue;
         }
@@ -96,32 +98,58 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         for (int sw = 0; sw < 4; sw++) {
             unsigned long long m = sMask[sw][wv];
             m = uniform_u64(m);
+            // Two list entries per trip: the second one's geometry (exponent, exp, alpha) does not depend on the first one's
+            // blend, so a lone wave -- a trained scene leaves about one per SIMD -- overlaps the two dependency chains instead of
+            // waiting out each instruction's latency; the blends themselves stay in list order.  (Odd counts: the last entry is
+            // evaluated twice and blended once.)
             while (m) {
-                const int j = (sw << 6) + __builtin_ctzll(m);
+                const int ja = (sw << 6) + __builtin_ctzll(m);
                 m &= m - 1;
-                const float4 A = sA[j];
-                const float4 B = sB[j];
-                const float cb = sC[j];
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = (A.z * dx + A.w * dy) * dx + (B.x * dy) * dy;  // the reference's exponent times log2(e)
-                const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power));
-                const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                const float test_T = T * (1.0f - alpha);
-                const bool stop = pass && test_T < 0.0001f;
-                const bool valid = pass && !stop;
-                done = done || stop;
-                // branch-free: a pixel that skips the splat blends it with weight zero (the three colour reads are issued
-                // with the geometry reads instead of behind a divergent branch)
-                const float w = valid ? alpha * T : 0.f;
-                C0 += B.z * w;
-                C1 += B.w * w;
-                C2 += cb * w;
-                T = valid ? test_T : T;
-                last_contributor = valid ? base + (unsigned)j + 1u : last_contributor;
+                const bool two = m != 0ull;
+                const int jb = two ? (sw << 6) + __builtin_ctzll(m) : ja;
+                m &= m - 1;  // (no-op when m == 0)
+                const float4 Aa = sA[ja], Ab = sA[jb];
+                const float4 Ba = sB[ja], Bb = sB[jb];
+                const float ca = sC[ja], cbb = sC[jb];
+                const float dxa = Aa.x - pxf, dya = Aa.y - pyf;
+                const float dxb = Ab.x - pxf, dyb = Ab.y - pyf;
+                const float power_a = (Aa.z * dxa + Aa.w * dya) * dxa + (Ba.x * dya) * dya;  // the reference's exponent times log2(e)
+                const float power_b = (Ab.z * dxb + Ab.w * dyb) * dxb + (Bb.x * dyb) * dyb;
+                const float alpha_a = fminf(0.99f, Ba.y * __builtin_amdgcn_exp2f(power_a));
+                const float alpha_b = fminf(0.99f, Bb.y * __builtin_amdgcn_exp2f(power_b));
+                const bool geo_a = !(power_a > 0.0f) && !(alpha_a < 1.0f / 255.0f);
+                const bool geo_b = two && !(power_b > 0.0f) && !(alpha_b < 1.0f / 255.0f);
+                {
+                    const bool pass = !done && geo_a;
+                    const float test_T = T * (1.0f - alpha_a);
+                    const bool stop = pass && test_T < 0.0001f;
+                    const bool valid = pass && !stop;
+                    done = done || stop;
+                    // branch-free: a pixel that skips the splat blends it with weight zero
+                    const float w = valid ? alpha_a * T : 0.f;
+                    C0 += Ba.z * w;
+                    C1 += Ba.w * w;
+                    C2 += ca * w;
+                    T = valid ? test_T : T;
+                    last_contributor = valid ? base + (unsigned)ja + 1u : last_contributor;
+                }
+                {
+                    const bool pass = !done && geo_b;
+                    const float test_T = T * (1.0f - alpha_b);
+                    const bool stop = pass && test_T < 0.0001f;
+                    const bool valid = pass && !stop;
+                    done = done || stop;
+                    const float w = valid ? alpha_b * T : 0.f;
+                    C0 += Bb.z * w;
+                    C1 += Bb.w * w;
+                    C2 += cbb * w;
+                    T = valid ? test_T : T;
+                    last_contributor = valid ? base + (unsigned)jb + 1u : last_contributor;
+                }
             }
             if (shortlist) {
                 const int s = 4 * i + sw + 1;
-                if (s < 8 && 64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+                if (64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
             }
         }
     }
@@ -148,9 +176,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc) {
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, unsigned tile_mul) {
     hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                       out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc);
+                       out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, tile_mul);
 }
 
 }  // namespace dgm

@@ -18,9 +18,12 @@
 //   * culling.  A half tile is entered only if the ellipse {alpha >= 1/255} itself -- not its bounding box -- reaches
 //     the half's 16 x 8 block of pixel centres (minimum of the quadric over the rectangle, evaluated by the staging
 //     lane: one lane per splat);
-//   * units.  Tiles with at most 512 list entries are replayed in units of 64 entries from the forward's 64-entry
-//     checkpoints (render.hip: `ckpt64`), so that a 200-entry tile -- the trained-scene case -- is four waves of work,
-//     not one; longer tiles keep the 256-entry segments;
+//   * units.  Tiles with at most 4096 list entries -- every tile of the BASELINE scenes -- are replayed in units of 64 entries
+//     from the forward's 64-entry checkpoints (render.hip: `ckpt64`, 64 bytes per entry), 16 workgroups per tile.  A unit is
+//     a serial chain of ~1000 cycles per blended entry for a lone wave; on a trained scene (lists of 200-1400 entries, half
+//     the tiles empty) the kernel's duration was that of ONE 256-entry segment -- 0.9 waves resident per SIMD, VALU busy 0.26
+//     (`profiles/r04_pmc_sq_trained.json`) -- and on the initial scene the shorter units trim the tail as well.  Longer
+//     lists keep 256-entry segments (16 bytes of checkpoints per entry);
 //   * rows.  36 bytes (9 floats), written only for instances some pixel blended; `live[row]` (one byte per instance,
 //     always written) tells preprocess_bwd which rows to read.  No zero rows are written or read.
 // No atomics, bit-reproducible (fixed reduction and summation order).
@@ -32,7 +35,10 @@ namespace dgm {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-static constexpr int RB4_KSPLIT = 8;  // workgroups per tile; units are dealt round-robin
+#ifndef RB4_KSPLIT_N
+#define RB4_KSPLIT_N 16
+#endif
+static constexpr int RB4_KSPLIT = RB4_KSPLIT_N;  // workgroups per tile; units are dealt round-robin (a 1024-entry tile: one 64-entry unit each)
 static constexpr int RB4_RS = 9;      // floats per staged output row (= DGM_SLAB_STRIDE)
 
 // replay state of one row pair (two pixels of the lane)
@@ -102,12 +108,14 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                    const float* __restrict__ bg, const float* __restrict__ rec, const float4* __restrict__ cfin,
                    const float4* __restrict__ ckpt, const float4* __restrict__ ckpt64, const unsigned* __restrict__ n_contrib,
                    const float* __restrict__ dL_dpixels, const unsigned* __restrict__ nproc_in,
-                   const unsigned* __restrict__ upos, float* __restrict__ slab, uint8_t* __restrict__ live) {
+                   const unsigned* __restrict__ upos, float* __restrict__ slab, uint8_t* __restrict__ live, const unsigned tile_mul) {
     __shared__ float4 sA[64];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
     __shared__ float4 sB[64];  // conic c * -log2(e)/2, opacity, r, g
     __shared__ float sC[64];   // b
     __shared__ float sOut[64 * RB4_RS];
-    const int tile = blockIdx.x;
+    // workgroup -> tile through a fixed permutation (tile_mul coprime to the tile count): heavy tiles are neighbours on
+    // screen, and neighbours in launch order end up on the same SIMDs
+    const int tile = (int)(((unsigned long long)blockIdx.x * tile_mul) % gridDim.x);
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int nproc = (int)nproc_in[tile];
@@ -176,7 +184,7 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
 #pragma unroll
             for (int h = 0; h < 2; h++) P[h].T = Tfin[h], P[h].S = Sfin[h];
         } else {
-            const float4* cp = shortlist ? ckpt64 + ((size_t)tile * 8 + (size_t)(k + 1)) * 256
+            const float4* cp = shortlist ? ckpt64 + ((size_t)(range.x >> 6) + (size_t)(k + 1)) * 256
                                          : ckpt + (size_t)((range.x + ((unsigned)(k + 1) << 8)) >> 8) * 256;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -279,9 +287,9 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
 void launch_render_bwd4(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
                         const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc,
-                        const unsigned* upos, float* slab, uint8_t* live) {
+                        const unsigned* upos, float* slab, uint8_t* live, unsigned tile_mul) {
     hipLaunchKernelGGL(render_bwd4_kernel, dim3(tiles, RB4_KSPLIT), dim3(64), 0, st, ranges, point_list, W, H, gridx, bg, rec,
-                       cfin, ckpt, ckpt64, n_contrib, dL_dpix, nproc, upos, slab, live);
+                       cfin, ckpt, ckpt64, n_contrib, dL_dpix, nproc, upos, slab, live, tile_mul);
 }
 
 }  // namespace dgm

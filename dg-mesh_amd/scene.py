@@ -42,6 +42,11 @@ class GaussianModel:
         self.max_radii2D = self.xyz_gradient_accum = self.denom = None
         self.optimizer = None
         self.spatial_lr_scale = 5
+        # mesh branch state that lives on the Gaussian model (gaussian_model_dpsr_dynamic_anchor.py:76-86): the DPSR iso-level, a
+        # trained scalar in the optimizer's 8th group, and the normalisation of the points into the unit cube
+        self.density_thres_param = torch.nn.Parameter(torch.tensor(0.0, dtype=torch.float32, device=device))
+        self.gaussian_center = torch.zeros(3, dtype=torch.float32, device=device)
+        self.gaussian_scale = torch.ones(1, dtype=torch.float32, device=device)
         self.scaling_activation = torch.exp
         self.opacity_activation = torch.sigmoid
         self.rotation_activation = F.normalize
@@ -132,12 +137,14 @@ class GaussianModel:
             {"params": [self._scaling], "lr": training_args.scaling_lr * self.spatial_lr_scale, "name": "scaling"},
             {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
             {"params": [self._normal], "lr": training_args.rotation_lr * 100, "name": "normal"},
-        ]  # (the reference's 8th group, density_thres, belongs to the DPSR mesh branch: out of scope)
+            {"params": [self.density_thres_param], "lr": 0.01, "name": "density_thres"},
+        ]
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         steps = training_args.position_lr_max_steps
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=lr_xyz, lr_final=training_args.position_lr_final * self.spatial_lr_scale,
             lr_delay_mult=training_args.position_lr_delay_mult, max_steps=steps)
+        self.density_thres_scheduler_args = get_expon_lr_func(lr_init=0.01, lr_final=0.0001, lr_delay_mult=0.01, max_steps=steps)
         # NB the reference applies the "normal" schedule built from rotation_lr and the "rotation" schedule built
         # from 100 * rotation_lr (gaussian_model_dpsr_dynamic_anchor.py:214-236); mirrored as is.
         self.normal_scheduler_args = get_expon_lr_func(lr_init=training_args.rotation_lr,
@@ -151,6 +158,8 @@ class GaussianModel:
         for group in self.optimizer.param_groups:
             if group["name"] == "xyz":
                 group["lr"] = self.xyz_scheduler_args(iteration)
+            elif group["name"] == "density_thres":
+                group["lr"] = self.density_thres_scheduler_args(iteration)
             elif group["name"] == "normal":
                 group["lr"] = self.normal_scheduler_args(iteration)
             elif group["name"] == "rotation":
@@ -161,7 +170,7 @@ class GaussianModel:
         from . import ply_io
         n = lambda t: t.detach().cpu().numpy().astype(np.float32)
         ply_io.save_gaussians(path, n(self._xyz), n(self._normal), n(self._features_dc), n(self._features_rest), n(self._opacity),
-                              n(self._scaling), n(self._rotation), float(getattr(self, "density_thres_param", 0.0)),
+                              n(self._scaling), n(self._rotation), float(self.density_thres_param.detach()),
                               tuple(float(v) for v in torch.as_tensor(getattr(self, "gaussian_center", [0.0, 0.0, 0.0])).reshape(-1).tolist()),
                               float(torch.as_tensor(getattr(self, "gaussian_scale", 1.0)).reshape(-1)[0]))
 
@@ -179,7 +188,7 @@ class GaussianModel:
         self.og_number_points = og_number_points
         self.load_raw(d["xyz"], d["features_dc"], d["features_rest"], d["scaling"], d["rotation"], d["opacity"], d["normal"])
         dev = self.device
-        self.density_thres_param = torch.tensor(float(d["density_thres"]), dtype=torch.float32, device=dev)
+        self.density_thres_param = torch.nn.Parameter(torch.tensor(float(d["density_thres"]), dtype=torch.float32, device=dev))
         self.gaussian_center = torch.tensor(d["gaussian_center"], dtype=torch.float32, device=dev)
         self.gaussian_scale = torch.tensor(float(d["gaussian_scale"]), dtype=torch.float32, device=dev)
         P = self._xyz.shape[0]

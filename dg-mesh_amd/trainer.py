@@ -103,28 +103,38 @@ def frame_schedule(n_frames, step, rank, world, seed=0):
 
 
 class MeshPhase:
-    """The mesh co-training phase's own state: the three extra networks, the DPSR module, the density threshold parameter
-    (R/scene/gaussian_model_dpsr_dynamic_anchor.py:83-86: the 8th Adam group of the Gaussian model), the normalisation
-    (gaussian_center / gaussian_scale, :76-77) and the V probe points that stand in for the DiffMC vertices."""
+    """The mesh co-training phase's own state: the three extra networks, the DPSR module and the V probe points that stand in for
+    the DiffMC vertices.  The density threshold (the 8th Adam group of the Gaussian model, exponential schedule 0.01 -> 1e-4)
+    and the normalisation gaussian_center / gaussian_scale live on the GaussianModel, as in the reference
+    (R/scene/gaussian_model_dpsr_dynamic_anchor.py:76-86, 201-229), so checkpoints carry the trained values; `density_thres`,
+    `center`, `scale` given here initialise them (R/train.py: normal_initialization sets init_density_threshold)."""
 
-    def __init__(self, deform_normal, deform_back_normal, appearance, dpsr=None, n_verts=20000, density_thres=0.0,
-                 center=(0.0, 0.0, 0.0), scale=1.0, seed=0, device="cuda", stand_in_weight=1e-6):
+    def __init__(self, deform_normal, deform_back_normal, appearance, dpsr=None, n_verts=20000, density_thres=None,
+                 center=None, scale=None, seed=0, device="cuda", stand_in_weight=1e-6):
         self.stand_in_weight = stand_in_weight
         self.deform_normal, self.deform_back_normal, self.appearance, self.dpsr = deform_normal, deform_back_normal, appearance, dpsr
         dev = torch.device(device)
         gen = torch.Generator().manual_seed(4242 + seed)
-        self.density_thres = torch.nn.Parameter(torch.tensor(float(density_thres), device=dev))
-        self.center = torch.tensor(center, dtype=torch.float32, device=dev)
-        self.scale = torch.tensor([float(scale)], dtype=torch.float32, device=dev)
-        # probe points in the unit cube (a shell around the centre, where an iso-surface would lie), their world positions,
-        # and fixed targets for the stand-in losses
+        self.init = {"density_thres": density_thres, "center": center, "scale": scale}
+        # probe points in the unit cube (a shell around the centre, where an iso-surface would lie) and fixed targets for the
+        # stand-in losses; their world positions follow from the Gaussian model's normalisation (bind())
         d = torch.randn(n_verts, 3, generator=gen)
         d = d / d.norm(dim=1, keepdim=True)
         self.probes = (0.5 + 0.25 * d * (1 + 0.1 * torch.randn(n_verts, 1, generator=gen))).clamp(0.02, 0.98).to(dev)
-        self.verts = ((self.probes * 2.0 - 1.0) * self.scale + self.center).contiguous()
+        self.verts = None
         self.phi_target = torch.zeros(n_verts, device=dev)
         self.color_target = torch.rand(n_verts, 3, generator=gen).to(dev)
-        self.optimizer = torch.optim.Adam([{"params": [self.density_thres], "lr": 0.001, "name": "density_thres"}], lr=0.0, eps=1e-15)
+
+    def bind(self, g):
+        """Applies the initial values to the Gaussian model and places the probe vertices in world space."""
+        with torch.no_grad():
+            if self.init["density_thres"] is not None:
+                g.density_thres_param.fill_(float(self.init["density_thres"]))
+            if self.init["center"] is not None:
+                g.gaussian_center = torch.tensor(self.init["center"], dtype=torch.float32, device=g.gaussian_center.device)
+            if self.init["scale"] is not None:
+                g.gaussian_scale = torch.tensor([float(self.init["scale"])], dtype=torch.float32, device=g.gaussian_scale.device)
+        self.verts = ((self.probes * 2.0 - 1.0) * g.gaussian_scale + g.gaussian_center).contiguous()
 
     def networks(self):
         return [self.deform_normal, self.deform_back_normal, self.appearance]
@@ -157,15 +167,16 @@ class Trainer:
             gaussians.get_xyz.is_cuda and render_fn is None and not is_6dof)
         dev = gaussians.get_xyz.device
         fused = (dev.type == "cuda") if fused_adam is None else fused_adam
+        if mesh is not None:
+            mesh.bind(gaussians)
         gaussians.training_setup(self.opt)
         deform.train_setting(self.opt)
         deform_back.train_setting(self.opt)
         self.optimizers = [gaussians.optimizer, deform.optimizer, deform_back.optimizer]
-        if mesh is not None:  # R/train.py:517-524: six optimizers (+ the density threshold's group)
+        if mesh is not None:  # R/train.py:517-524: six optimizers (the density threshold is the Gaussian optimizer's 8th group)
             for m in mesh.networks():
                 m.train_setting(self.opt)
                 self.optimizers.append(m.optimizer)
-            self.optimizers.append(mesh.optimizer)
         self.multi_adam = None
         if fused:  # same update rule, ONE kernel for every tensor of the three optimizers
             from .optim import MultiAdam
@@ -204,7 +215,7 @@ class Trainer:
         if self.mesh is not None:  # the five networks of SURVEY.md section 8(e)'s bucket, the normals, the density threshold
             for m in self.mesh.networks():
                 params += list(m.net.parameters())
-            params += [gaussians._normal, self.mesh.density_thres]
+            params += [gaussians._normal, gaussians.density_thres_param]
         self.params = [p for p in params if p.requires_grad]
         # "pack": gradients are fresh tensors every step (no accumulate kernels); "views": .grad lives in the bucket
         self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or self.world > 1) else None
@@ -316,7 +327,8 @@ class Trainer:
             d_xyz, d_rotation, d_scaling = 0.0, 0.0, 0.0
         else:
             N = g.get_xyz.shape[0]
-            time_input = self.time_input(cam, N, iteration)
+            time_input = self.time_input(cam, N, iteration)   # fid + this iteration's first noise sample (R/train.py:158-166)
+            t_back = self.time_input(cam, N, iteration)       # ... and its second one, for the backward networks (:208-216)
             if self.fused_glue:  # raw (N, 13) head output straight into the fused glue kernels (glue.py)
                 delta = self.deform.step_raw(g.get_xyz.detach(), time_input)
             if delta is None:
@@ -332,23 +344,23 @@ class Trainer:
                 # the deformation network's: twice the window to hide the exchange in.  Same values (the deformed means are
                 # the same fp32 sum the glue kernel forms; the two gradients of `delta` commute).
                 means = (g.get_xyz.detach() + delta.detach()[:, :3]).contiguous()
-                back = self.deform_back.step_raw(means, self.time_input(cam, N, iteration))
+                back = self.deform_back.step_raw(means, t_back)
                 losses["cycle_loss"] = cycle_loss(delta, back)
                 pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta, **lean)
             else:
                 pkg = self.render_fn(cam, g, self.pipe, self.bg, None, None, None, self.is_6dof, delta=delta, **lean)
-                back = self.deform_back.step_raw(pkg["means3D"].detach(), self.time_input(cam, N, iteration))
+                back = self.deform_back.step_raw(pkg["means3D"].detach(), t_back)
                 losses["cycle_loss"] = cycle_loss(delta, back)
         else:
             pkg = self.render_fn(cam, g, self.pipe, self.bg, d_xyz, d_rotation, d_scaling, self.is_6dof)
             if iteration >= opt.warm_up:
                 deformed_xyz = g.get_xyz + d_xyz
-                back = self.deform_back.step(deformed_xyz.detach(), self.time_input(cam, N, iteration))
+                back = self.deform_back.step(deformed_xyz.detach(), t_back)
                 cycle = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rotation) + S.l1_loss(-back[2], d_scaling)) / 3.0
                 losses["cycle_loss"] = cycle
         if self.mesh is not None and iteration >= opt.dpsr_iter:
             self.mesh_terms(cam, iteration, losses, pkg, delta if delta is not None else None,
-                            None if delta is not None else (d_xyz if iteration >= opt.warm_up else None))
+                            None if delta is not None else (d_xyz if iteration >= opt.warm_up else None), time_input, t_back)
         image = pkg["render"]
         gt = cam.original_image
         if image.is_cuda and self.fused_loss:  # same value, two HIP kernels instead of 5 convs + autograd
@@ -359,16 +371,17 @@ class Trainer:
             losses["img_loss"] = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - S.ssim(image, gt))
         return losses, pkg
 
-    def mesh_terms(self, cam, iteration, losses, pkg, delta, d_xyz):
-        """The mesh co-training additions of one iteration (see the module docstring); adds to `losses` in place."""
+    def mesh_terms(self, cam, iteration, losses, pkg, delta, d_xyz, t_fwd, t_back):
+        """The mesh co-training additions of one iteration (see the module docstring); adds to `losses` in place.  The normal
+        networks see the time inputs of their position networks -- deform_normal the deformation's noise sample, deform_back_normal
+        the backward network's (R/train.py:167-175, 225-228) -- and the vertex queries the noise-free fid (R/utils/renderer.py:177)."""
         g, opt, ms = self.g, self.opt, self.mesh
         N = g.get_xyz.shape[0]
         xyz_d = g.get_xyz.detach()
-        t_in = self.time_input(cam, N, iteration)
         normal_nets = iteration >= opt.dpsr_iter + opt.normal_deform_delay
-        d_normal = ms.deform_normal.step(xyz_d, t_in) if normal_nets else None          # R/train.py:170-175
+        d_normal = ms.deform_normal.step(xyz_d, t_fwd) if normal_nets else None         # R/train.py:170-175
         if normal_nets:                                                                   # R/train.py:225-235: cycle / 4
-            d_normal_back = ms.deform_back_normal.step(xyz_d, t_in)
+            d_normal_back = ms.deform_back_normal.step(xyz_d, t_back)
             l_n = S.l1_loss(-d_normal_back, d_normal)
             if "cycle_loss" in losses:
                 losses["cycle_loss"] = losses["cycle_loss"] * 0.75 + l_n * 0.25
@@ -380,19 +393,19 @@ class Trainer:
         dx = delta[:, :3] if delta is not None else d_xyz
         freeze_pos = iteration < opt.dpsr_iter + opt.normal_warm_up
         pts = (xyz_d + dx.detach()) if freeze_pos else (g.get_xyz + dx)
-        pts = ((pts - ms.center) / ms.scale) / 2.0 + 0.5
+        pts = ((pts - g.gaussian_center) / g.gaussian_scale) / 2.0 + 0.5
         pts = torch.clamp(pts, 1e-6, 1 - 1e-6)
         normals = g.get_normal + d_normal if d_normal is not None else g.get_normal
         psr = ms.dpsr(pts.unsqueeze(0), normals.unsqueeze(0))
         sign = torch.where(psr[0, 0, 0, 0].detach() < 0, -1.0, 1.0)                       # (no host read-back of the sign)
-        psr = psr * sign - ms.density_thres
+        psr = psr * sign - g.density_thres_param
         # stand-in for DiffMC -> nvdiffrast: phi at the V probe points; the probes act as the mesh vertices
         from .dpsr import grid_interp
         phi_v = grid_interp(psr.unsqueeze(-1), ms.probes.unsqueeze(0))[0, :, 0]
         # (stand-in losses carry a tiny weight: they exist to drive the chain's backward, not to shape the scene)
         losses["mask_loss"] = S.l1_loss(phi_v, ms.phi_target) * 100 * opt.mask_loss_weight * ms.stand_in_weight
         V = ms.verts.shape[0]
-        t_v = self.time_input(cam, V, iteration)
+        t_v = cam.fid.reshape(1, 1).expand(V, -1)
         back_v = self.deform_back.step(ms.verts, t_v)[0]                                  # R/utils/renderer.py:179-181
         vtx_color = ms.appearance.step(ms.verts + back_v, t_v)
         losses["mesh_img_loss"] = S.l1_loss(vtx_color, ms.color_target) * opt.mesh_img_loss_weight * (1e3 * ms.stand_in_weight)

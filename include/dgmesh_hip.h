@@ -143,6 +143,8 @@ typedef struct {
     size_t live;       /* u8[R] live[row] = 1 iff some pixel blended the instance, i.e. slab[row] was written by this backward */
     size_t ckpt;       /* float4[R/256 + 1][256]: (T, C.rgb) of a tile's pixels after each 256 list entries (forward ->
                           segment-parallel backward) */
+    size_t ckpt64;     /* float4[R/64 + 1][256]: tiles with <= 4096 list entries leave (T, C.rgb) after each 64 entries instead
+                          (slot (first + 64 i) / 64), so that the backward replays them in 64-entry units on more waves */
     size_t binning_bytes;
     /* image buffer */
     size_t final_T;   /* float[H*W] */
@@ -150,8 +152,6 @@ typedef struct {
     size_t ranges;    /* uint2[tiles] */
     size_t nproc;     /* u32[tiles] list entries the backward has to replay (deepest contributor of the tile) */
     size_t cfin;      /* float4[tiles][256]: final (T, C.rgb without background) per pixel, backward lane order */
-    size_t ckpt64;    /* float4[tiles][8][256]: tiles with <= 512 list entries also leave (T, C.rgb) after each 64 entries
-                         (slot i = state after 64 i entries, i = 1..7), so that the backward replays them in 64-entry units */
     size_t image_bytes;
     int tiles_x, tiles_y, n_chunks, chunk_size;
 } dgm_state_layout;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4, call F: 64-entry units up to 1024 entries; the row write / gather design matrix
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_raster.py tests/test_gpu_vs_reference.py -m gpu -x -q 2>&1 | tail -5
+for k in init trained; do
+  echo "== new $k"; timeout 300 python tools/raster_bench.py cfg2 --kind $k --iters 30 2>&1 | tail -1 | tee gpurun_out/r4_f_new_$k.json
+  for v in dg-mesh_amd/lib/variants/r4_*.so; do
+    [ -f "$v" ] || continue
+    echo "== $(basename $v .so) $k"; DGM_LIB_PATH=$v timeout 300 python tools/raster_bench.py cfg2 --kind $k --iters 30 2>&1 | tail -1 | tee gpurun_out/r4_f_$(basename $v .so)_$k.json
+  done
+done

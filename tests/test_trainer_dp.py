@@ -170,7 +170,13 @@ def test_mesh_phase_bucket_holds_the_five_networks():
     assert [count(m) for m in nets] == [523051, 523051, 520481, 520481, 520481]
     P = tr.g._xyz.shape[0]
     assert tr.grad_bytes() == 4 * (2607545 + 62 * P + 1)  # 62 floats per Gaussian: 59 of the splat + 3 of the normal
-    assert len(tr.optimizers) == 7  # R/train.py:517-524's six + the density threshold's group
+    assert len(tr.optimizers) == 6  # R/train.py:517-524's six; the density threshold is the Gaussian optimizer's 8th group,
+    names = [g["name"] for g in tr.g.optimizer.param_groups]  # scheduled 0.01 -> 1e-4 like the reference's (gaussian_model_*.py:201-229)
+    assert names[-1] == "density_thres" and len(names) == 8
+    tr.g.update_learning_rate(0)
+    lr0 = tr.g.optimizer.param_groups[-1]["lr"]
+    tr.g.update_learning_rate(tr.opt.position_lr_max_steps)
+    assert abs(tr.g.optimizer.param_groups[-1]["lr"] - 1e-4) < 1e-9 and abs(lr0 - 0.01) < 1e-9
 
 
 def test_mesh_phase_dp2_replicas_identical_and_all_networks_step():
