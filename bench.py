@@ -52,7 +52,7 @@ STEADY_STEPS = int(os.environ.get("DGM_BENCH_STEADY_STEPS", "200"))
 WORKLOAD = "cfg2"
 
 
-def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase="gs", dpsr_res=288, n_verts=60000):
+def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase="gs", dpsr_res=288, n_verts=60000, densify=False):
     syn = importlib.import_module("dg-mesh_amd.synthetic")
     S = importlib.import_module("dg-mesh_amd.scene")
     D = importlib.import_module("dg-mesh_amd.deform")
@@ -101,13 +101,44 @@ def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase=
         mesh = T.MeshPhase(dn, dbn, app, dpsr=DP.DPSR(res=(dpsr_res,) * 3, sig=2.0), n_verts=n_verts, scale=1.1 * extent, seed=seed,
                            device=dev)
     tr = T.Trainer(g, deform, deform_back, cams, background=bg, is_blender=c["is_blender"], rank=rank, world=world,
-                   seed=seed, mesh=mesh)
+                   seed=seed, mesh=mesh, densify=densify, cameras_extent=c.get("extent", 1.3))
     return tr, (P, W, H)
 
 
+def reference_host_modules():
+    """The reference's own `utils/time_utils.py` (DeformNetworkNormal) and `utils/loss_utils.py` (l1_loss, ssim), byte-compiled
+    by oracle/build_ref.sh where /root/reference exists (binaries only; they travel to the GPU box like the reference kernels).
+    None when they were not built."""
+    import importlib.machinery
+    import importlib.util
+    import types
+    root = os.path.join(ROOT, "oracle", "_ref", "pyref")
+    if not all(os.path.exists(os.path.join(root, f)) for f in ("time_utils.pyc", "loss_utils.pyc", "rigid_utils.pyc")):
+        return None
+    saved = {k: sys.modules.get(k) for k in ("utils", "utils.rigid_utils")}
+
+    def load(name, fname):
+        loader = importlib.machinery.SourcelessFileLoader(name, os.path.join(root, fname))
+        mod = importlib.util.module_from_spec(importlib.util.spec_from_loader(name, loader))
+        sys.modules[name] = mod
+        loader.exec_module(mod)
+        return mod
+    try:
+        sys.modules["utils"] = types.ModuleType("utils")
+        load("utils.rigid_utils", "rigid_utils.pyc")
+        return load("ref_time_utils", "time_utils.pyc"), load("ref_loss_utils", "loss_utils.pyc")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def cpu_baseline(P, W, H, max_threads=32):
-    """The same train step on the host: oracle rasterizer (C, OpenMP) + the MLPs on PyTorch-CPU.  One step of the
-    full cfg2 workload is the bounded sample."""
+    """The same train step on the host: the reference's own network and loss modules on PyTorch-CPU (this repo's torch
+    restatement of them only if the byte-compiled modules are absent) around the oracle rasterizer (C, OpenMP; the reference
+    has no CPU rasterizer).  A few steps of the full cfg2 workload are the bounded sample."""
     syn = importlib.import_module("dg-mesh_amd.synthetic")
     D = importlib.import_module("dg-mesh_amd.deform")
     S = importlib.import_module("dg-mesh_amd.scene")
@@ -121,7 +152,13 @@ def cpu_baseline(P, W, H, max_threads=32):
     cam = syn.config_camera(WORKLOAD, frame=0)
     gt = torch.tensor(syn.gt_image(W, H, 0))
     torch.manual_seed(0)
-    nets = [D.DeformNetworkNormal(is_blender=True, trunk_impl="torch") for _ in range(2)]
+    ref = reference_host_modules()
+    if ref is not None:
+        nets = [ref[0].DeformNetworkNormal(is_blender=True) for _ in range(2)]
+        l1_loss, ssim = ref[1].l1_loss, ref[1].ssim
+    else:
+        nets = [D.DeformNetworkNormal(is_blender=True, trunk_impl="torch") for _ in range(2)]
+        l1_loss, ssim = S.l1_loss, S.ssim
     with torch.no_grad():  # same small-deformation heads as the GPU workload (build_scene), so R is comparable
         for m in nets:
             for head in (m.gaussian_warp, m.gaussian_rotation, m.gaussian_scaling, m.gaussian_normal):
@@ -143,12 +180,12 @@ def cpu_baseline(P, W, H, max_threads=32):
         f = orc.forward(bg, a["means3D"], None, a["opacities"], a["scales"], a["rotations"], 1.0, None,
                         cam.world_view_transform, cam.full_proj_transform, tanx, tany, H, W, a["shs"], 3, cam.camera_center)
         img = torch.tensor(f["color"], requires_grad=True)
-        loss_img = 0.8 * S.l1_loss(img, gt) + 0.2 * (1.0 - S.ssim(img, gt))
+        loss_img = 0.8 * l1_loss(img, gt) + 0.2 * (1.0 - ssim(img, gt))
         loss_img.backward()
         gr = orc.backward(f, bg, a["means3D"], None, a["scales"], a["rotations"], 1.0, None, cam.world_view_transform,
                           cam.full_proj_transform, tanx, tany, img.grad.numpy(), a["shs"], 3, cam.camera_center)
         back = nets[1]((xyz + d_xyz).detach(), t_in)
-        cyc = (S.l1_loss(-back[0], d_xyz) + S.l1_loss(-back[1], d_rot) + S.l1_loss(-back[2], d_scale)) / 3.0
+        cyc = (l1_loss(-back[0], d_xyz) + l1_loss(-back[1], d_rot) + l1_loss(-back[2], d_scale)) / 3.0
         surrogate = (d_xyz * torch.tensor(gr["dL_dmeans3D"])).sum() + (d_rot * torch.tensor(gr["dL_drotations"])).sum() + \
             (d_scale * torch.tensor(gr["dL_dscales"])).sum()
         (cyc + surrogate).backward()
@@ -162,9 +199,13 @@ def cpu_baseline(P, W, H, max_threads=32):
         f = one_step()
         n_steps += 1
     dt = (time.time() - t0) / n_steps
-    return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": "port",
+    kind = "reference modules + oracle rasterizer" if ref is not None else "port"
+    what = ("the reference's DeformNetworkNormal x 2 fwd+bwd and its l1_loss / ssim (utils/time_utils.py, utils/loss_utils.py, "
+            "byte-compiled)" if ref is not None else "2 deformation MLPs fwd+bwd + L1/SSIM (this repo's torch restatement)")
+    return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": kind,
             "sample": f"{n_steps} full {WORKLOAD} train steps ({W}x{H}, P={P}, R={f['num_rendered']}): oracle rasterizer "
-                      f"fwd+bwd (C/OpenMP) + 2 deformation MLPs fwd+bwd + L1/SSIM + Adam on PyTorch-CPU, {dt:.1f} s each"}
+                      f"fwd+bwd (C/OpenMP; the reference has no CPU rasterizer) + {what} + torch.optim.Adam on PyTorch-CPU, "
+                      f"{dt:.1f} s each"}
 
 
 def trained_like_render_bwd(dev, iters=12):
@@ -207,7 +248,7 @@ def trained_like_render_bwd(dev, iters=12):
     ach = rb_bytes / (rb * 1e-3) / 1e9 if rb > 0 else 0.0
     ach_grp = grp_bytes / ((rb + pb) * 1e-3) / 1e9 if rb + pb > 0 else 0.0
     return {"scene": "trained-like (SURVEY.md 8d): shell r=0.8, sigma~0.01, opacity U[0.5,0.99]", "num_rendered": R,
-            "kernel": "render_bwd3_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "render_bwd4_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": rb_bytes, "avg_ms": rb,
             "group_with_preprocess_bwd": {"algorithmic_bytes": grp_bytes, "avg_ms": rb + pb, "achieved": ach_grp,
                                           "frac": ach_grp / HBM_PEAK_GBS},
@@ -226,7 +267,7 @@ def frac_valu_from_profiles():
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            for short in ("render_bwd3_kernel", "render_fwd_kernel"):
+            for short in ("render_bwd4_kernel", "render_fwd_kernel"):
                 if short in k and short not in out and "SQ_ACTIVE_INST_VALU" in v and "wall_cycles" in v:
                     # SQ_ACTIVE_INST_VALU: quad-cycles of VALU execution summed over waves; x4 cycles x 32 lanes per cycle
                     lane_ops = 4.0 * v["SQ_ACTIVE_INST_VALU"] * 32.0
@@ -399,6 +440,35 @@ def main():
         finally:
             L.lib().dgm_mlp_set_gemm(prev)
 
+    # densification inside a timed region (R/train.py:489-515: every 100 iterations clone / split / prune + optimizer surgery;
+    # the headline region times fixed-P steps only): a second trainer with densify=True, 200 steps that contain two such events
+    with_densify = None
+    if world == 1 and not args.no_extras and args.phase == "gs":
+        try:
+            tr2, _ = build_scene(dev, rank, world, mlp_impl, densify=True)
+            itd = tr2.opt.warm_up + 2000 + 1          # 5001: the first step is not a densification step
+            for i in range(8):
+                tr2.step(itd + i)
+            P0 = int(tr2.g.get_xyz.shape[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_d, events, P_path = 200, 0, [P0]
+            for i in range(n_d):
+                it = itd + 8 + i
+                tr2.step(it)
+                if it > tr2.opt.densify_from_iter and it % tr2.opt.densification_interval == 0:
+                    events += 1
+                    P_path.append(int(tr2.g.get_xyz.shape[0]))
+            torch.cuda.synchronize()
+            d_dt = time.perf_counter() - t0
+            with_densify = {"value": n_d / d_dt, "unit": "it/s", "ms_per_step": 1e3 * d_dt / n_d, "steps": n_d,
+                            "densify_events": events, "P": P_path,
+                            "note": "densify_and_prune every 100 iterations inside the timed region (amortised); P changes at "
+                                    "each event, so the steps after it are not the headline's workload"}
+            del tr2
+        except Exception as ex:  # an extra must never take the headline down
+            with_densify = {"error": str(ex)}
+
     trained = None
     if rank == 0 and world == 1 and not args.no_extras and args.phase == "gs":
         try:
@@ -445,7 +515,7 @@ def main():
             # backward data + weight gradient of one layer in one launch (plane arithmetic): G_l read once algorithmically
             "mlp_bwd_pair": ("mlp_bwd_pair_kernel (256->256 backward-data on part of the CUs + 256x256 weight gradient on the rest)",
                              2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r03_pmc_bwd_pair.json"),
-            "render_bwd": ("render_bwd3_kernel", 0.0, alg_bytes, "pmc_render_bwd3.json"),
+            "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r04_pmc_render_bwd4.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
             "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
             "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 48.0 * n_inst, None),
@@ -485,14 +555,15 @@ def main():
                                         "split once by the producer, 3 MFMAs per product" if planes else
                                         "f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
                                         if f16x3 else "bf16x6: 3 bf16 planes, 6 MFMAs per product")})
-        rb_traffic, rb_src = pmc_traffic("pmc_render_bwd3.json")
+        rb_traffic, rb_src = pmc_traffic("r04_pmc_render_bwd4.json")
         out = {
             "metric": ("train-step iters/sec (800x800, ~100k Gaussians)" if WORKLOAD == "cfg2"
                        else f"train-step iters/sec ({WORKLOAD}: {W}x{H}, P={P}; informational, the metric is quoted on cfg2)"),
             "value": args.steps * world / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("f32 (f16x3p split products, fp32 accumulate)" if mlp_impl == "hip" and gemm_mode == 3 else
+                                          "f32 (native fp32 MFMA)" if gemm_mode == 1 else "f32"), "data": "synthetic",
             "phase": ("dynamic Gaussian splatting (deform + deform_back)" if args.phase == "gs" else
                       f"mesh co-training: deform, deform_normal, deform_back, deform_back_normal on P + DPSR {args.dpsr_res}^3 (splat, "
                       f"spectral solve, read-back, adjoints) + deform_back and appearance on V={args.verts} vertices; DPSR step included, "
@@ -508,7 +579,7 @@ def main():
             "roofline": roof,
             # the rasterizer backward, graded against HBM by BASELINE.json's north_star (VALU-bound in practice:
             # profiles/*pmc_sq*.json)
-            "roofline_render_bwd": {"kernel": "render_bwd3_kernel", "bound": "hbm", "achieved": achieved,
+            "roofline_render_bwd": {"kernel": "render_bwd4_kernel", "bound": "hbm", "achieved": achieved,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                     "traffic": rb_traffic, "algorithmic_bytes": alg_bytes, "avg_ms": bwd_ms,
                                     "launches": bwd_n},
@@ -526,10 +597,12 @@ def main():
             out["allreduce"] = allreduce
         if f32_mode is not None:
             out["mlp_f32_mode"] = f32_mode
+        if with_densify is not None:
+            out["with_densify"] = with_densify
         if trained is not None:
             out["roofline_render_bwd_trained"] = trained
         fv = frac_valu_from_profiles()
-        for short, st_name in (("render_bwd3_kernel", "render_bwd"), ("render_fwd_kernel", "render_fwd")):
+        for short, st_name in (("render_bwd4_kernel", "render_bwd"), ("render_fwd_kernel", "render_fwd")):
             if short in fv and st_name in out["kernels"]:  # against the 2.4 GHz peak: 256 CU x 4 SIMD x 32 lanes = 78.6 T lane-op/s
                 fv[short]["frac_valu"] = fv[short]["valu_lane_ops_per_launch"] / (out["kernels"][st_name]["avg_ms"] * 1e-3 * 78.6e12)
         if fv:

@@ -38,7 +38,10 @@ out = sys.argv[1]
 os.makedirs(out, exist_ok=True)
 R = "/root/reference/dgmesh"
 for src, name in ((R + "/gaussian_renderer/__init__.py", "gaussian_renderer.pyc"), (R + "/utils/sh_utils.py", "sh_utils.pyc"),
-                  (R + "/utils/rigid_utils.py", "rigid_utils.pyc")):
+                  (R + "/utils/rigid_utils.py", "rigid_utils.pyc"),
+                  # the networks and the image loss of the train step, for bench.py's cpu_baseline leg (the reference's own modules
+                  # on the host cores; pure torch, they import nothing but utils.rigid_utils)
+                  (R + "/utils/time_utils.py", "time_utils.pyc"), (R + "/utils/loss_utils.py", "loss_utils.pyc")):
     py_compile.compile(src, cfile=os.path.join(out, name), dfile=os.path.basename(src), doraise=True)
 print("build_ref: wrote pyref/", sorted(os.listdir(out)))
 PY

@@ -11,7 +11,7 @@ import sys
 
 fetch_csv, write_csv, out_dir, workload = sys.argv[1:5]
 KERNELS = {"gemm3r_fwd": "mlp_gemm3p_kernel<0, false>", "gemm3r_bwd": "mlp_gemm3p_kernel<1, false>", "dw3b": "mlp_dw3b_kernel",
-           "render_bwd3": "render_bwd3_kernel", "render_fwd": "render_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
+           "render_bwd4": "render_bwd4_kernel", "render_fwd": "render_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
            "tile_sort_radix": "tile_sort_radix_kernel", "heads_bwd": "mlp_heads_bwd_kernel", "reduce_dw": "mlp_reduce_dw_all_kernel",
            "dw3e_352": "mlp_dw3e_kernel<11>", "dw3e_96": "mlp_dw3e_kernel<3>", "gemm3p_skip": "mlp_gemm3p_kernel<2, false>",
            "gemm3r_dual": "mlp_gemm3r_kernel<0, 6, 1, true>", "scatter": "dgm::scatter_kernel",
@@ -21,7 +21,7 @@ KERNELS = {"gemm3r_fwd": "mlp_gemm3p_kernel<0, false>", "gemm3r_bwd": "mlp_gemm3
            "gemm4_l0": "mlp_gemm4_kernel<6, 384, 192, 0, true, 8>", "dw4_emb": "mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>",
            "embed4": "mlp_embed4_kernel", "bwd_pair": "mlp_bwd_pair_kernel"}
 # kernels whose reads are gathers of short records: the x2 streaming-read correction of FETCH_SIZE is not calibrated for them
-GATHER = {"render_bwd3", "render_fwd", "preprocess_bwd", "tile_sort_radix", "scatter"}
+GATHER = {"render_bwd4", "render_fwd", "preprocess_bwd", "tile_sort_radix", "scatter"}
 
 
 def per_kernel(path, counter):
