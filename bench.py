@@ -89,11 +89,11 @@ def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase=
         # mesh co-training phase (R/train.py:165-176, 243-285): the two normal networks on the P Gaussians, DPSR on the deformed
         # points (grid dpsr_res^3), deform_back + appearance on V vertices.  DiffMC / nvdiffrast are third-party and not
         # rebuilt: phi is probed at V fixed points that stand in for the mesh vertices (trainer.py).  The appearance network
-        # differentiates w.r.t. its input (vertex positions moved by deform_back), which the fused trunk does not: PyTorch trunk.
+        # differentiates w.r.t. its input (vertex positions moved by deform_back): dgm_mlp_backward_dx of the fused trunk.
         DP = importlib.import_module("dg-mesh_amd.dpsr")
         dn = D.DeformModelNormalSep(is_blender=c["is_blender"], model_name="deform_normal", device=dev, trunk_impl=mlp_impl)
         dbn = D.DeformModelNormalSep(is_blender=c["is_blender"], model_name="deform_back_normal", device=dev, trunk_impl=mlp_impl)
-        app = D.AppearanceModel(is_blender=c["is_blender"], device=dev, trunk_impl="torch")
+        app = D.AppearanceModel(is_blender=c["is_blender"], device=dev, trunk_impl=mlp_impl)
         with torch.no_grad():
             for m in (dn, dbn):  # zero-initialised head in the reference (time_utils.py:248-249): small but non-zero here
                 torch.nn.init.normal_(m.net.gaussian_normal.weight, std=1e-3)

@@ -88,6 +88,7 @@ SYMBOLS = {
     "dgm_mlp_describe_workspace": (_i, [_i, _c.POINTER(_c.c_size_t), _i]),
     "dgm_mlp_forward": (_i, [_c.POINTER(MlpParams), _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_mlp_backward": (_i, [_c.POINTER(MlpParams), _i, _vp, _i, _vp, _vp * 8, _vp * 8, _vp, _vp, _vp, _vp]),
+    "dgm_mlp_backward_dx": (_i, [_c.POINTER(MlpParams), _i, _vp, _i, _vp, _vp * 8, _vp * 8, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _LIB = None

@@ -1097,7 +1097,7 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
 }
 
 int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws& w, float* const* dW, float* const* db, float* dWh,
-                    float* dbh, float* dtemb, hipStream_t st) {
+                    float* dbh, float* dtemb, hipStream_t st, const float* x_in = nullptr, float* dX = nullptr) {
     const P4Plan pl = p4_plan(N);
     const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
     const int sk = p->skip_layer;
@@ -1150,6 +1150,9 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
             a.A = G, a.Aexp = Ge, a.Bp = w.Wd3[l], a.b_inv = w.wsc_d[l], a.mask_in = w.mask[l - 1], a.C = Gn, a.Cexp = Gne;
         }
         d.G = G, d.Gexp = Ge;
+        if (dX && (l == sk || l == 0))  // gradient w.r.t. the positions: G_5 W_5[:, :63] into scratch (the forward's Cin, idle now), then + G_0 W_0[:, :63] and PE'
+            hipLaunchKernelGGL(mlp_dx4_kernel, dim3(nt), dim3(256), 0, st, N, (const unsigned char*)G, (const int*)Ge, p->W[l],
+                               layer_in(p, l), reinterpret_cast<float*>(w.Cin), l == 0 ? 1 : 0, x_in, dX);
         // partial tiles of the layer: [chunk][Kp][256]; paired skip layer: trunk rows [n_dw][256][256], then embedding rows [chunks][96][256]
         float* part_emb = w.partial_l[l];
         float* part_trunk = w.partial_l[l] + (l == sk ? (size_t)MLP_EMB * MLP_W : 0);
@@ -1388,10 +1391,18 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
 
 int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace, float* const* dW,
                      float* const* db, float* dWh, float* dbh, float* dtemb, void* stream) {
+    return dgm_mlp_backward_dx(p, N, dOut, temb_stride, workspace, dW, db, dWh, dbh, dtemb, nullptr, nullptr, stream);
+}
+
+int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace, float* const* dW,
+                        float* const* db, float* dWh, float* dbh, float* dtemb, const float* x, float* dX, void* stream) {
     if (check_params(p)) return 1;
     if (N <= 0) return 0;
     if (!dOut || !workspace || !dW || !db || !dWh || !dbh) return mlp_fail("mlp_backward: NULL pointer");
+    if ((x == nullptr) != (dX == nullptr)) return mlp_fail("mlp_backward: x and dX come together");
     const int mode = effective_mode(temb_stride, N);
+    if (dX && mode != 3)
+        return mlp_fail("mlp_backward: the gradient w.r.t. the positions exists in the plane arithmetic only (f16x3p, broadcast time row)");
     {
         const int fm = recall_ws_mode(workspace);
         if (fm >= 0 && fm != mode)
@@ -1399,7 +1410,7 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
     }
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
-    if (mode == 3) return backward_planes(p, N, dOut, w, dW, db, dWh, dbh, dtemb, st);
+    if (mode == 3) return backward_planes(p, N, dOut, w, dW, db, dWh, dbh, dtemb, st, x, dX);
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
     const int grid = (N + GM - 1) / GM;
     const bool f32 = mode == 1;

@@ -1039,4 +1039,85 @@ mlp_bwd_pair_kernel(const Gemm4Args ga, const Dw4Args da, const int n_dw, const 
     }
 }
 
+// ---- gradient w.r.t. the positions -------------------------------------------------------------------------------------------
+// dL/dx of the trunk: the embedding PE(x) feeds layer 0 and (skip) layer 5, so dL/dPE = G_0 W_0[:, :63] + G_5 W_5[:, :63] and
+// dL/dx_d = dPE[d] + sum_k 2^k (cos(2^k x_d) dPE[3 + 6 k + d] - sin(2^k x_d) dPE[6 + 6 k + d])        (R/utils/time_utils.py:30-55).
+// Needed where a network's INPUT carries a gradient: the appearance network on mesh vertices moved by deform_back
+// (R/utils/renderer.py:179-181).  Two launches of one kernel, when G_5 / G_0 are the live gradient buffer: the first writes
+// G_5 W_5[:, :63] per row (fp32, 64 floats) to a scratch area, the second adds G_0 W_0[:, :63] and applies the derivative of PE.
+// G is in plane format; the products run in fp32 on the vector ALU: K = 256, 63 columns -- 2 x 3.3 GFLOP at N = 100 k, a small
+// fraction of a network pass, and the vertex count of the mesh phase is smaller still.  One 32-row tile per workgroup, thread
+// (ty, tx) owns rows {2 ty, 2 ty + 1} x columns {4 tx .. 4 tx + 3}; G and W go through LDS in K chunks of 32.
+__global__ void __launch_bounds__(256)
+mlp_dx4_kernel(int N, const unsigned char* __restrict__ G, const int* __restrict__ Gexp, const float* __restrict__ W, int in_features,
+               float* __restrict__ scratch, int finish, const float* __restrict__ x, float* __restrict__ dX) {
+    __shared__ float sG[32][32 + 1];
+    __shared__ float sW[32][64 + 1];
+    __shared__ float sE[32][64 + 1];
+    const int tile = blockIdx.x, r0 = tile * 32, tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    const float scale = __builtin_ldexpf(1.0f, -Gexp[tile]);  // value = (h + l) * 2^-e
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int k0 = 0; k0 < 256; k0 += 32) {
+        {   // G chunk: 32 rows x 32 k, h + l   (thread: row tid / 8, four k)
+            const int r = tid >> 3, kk = (tid & 7) * 4;
+            const unsigned char* row = G + (size_t)(r0 + r) * 1024;
+            const uint2 h = *reinterpret_cast<const uint2*>(row + (k0 + kk) * 2);
+            const uint2 l = *reinterpret_cast<const uint2*>(row + 512 + (k0 + kk) * 2);
+            const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+            const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
+            sG[r][kk + 0] = (float)h0[0] + (float)l0[0];
+            sG[r][kk + 1] = (float)h0[1] + (float)l0[1];
+            sG[r][kk + 2] = (float)h1[0] + (float)l1[0];
+            sG[r][kk + 3] = (float)h1[1] + (float)l1[1];
+        }
+        for (int i = tid; i < 32 * 64; i += 256) {  // W chunk: rows k0 .. k0 + 31 (output units), columns 0 .. 62 (+ one zero)
+            const int kk = i >> 6, c = i & 63;
+            sW[kk][c] = c < 63 ? W[(size_t)(k0 + kk) * in_features + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; kk++) {
+            const float g0 = sG[2 * ty][kk], g1 = sG[2 * ty + 1][kk];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float wv = sW[kk][4 * tx + c];
+                acc[0][c] = fmaf(g0, wv, acc[0][c]);
+                acc[1][c] = fmaf(g1, wv, acc[1][c]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int r = r0 + 2 * ty + e;
+        float4 v = make_float4(acc[e][0] * scale, acc[e][1] * scale, acc[e][2] * scale, acc[e][3] * scale);
+        float4* sp = reinterpret_cast<float4*>(scratch + (size_t)r * 64 + 4 * tx);  // (rows are padded to whole tiles)
+        if (finish) {
+            const float4 p = *sp;
+            v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+            sE[2 * ty + e][4 * tx + 0] = v.x, sE[2 * ty + e][4 * tx + 1] = v.y, sE[2 * ty + e][4 * tx + 2] = v.z, sE[2 * ty + e][4 * tx + 3] = v.w;
+        } else {
+            *sp = v;
+        }
+    }
+    if (!finish) return;
+    __syncthreads();
+    if (tid < 96) {
+        const int rl = tid / 3, d = tid - 3 * rl, r = r0 + rl;
+        if (r < N) {
+            const float xv = x[3 * r + d];
+            float g = sE[rl][d];
+#pragma unroll
+            for (int q = 0; q < 10; q++) {
+                float sn, cs;
+                const float f = (float)(1 << q);
+                sincosf(xv * f, &sn, &cs);
+                g += f * (cs * sE[rl][3 + 6 * q + d] - sn * sE[rl][6 + 6 * q + d]);
+            }
+            dX[3 * r + d] = g;
+        }
+    }
+}
+
 }  // namespace dgm

@@ -60,8 +60,9 @@ def pack_heads(heads):
 
 
 class _MLPFunction(torch.autograd.Function):
-    """inputs: x (N,3) [no grad], t_emb ((1,T) when broadcast else (N,T)), the number of heads n, then the n head weights,
-    the n head biases, W0..W7, b0..b7."""
+    """inputs: x (N,3), t_emb ((1,T) when broadcast else (N,T)), the number of heads n, then the n head weights, the n head
+    biases, W0..W7, b0..b7.  x gets a gradient when it asks for one (dgm_mlp_backward_dx: the appearance network on mesh
+    vertices moved by deform_back, R/utils/renderer.py:179-181); the training loop's networks detach it (R/train.py:156)."""
 
     @staticmethod
     def forward(ctx, x, t_emb, bcast, n_heads, *tensors):
@@ -79,14 +80,14 @@ class _MLPFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(L.dgm_mlp_forward(ctypes.byref(p), N, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(t_emb.data_ptr()),
                                          0 if bcast else T, ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), st))
-        ctx.save_for_backward(ws, Wh, bh, *W, *b)
+        ctx.save_for_backward(ws, Wh, bh, x, *W, *b)
         ctx.meta = (N, T, bool(bcast), t_emb.requires_grad, [w.shape[0] for w in hw])
         return out
 
     @staticmethod
     def backward(ctx, dOut):
         L = _lib.lib()
-        ws, Wh, bh, *wb = ctx.saved_tensors
+        ws, Wh, bh, x, *wb = ctx.saved_tensors
         W, b = wb[:8], wb[8:]
         N, T, bcast, need_t, head_rows = ctx.meta
         dOut = dOut.contiguous()
@@ -100,13 +101,21 @@ class _MLPFunction(torch.autograd.Function):
         dWp = arr(*[t.data_ptr() for t in dW])
         dbp = arr(*[t.data_ptr() for t in db])
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dX = None
         with torch.cuda.device(dev):
-            _lib.check(L.dgm_mlp_backward(ctypes.byref(p), N, ctypes.c_void_p(dOut.data_ptr()), 0 if bcast else T,
-                                          ctypes.c_void_p(ws.data_ptr()), dWp, dbp, ctypes.c_void_p(dWh.data_ptr()),
-                                          ctypes.c_void_p(dbh.data_ptr()), ctypes.c_void_p(dtemb.data_ptr()), st))
+            if ctx.needs_input_grad[0]:
+                dX = torch.empty((N, 3), dtype=torch.float32, device=dev)
+                _lib.check(L.dgm_mlp_backward_dx(ctypes.byref(p), N, ctypes.c_void_p(dOut.data_ptr()), 0 if bcast else T,
+                                                 ctypes.c_void_p(ws.data_ptr()), dWp, dbp, ctypes.c_void_p(dWh.data_ptr()),
+                                                 ctypes.c_void_p(dbh.data_ptr()), ctypes.c_void_p(dtemb.data_ptr()),
+                                                 ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dX.data_ptr()), st))
+            else:
+                _lib.check(L.dgm_mlp_backward(ctypes.byref(p), N, ctypes.c_void_p(dOut.data_ptr()), 0 if bcast else T,
+                                              ctypes.c_void_p(ws.data_ptr()), dWp, dbp, ctypes.c_void_p(dWh.data_ptr()),
+                                              ctypes.c_void_p(dbh.data_ptr()), ctypes.c_void_p(dtemb.data_ptr()), st))
         # the heads' gradients: row blocks of the two stacked buffers (contiguous views, no copies)
         dWs, dbs = torch.split(dWh, head_rows, 0), torch.split(dbh, head_rows, 0)
-        return (None, dtemb if need_t else None, None, None, *dWs, *dbs, *dW, *db)
+        return (dX, dtemb if need_t else None, None, None, *dWs, *dbs, *dW, *db)
 
 
 class _TimeNetFunction(torch.autograd.Function):
@@ -175,9 +184,9 @@ def check_supported(net, heads, t_emb):
 def network_forward(net, heads, x, t_emb, bcast):
     if not x.is_cuda:
         raise RuntimeError("trunk_impl='hip' needs CUDA/HIP tensors (dg-mesh_amd has no CPU path for its kernels)")
-    if x.requires_grad:
-        raise RuntimeError("trunk_impl='hip' does not differentiate w.r.t. the positions (the training loop detaches them, "
-                           "R/train.py:156); pass xyz.detach() or use trunk_impl='torch'")
+    if x.requires_grad and not bcast:
+        raise RuntimeError("trunk_impl='hip' differentiates w.r.t. the positions only with a broadcast time row (the plane "
+                           "arithmetic); use trunk_impl='torch' for per-row time inputs")
     check_supported(net, heads, t_emb)
     W = [l.weight for l in net.linear]
     b = [l.bias for l in net.linear]

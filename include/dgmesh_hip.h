@@ -241,6 +241,13 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
  * ((t_dim) summed over rows when temb_stride == 0, else (N, t_dim)); dtemb may be NULL. */
 int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace,
                      float* const* dW, float* const* db, float* dWh, float* dbh, float* dtemb, void* stream);
+/* The same, plus dX (N, 3) = dL/dx through both uses of PE(x) (layer 0 and the skip layer) and the derivative of the positional
+ * encoding; x is the forward pass's input.  For networks whose input carries a gradient -- the appearance network on mesh
+ * vertices moved by deform_back (dgmesh/utils/renderer.py:179-181, dgmesh/utils/time_utils.py:269-323).  x and dX may both be
+ * NULL (= dgm_mlp_backward).  Plane arithmetic (the default) only: other modes return an error rather than drop the gradient. */
+int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace,
+                        float* const* dW, float* const* db, float* dWh, float* dbh, float* dtemb, const float* x, float* dX,
+                        void* stream);
 
 /* The time branch of the is_blender networks for ONE row (t is identical for every Gaussian of an iteration,
  * dgmesh/train.py:158): out (n_out) = W2 relu(W1 PE(t) + b1) + b2 with PE(t) = [t, sin(2^k t), cos(2^k t), k < n_freq]

@@ -138,7 +138,7 @@ def make_mesh_trainer(rank, world, res=48, n_verts=4000, **kw):
     torch.manual_seed(7)
     dn = D.DeformModelNormalSep(is_blender=True, model_name="deform_normal", device=dev, trunk_impl="hip")
     dbn = D.DeformModelNormalSep(is_blender=True, model_name="deform_back_normal", device=dev, trunk_impl="hip")
-    app = D.AppearanceModel(is_blender=True, device=dev, trunk_impl="torch")  # differentiates w.r.t. its input: PyTorch trunk
+    app = D.AppearanceModel(is_blender=True, device=dev, trunk_impl="hip")  # differentiates w.r.t. its input (dgm_mlp_backward_dx)
     with torch.no_grad():
         for m in (dn, dbn):
             torch.nn.init.normal_(m.net.gaussian_normal.weight, std=0.02)
