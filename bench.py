@@ -514,7 +514,7 @@ def main():
             "mlp_layer_dw": (kn[2], layer_flops, dw_bytes, pm[2]),
             # backward data + weight gradient of one layer in one launch (plane arithmetic): G_l read once algorithmically
             "mlp_bwd_pair": ("mlp_bwd_pair_kernel (256->256 backward-data on part of the CUs + 256x256 weight gradient on the rest)",
-                             2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r03_pmc_bwd_pair.json"),
+                             2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r04_pmc_bwd_pair.json"),
             "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r04_pmc_render_bwd4.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
             "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
@@ -616,9 +616,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         if WORKLOAD == "cfg2":  # informational, offline: the reference's own step on this GPU model (a -m gpu test measures it)
             try:
-                r = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_vs_ours_step.json")))
+                r = json.load(open(os.path.join(ROOT, "profiles", "r04_ref_vs_ours_step.json")))
                 out["reference_same_gpu"] = {"value": r["reference_shaped_it_s"], "unit": "it/s",
-                                             "source": "profiles/r02_ref_vs_ours_step.json (committed measurement of "
+                                             "source": "profiles/r04_ref_vs_ours_step.json (committed measurement of "
                                                        "tests/test_gpu_vs_reference.py, not taken in this run)"}
             except Exception:
                 pass

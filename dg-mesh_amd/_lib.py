@@ -127,6 +127,33 @@ def lib():
     return _LIB
 
 
+def stream_ptr():
+    """Raw handle of torch's current stream on the current device, as the C ABI takes it (torch.cuda.current_stream() builds a
+    Stream object through three Python layers: ~11 us, and the step asks ~10 times)."""
+    import torch
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """`with torch.cuda.device(device)` when `device` is not already current; nothing otherwise (the common case)."""
+    import torch
+    idx = device.index
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
 def check(status):
     if status != 0:
         raise RuntimeError(lib().dgm_last_error().decode() or "libdgmesh_hip error")

@@ -29,14 +29,14 @@ def _vp(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.stream_ptr()
 
 
 def _decide(g, P, keep_mask=None, args=None):
     L = _lib.lib()
     dev = g._xyz.device
     scratch = torch.empty(L.dgm_densify_scratch_bytes(P), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         if keep_mask is not None:
             km = keep_mask.to(torch.uint8).contiguous()
             _lib.check(L.dgm_densify_decide(P, None, None, None, None, 0.0, 0.0, 0.0, 0.0, _vp(km), _vp(scratch), _stream()))
@@ -77,7 +77,7 @@ def _apply(g, P, scratch, K, C, S, z):
     VP = ctypes.c_void_p * n
     if Pn > 0:
         src = torch.empty(Pn, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(L.dgm_densify_apply(
                 P, K, C, S, _vp(scratch), _vp(src), n, VP(*[e[2].data_ptr() for e in entries]),
                 VP(*[e[3].data_ptr() for e in entries]),

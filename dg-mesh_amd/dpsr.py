@@ -20,7 +20,7 @@ def _vp(t):
 
 
 def _st():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.stream_ptr()
 
 
 def _chk_pts(pts):
@@ -34,7 +34,7 @@ class _Splat(torch.autograd.Function):
         _chk_pts(V), _chk_pts(N)
         V, N = V.contiguous(), N.contiguous()
         grid = torch.empty((3, res, res, res), dtype=torch.float32, device=V.device)
-        with torch.cuda.device(V.device):
+        with _lib.device_guard(V.device):
             _lib.check(_lib.lib().dgm_dpsr_splat_forward(V.shape[0], res, _vp(V), _vp(N), _vp(grid), _st()))
         ctx.save_for_backward(V, N)
         ctx.res = res
@@ -45,7 +45,7 @@ class _Splat(torch.autograd.Function):
         V, N = ctx.saved_tensors
         dgrid = dgrid.contiguous()
         dV, dN = torch.empty_like(V), torch.empty_like(N)
-        with torch.cuda.device(V.device):
+        with _lib.device_guard(V.device):
             _lib.check(_lib.lib().dgm_dpsr_splat_backward(V.shape[0], ctx.res, _vp(V), _vp(N), _vp(dgrid), _vp(dV), _vp(dN), _st()))
         return dV, dN, None
 
@@ -56,7 +56,7 @@ class _Interp(torch.autograd.Function):
         _chk_pts(V)
         phi, V = phi.contiguous(), V.contiguous()
         fv = torch.empty(V.shape[0], dtype=torch.float32, device=V.device)
-        with torch.cuda.device(V.device):
+        with _lib.device_guard(V.device):
             _lib.check(_lib.lib().dgm_dpsr_interp_forward(V.shape[0], phi.shape[0], _vp(phi), _vp(V), _vp(fv), _st()))
         ctx.save_for_backward(phi, V)
         return fv
@@ -66,7 +66,7 @@ class _Interp(torch.autograd.Function):
         phi, V = ctx.saved_tensors
         dfv = dfv.contiguous()
         dphi, dV = torch.empty_like(phi), torch.empty_like(V)
-        with torch.cuda.device(V.device):
+        with _lib.device_guard(V.device):
             _lib.check(_lib.lib().dgm_dpsr_interp_backward(V.shape[0], phi.shape[0], _vp(phi), _vp(V), _vp(dfv), _vp(dphi), _vp(dV), _st()))
         return dphi, dV
 
@@ -78,7 +78,7 @@ class _Spectral(torch.autograd.Function):
     def forward(ctx, ras_s, res, sig):
         x = torch.view_as_real(ras_s.contiguous()).contiguous()          # (3, R, R, R/2+1, 2)
         out = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _lib.check(_lib.lib().dgm_dpsr_spectral(res, float(sig), _vp(x), _vp(out), 0, _st()))
         ctx.res, ctx.sig = res, float(sig)
         return torch.view_as_complex(out)
@@ -87,7 +87,7 @@ class _Spectral(torch.autograd.Function):
     def backward(ctx, dPhi):
         g = torch.view_as_real(dPhi.contiguous()).contiguous()
         out = torch.empty((3,) + tuple(g.shape), dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.device_guard(g.device):
             _lib.check(_lib.lib().dgm_dpsr_spectral(ctx.res, ctx.sig, _vp(g), _vp(out), 1, _st()))
         return torch.view_as_complex(out), None, None
 

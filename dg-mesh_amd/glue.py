@@ -17,7 +17,7 @@ def _vp(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.stream_ptr()
 
 
 def _f32c(t, name):
@@ -37,7 +37,7 @@ class _GaussianApply(torch.autograd.Function):
             raise RuntimeError("gaussian_apply: delta must be (P, >= 10): [d_xyz | d_rotation | d_scaling | ...]")
         means, scales = torch.empty_like(xyz), torch.empty_like(scaling)
         rots, opac = torch.empty_like(rotation), torch.empty_like(opacity)
-        with torch.cuda.device(xyz.device):
+        with _lib.device_guard(xyz.device):
             _lib.check(L.dgm_gaussian_apply_forward(P, _vp(xyz), _vp(scaling), _vp(rotation), _vp(opacity), _vp(delta), ld,
                                                     _vp(means), _vp(scales), _vp(rots), _vp(opac), _stream()))
         ctx.save_for_backward(scaling, rotation, opacity)
@@ -55,7 +55,7 @@ class _GaussianApply(torch.autograd.Function):
         d_xyz, d_scaling = torch.empty_like(scaling), torch.empty_like(scaling)
         d_rotation, d_opacity = torch.empty_like(rotation), torch.empty_like(opacity)
         d_delta = torch.empty((P, ld), dtype=torch.float32, device=scaling.device)
-        with torch.cuda.device(scaling.device):
+        with _lib.device_guard(scaling.device):
             _lib.check(L.dgm_gaussian_apply_backward(P, _vp(scaling), _vp(rotation), _vp(opacity), _vp(g_means), _vp(g_scales),
                                                      _vp(g_rots), _vp(g_opac), _vp(d_xyz), _vp(d_scaling), _vp(d_rotation),
                                                      _vp(d_opacity), _vp(d_delta), ld, _stream()))
@@ -77,7 +77,7 @@ class _CycleLoss(torch.autograd.Function):
         N, ld = a.shape
         ws = torch.empty(L.dgm_cycle_loss_workspace_bytes(N), dtype=torch.uint8, device=a.device)
         out = torch.empty(4, dtype=torch.float32, device=a.device)
-        with torch.cuda.device(a.device):
+        with _lib.device_guard(a.device):
             _lib.check(L.dgm_cycle_loss_forward(N, _vp(a), _vp(b), ld, _vp(ws), _vp(out), _stream()))
         ctx.save_for_backward(a, b)
         return out[0]
@@ -89,7 +89,7 @@ class _CycleLoss(torch.autograd.Function):
         N, ld = a.shape
         g = g.contiguous().float().reshape(1)
         d_a, d_b = torch.empty_like(a), torch.empty_like(b)
-        with torch.cuda.device(a.device):
+        with _lib.device_guard(a.device):
             _lib.check(L.dgm_cycle_loss_backward(N, _vp(a), _vp(b), ld, _vp(g), _vp(d_a), _vp(d_b), _stream()))
         return d_a, d_b
 

@@ -15,7 +15,7 @@ def distCUDA2(points):
     pts = points.contiguous().float()
     means = torch.zeros((P,), dtype=torch.float32, device=points.device)  # torch::full({P}, 0.0), spatial.cu:21
     if P:
-        with torch.cuda.device(points.device):
+        with _lib.device_guard(points.device):
             _lib.check(_lib.lib().dgm_knn_mean_dist2(P, ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(means.data_ptr()),
-                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                                     _lib.stream_ptr()))
     return means

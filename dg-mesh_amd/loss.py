@@ -15,11 +15,11 @@ class _ImageLoss(torch.autograd.Function):
         C, H, W = image.shape
         ws = torch.empty(L.dgm_image_loss_workspace_bytes(C, H, W), dtype=torch.uint8, device=image.device)
         out = torch.empty(3, dtype=torch.float32, device=image.device)
-        with torch.cuda.device(image.device):
+        with _lib.device_guard(image.device):
             _lib.check(L.dgm_image_loss_forward(
                 ctypes.c_void_p(image.data_ptr()), ctypes.c_void_p(gt.data_ptr()), C, H, W, float(lambda_dssim),
                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                _lib.stream_ptr()))
         ctx.save_for_backward(image, gt, ws)
         ctx.lam = float(lambda_dssim)
         return out[0]
@@ -31,11 +31,11 @@ class _ImageLoss(torch.autograd.Function):
         C, H, W = image.shape
         g = grad_out.contiguous().float().reshape(1)
         d_image = torch.empty_like(image)
-        with torch.cuda.device(image.device):
+        with _lib.device_guard(image.device):
             _lib.check(L.dgm_image_loss_backward(
                 ctypes.c_void_p(image.data_ptr()), ctypes.c_void_p(gt.data_ptr()), C, H, W, ctx.lam,
                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(d_image.data_ptr()),
-                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                _lib.stream_ptr()))
         return d_image, None, None
 
 

@@ -25,8 +25,8 @@ def get_opacity_field_from_gaussians(xyzs, rotations, scalings, opacities, resol
     occ = torch.empty([resolution] * 3, dtype=torch.float32, device=dev)
     scratch = torch.empty(L.dgm_opacity_field_scratch_bytes(P), dtype=torch.uint8, device=dev)
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         _lib.check(L.dgm_opacity_field(P, vp(xyzs), vp(rotations), vp(scalings), vp(opacities), float(opacity_threshold),
                                        int(resolution), int(num_blocks), float(block_size * relax_ratio), vp(coords), vp(scratch),
-                                       vp(occ), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                       vp(occ), _lib.stream_ptr()))
     return occ

@@ -42,7 +42,7 @@ def _f32c(t, name):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.stream_ptr()
 
 
 def _resizer(t):
@@ -79,7 +79,7 @@ class _CModule:
         rendered = ctypes.c_int(0)
         cbs = (_resizer(geom), _resizer(binning), _resizer(img))
         t_call = time.perf_counter()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(L.dgm_rasterize_forward(
                 cbs[0], None, cbs[1], None, cbs[2], None, P, int(degree), M, _ptr(background), W, H, _ptr(means3D),
                 _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
@@ -114,7 +114,7 @@ class _CModule:
         sh_active = M > 0 and (colors is None or colors.numel() == 0)
         dL_dsh = new(P, M, 3) if sh_active else torch.zeros((P, M, 3), dtype=torch.float32, device=dev)
         if P != 0:
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 _lib.check(L.dgm_rasterize_backward(
                     P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
                     _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
@@ -131,7 +131,7 @@ class _CModule:
         if P != 0:
             means3D = _f32c(means3D, "means3D")
             viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
-            with torch.cuda.device(means3D.device):
+            with _lib.device_guard(means3D.device):
                 _lib.check(_lib.lib().dgm_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix),
                                                        _ptr(present), _stream()))
         return present
@@ -228,7 +228,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         rendered = ctypes.c_int(0)
         cbs = (_resizer(geom), _resizer(binning), _resizer(img))
         t_call = time.perf_counter()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(L.dgm_rasterize_forward_split_sh(
                 cbs[0], None, cbs[1], None, cbs[2], None, P, int(rs.sh_degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh_dc),
                 _ptr(sh_rest), None, _ptr(opacities), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), None, _ptr(view),
@@ -258,7 +258,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         dL_dscales, dL_drotations = new(P, 3), new(P, 4)
         dL_ddc, dL_drest = torch.empty_like(sh_dc), torch.empty_like(sh_rest)
         if P != 0:
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 _lib.check(L.dgm_rasterize_backward_split_sh(
                     P, int(rs.sh_degree), M, int(ctx.num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh_dc), _ptr(sh_rest),
                     None, _ptr(scales), float(rs.scale_modifier), _ptr(rotations), None, _ptr(view), _ptr(proj), _ptr(campos),

@@ -228,7 +228,7 @@ class GaussianModel:
             from . import _lib
             from .densify import _stream, _vp
             P = radii.shape[0]
-            with torch.cuda.device(radii.device):
+            with _lib.device_guard(radii.device):
                 _lib.check(_lib.lib().dgm_densify_stats(P, None if g is None else _vp(g), _vp(radii), _vp(self.max_radii2D),
                                                         _vp(self.xyz_gradient_accum), _vp(self.denom), _stream()))
             return
@@ -320,7 +320,13 @@ def eval_sh(deg, sh, dirs):
     """sh (..., C, >= (deg+1)^2), dirs (..., 3) unit vectors -> (..., C): the Python SH path of the reference's render()
     (pipe.convert_SHs_python, R/gaussian_renderer/__init__.py:95-100)."""
     n = (deg + 1) ** 2
-    return (sh[..., :n] * sh_basis(deg, dirs).unsqueeze(-2)).sum(-1)
+    basis = sh_basis(deg, dirs)
+    # term by term, in coefficient order: the reference's running sum (R/utils/sh_utils.py:75-101), so that the colours handed to
+    # the rasterizer are bit-identical to the reference render()'s (a reduction over the last axis rounds differently)
+    out = basis[..., 0:1] * sh[..., 0]
+    for k in range(1, n):
+        out = out + basis[..., k:k + 1] * sh[..., k]
+    return out
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, is_6dof=False, scaling_modifier=1.0,
