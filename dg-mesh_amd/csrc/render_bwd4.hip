@@ -227,6 +227,8 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                 const bool top = ((m_top >> j) & 1ull) && cidx < lc_top;
                 const bool bot = ((m_bot >> j) & 1ull) && cidx < lc_bot;
                 Sums4 q;
+                // (the two halves as ONE instruction stream -- two independent chains for a lone wave to interleave -- was measured
+                // and dropped: 126 registers or 33 spilled ones, 0.289 -> 0.339 ms on the initial scene, 0.079 -> 0.086 trained-like)
                 bool any = top && blend_pair4<true>(P[0], A, B, cb, adx2, bdx, cidx, q);
                 if (bot) {
                     if (!any) q.c0 = q.c1 = q.c2 = q.s0 = q.s1 = q.s2 = (f2){0.f, 0.f};  // (only when the top half did not write them)
