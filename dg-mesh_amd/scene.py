@@ -270,6 +270,7 @@ class OptimizationParams:
     densify_until_iter = 15_000
     densification_interval = 100
     opacity_reset_interval = 3000
+    densify_grad_threshold = 0.0002
     # mesh co-training phase (R/arguments/__init__.py:109, 142, 148-149; R/train.py:124-127)
     dpsr_iter = 5000
     normal_warm_up = 1_000
