@@ -40,12 +40,12 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, unsigned tile_mul);
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc);
 // render_bwd3.hip
 void launch_render_bwd4(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
                         const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc,
-                        const unsigned* upos, float* slab, uint8_t* live, unsigned tile_mul);
+                        const unsigned* upos, float* slab, uint8_t* live);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
                            const float* shs, const float* shs_rest, const uint8_t* clamped, const float* scales,
@@ -188,17 +188,6 @@ void prof_end(int s, hipStream_t st) {
 }  // namespace dgm
 
 namespace {
-
-// Multiplier of the blend kernels' workgroup -> tile permutation: near tiles / golden ratio, coprime to the tile count
-// (off unless DGM_TILE_PERM=1: measured at cfg2, it cost the forward 5 % on the initial scene and the backward 12 % on the trained one).
-unsigned tile_permutation_multiplier(int tiles) {
-    static const bool on = [] { const char* e = getenv("DGM_TILE_PERM"); return e && atoi(e) != 0; }();
-    if (!on || tiles < 8) return 1u;
-    auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
-    unsigned m = (unsigned)(tiles * 0.6180339887) | 1u;
-    while (gcd(m, (unsigned)tiles) != 1u) m += 2;
-    return m % (unsigned)tiles;
-}
 
 int check_launch(const char* what, bool debug, hipStream_t st) {
     hipError_t e = hipGetLastError();
@@ -430,7 +419,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
 
     tm.begin(DGM_STAGE_RENDER_FWD);
     launch_render_fwd(st, tiles, ranges, point_list, width, height, gridx, rec, background, out_color, final_T,
-                      n_contrib, ckpt, cfin, ckpt64, nproc, tile_permutation_multiplier(tiles));
+                      n_contrib, ckpt, cfin, ckpt64, nproc);
     DGM_CHECK("render_fwd");
     tm.end(DGM_STAGE_RENDER_FWD);
     tm.finish();
@@ -502,7 +491,7 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
     launch_render_bwd4(st, tiles, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, ckpt64, n_contrib,
-                       dL_dpix, nproc, upos, slab, live, tile_permutation_multiplier(tiles));
+                       dL_dpix, nproc, upos, slab, live);
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);
 

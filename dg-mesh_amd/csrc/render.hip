@@ -25,15 +25,13 @@ __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
-                  float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out, const unsigned tile_mul) {
+                  float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out) {
     __shared__ float4 sA[256];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
     __shared__ float4 sB[256];  // conic c * -log2(e)/2, opacity, r, g
     __shared__ float sC[256];   // b
     __shared__ unsigned long long sMask[4][4];  // [staging wave][quadrant]
     __shared__ unsigned sMaxC[4];               // per-wave maximum of last_contributor
-    // workgroup -> tile through a fixed permutation (tile_mul coprime to the tile count; 1 = identity): long lists are
-    // neighbours on screen, and neighbours in launch order share CUs
-    const int tile = (int)(((unsigned long long)blockIdx.x * tile_mul) % gridDim.x);
+    const int tile = blockIdx.x;
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tile_x * DGM_TILE + (wv & 1) * 8 + (lane & 7);
@@ -176,9 +174,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, unsigned tile_mul) {
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc) {
     hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                       out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, tile_mul);
+                       out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc);
 }
 
 }  // namespace dgm

@@ -100,6 +100,9 @@ __device__ __forceinline__ bool blend_pair4(Pair4& p, const float4 A, const floa
 #ifndef RB4_REDUCE
 #define RB4_REDUCE 0  // 0: select-free DPP butterfly (render_common.hpp: wave_reduce8m); 1: v_mfma_f32_16x16x4_f32 with selector columns
 #endif
+#ifndef RB4_XCD_MAP
+#define RB4_XCD_MAP 1
+#endif
 #ifndef RB4_WAVES_PER_EU
 #define RB4_WAVES_PER_EU 5
 #endif
@@ -108,14 +111,27 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                    const float* __restrict__ bg, const float* __restrict__ rec, const float4* __restrict__ cfin,
                    const float4* __restrict__ ckpt, const float4* __restrict__ ckpt64, const unsigned* __restrict__ n_contrib,
                    const float* __restrict__ dL_dpixels, const unsigned* __restrict__ nproc_in,
-                   const unsigned* __restrict__ upos, float* __restrict__ slab, uint8_t* __restrict__ live, const unsigned tile_mul) {
+                   const unsigned* __restrict__ upos, float* __restrict__ slab, uint8_t* __restrict__ live, const int ntiles) {
     __shared__ float4 sA[64];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
     __shared__ float4 sB[64];  // conic c * -log2(e)/2, opacity, r, g
     __shared__ float sC[64];   // b
     __shared__ float sOut[64 * RB4_RS];
-    // workgroup -> tile through a fixed permutation (tile_mul coprime to the tile count): heavy tiles are neighbours on
-    // screen, and neighbours in launch order end up on the same SIMDs
-    const int tile = (int)(((unsigned long long)blockIdx.x * tile_mul) % gridDim.x);
+    // Workgroup -> (tile, unit slot).  Consecutive workgroup ids go round the 8 XCDs (id % 8), each with its own L2.  All 16 unit
+    // slots of a tile, and 8 horizontally adjacent tiles, are given to ONE XCD and to nearby ids: the tile's pixel state (8 KB: final
+    // blend state, dL/dpixel, n_contrib) is then fetched into that L2 once instead of once per unit, and the 36-byte rows of a
+    // Gaussian's neighbouring instances -- adjacent in the slab -- meet in the same L2 before they are written back.
+    //   id = (((tile / 64) * KSPLIT + slot) * 8 + tile % 8) * 8 + (tile / 8) % 8
+    const unsigned wid = blockIdx.x;
+#if RB4_XCD_MAP
+    const unsigned xcd = wid & 7u, qq = wid >> 3;
+    const unsigned rr = qq >> 3;
+    const int slot = (int)(rr % RB4_KSPLIT);
+    const int tile = (int)(((rr / RB4_KSPLIT) << 6) | (xcd << 3) | (qq & 7u));
+    if (tile >= ntiles) return;
+#else  // (A/B: slot-major, a tile's units 2500 ids apart and on alternating XCDs -- the round-4 form before this mapping)
+    const int slot = (int)(wid / (unsigned)ntiles), tile = (int)(wid % (unsigned)ntiles);
+    if (slot >= RB4_KSPLIT) return;
+#endif
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int nproc = (int)nproc_in[tile];
@@ -123,8 +139,8 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
     const int ulen = shortlist ? 64 : 256;
     const int nunits = (nproc + ulen - 1) / ulen;
     // list entries behind the deepest contributor of the tile are never replayed: dead, no row; the tile's workgroups share them
-    for (int pos = nproc + (int)blockIdx.y * 64 + (int)threadIdx.x; pos < n; pos += RB4_KSPLIT * 64) live[upos[range.x + pos]] = 0;
-    if ((int)blockIdx.y >= nunits) return;
+    for (int pos = nproc + slot * 64 + (int)threadIdx.x; pos < n; pos += RB4_KSPLIT * 64) live[upos[range.x + pos]] = 0;
+    if (slot >= nunits) return;
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int lane = threadIdx.x;
     const int px = tile_x * DGM_TILE + (lane & 15);
@@ -176,7 +192,7 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
     const unsigned lc_top = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(max(P[0].lc0, P[0].lc1)));
     const unsigned lc_bot = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(max(P[1].lc0, P[1].lc1)));
 
-    for (int k = (int)blockIdx.y; k < nunits; k += RB4_KSPLIT) {
+    for (int k = slot; k < nunits; k += RB4_KSPLIT) {
         const int seg_begin = k * ulen;
         const int seg_end = min(nproc, seg_begin + ulen);
         // replay state at the back end of the unit
@@ -289,9 +305,10 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
 void launch_render_bwd4(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
                         const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc,
-                        const unsigned* upos, float* slab, uint8_t* live, unsigned tile_mul) {
-    hipLaunchKernelGGL(render_bwd4_kernel, dim3(tiles, RB4_KSPLIT), dim3(64), 0, st, ranges, point_list, W, H, gridx, bg, rec,
-                       cfin, ckpt, ckpt64, n_contrib, dL_dpix, nproc, upos, slab, live, tile_mul);
+                        const unsigned* upos, float* slab, uint8_t* live) {
+    const unsigned groups = ((unsigned)tiles + 63u) / 64u;
+    hipLaunchKernelGGL(render_bwd4_kernel, dim3(groups * RB4_KSPLIT * 64u), dim3(64), 0, st, ranges, point_list, W, H, gridx, bg, rec,
+                       cfin, ckpt, ckpt64, n_contrib, dL_dpix, nproc, upos, slab, live, tiles);
 }
 
 }  // namespace dgm
