@@ -22,7 +22,7 @@
 //     from the forward's 64-entry checkpoints (render.hip: `ckpt64`, 64 bytes per entry), 16 workgroups per tile.  A unit is
 //     a serial chain of ~1000 cycles per blended entry for a lone wave; on a trained scene (lists of 200-1400 entries, half
 //     the tiles empty) the kernel's duration was that of ONE 256-entry segment -- 0.9 waves resident per SIMD, VALU busy 0.26
-//     (`profiles/r04_pmc_sq_trained.json`) -- and on the initial scene the shorter units trim the tail as well.  Longer
+//     (`profiles/r04_rasterbench_sq_trained_ksplit8.json`) -- and on the initial scene the shorter units trim the tail as well.  Longer
 //     lists keep 256-entry segments (16 bytes of checkpoints per entry);
 //   * rows.  36 bytes (9 floats), written only for instances some pixel blended; `live[row]` (one byte per instance,
 //     always written) tells preprocess_bwd which rows to read.  No zero rows are written or read.
