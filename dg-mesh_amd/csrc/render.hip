@@ -50,10 +50,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     unsigned last_contributor = 0;
-    bool done = !inside;
+    unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);  // lanes whose pixel is finished (wave-uniform lane mask)
 
     for (int i = 0; i < rounds; i++) {
-        if (__syncthreads_and(done)) break;  // also orders the previous round's LDS reads before the refill
+        if (__syncthreads_and(done_m == ~0ull)) break;  // also orders the previous round's LDS reads before the refill
         if (i > 0 && !shortlist) {
             // state after the first 256 i list entries, for the segment-parallel backward (render_bwd4.hip): slot
             // floor((range.x + 256 i) / 256) is unique per (tile, i); pixel order = the backward's lane mapping
@@ -84,7 +84,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         }
         __syncthreads();
         const unsigned base = (unsigned)(i << 8);
-        if (__ballot(!done) == 0ull) {  // whole quadrant finished: keep helping with staging only
+        if (done_m == ~0ull) {  // whole quadrant finished: keep helping with staging only
             if (shortlist)
                 for (int sw = 0; sw < 4; sw++) {
                     const int s = 4 * i + sw + 1;
@@ -115,14 +115,20 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                 const float power_b = (Ab.z * dxb + Ab.w * dyb) * dxb + (Bb.x * dyb) * dyb;
                 const float alpha_a = fminf(0.99f, Ba.y * __builtin_amdgcn_exp2f(power_a));
                 const float alpha_b = fminf(0.99f, Bb.y * __builtin_amdgcn_exp2f(power_b));
-                const bool geo_a = !(power_a > 0.0f) && !(alpha_a < 1.0f / 255.0f);
-                const bool geo_b = two && !(power_b > 0.0f) && !(alpha_b < 1.0f / 255.0f);
+                // the blend decisions as 64-bit lane masks in scalar registers (ballot / inverse ballot): "done", "passes",
+                // "stops here" and "blends" combine with scalar and / andn2 instead of a second vector compare each
+                // (one ballot per compare, combined in scalar registers: a ballot of a compound condition is lowered through a
+                // select and a second compare)
+                const unsigned long long geo_a = __builtin_amdgcn_ballot_w64(!(power_a > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha_a < 1.0f / 255.0f));
+                const unsigned long long geo_b = __builtin_amdgcn_ballot_w64(!(power_b > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha_b < 1.0f / 255.0f)) &
+                                                 (two ? ~0ull : 0ull);
                 {
-                    const bool pass = !done && geo_a;
+                    const unsigned long long pass = geo_a & ~done_m;
                     const float test_T = T * (1.0f - alpha_a);
-                    const bool stop = pass && test_T < 0.0001f;
-                    const bool valid = pass && !stop;
-                    done = done || stop;
+                    const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                    const unsigned long long valid_m = pass & ~low;
+                    done_m |= pass & low;
+                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
                     // branch-free: a pixel that skips the splat blends it with weight zero
                     const float w = valid ? alpha_a * T : 0.f;
                     C0 += Ba.z * w;
@@ -132,11 +138,12 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                     last_contributor = valid ? base + (unsigned)ja + 1u : last_contributor;
                 }
                 {
-                    const bool pass = !done && geo_b;
+                    const unsigned long long pass = geo_b & ~done_m;
                     const float test_T = T * (1.0f - alpha_b);
-                    const bool stop = pass && test_T < 0.0001f;
-                    const bool valid = pass && !stop;
-                    done = done || stop;
+                    const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                    const unsigned long long valid_m = pass & ~low;
+                    done_m |= pass & low;
+                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
                     const float w = valid ? alpha_b * T : 0.f;
                     C0 += Bb.z * w;
                     C1 += Bb.w * w;

@@ -70,10 +70,14 @@ __device__ __forceinline__ bool blend_pair4(Pair4& p, const float4 A, const floa
     f2 alpha = B.y * G;
     alpha.x = fminf(0.99f, alpha.x);
     alpha.y = fminf(0.99f, alpha.y);
-    const bool v0 = cidx < p.lc0 && !(power.x > 0.0f) && !(alpha.x < 1.0f / 255.0f);
-    const bool v1 = cidx < p.lc1 && !(power.y > 0.0f) && !(alpha.y < 1.0f / 255.0f);
-    if (__ballot(v0 || v1) == 0ull) return false;
-    const f2 vm = {v0 ? 1.f : 0.f, v1 ? 1.f : 0.f};
+    // the decisions as lane masks in scalar registers: one ballot per compare (a ballot of a compound condition is lowered
+    // through a select and a second compare), combined with scalar ands
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cidx < p.lc0) & __builtin_amdgcn_ballot_w64(!(power.x > 0.0f)) &
+                                  __builtin_amdgcn_ballot_w64(!(alpha.x < 1.0f / 255.0f));
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(cidx < p.lc1) & __builtin_amdgcn_ballot_w64(!(power.y > 0.0f)) &
+                                  __builtin_amdgcn_ballot_w64(!(alpha.y < 1.0f / 255.0f));
+    if ((m0 | m1) == 0ull) return false;
+    const f2 vm = {__builtin_amdgcn_inverse_ballot_w64(m0) ? 1.f : 0.f, __builtin_amdgcn_inverse_ballot_w64(m1) ? 1.f : 0.f};
     alpha = alpha * vm;  // a skipped pixel is alpha = 0: T, S' stay, every sum gets zero
     const f2 one_m_a = 1.f - alpha;
     f2 inv;
