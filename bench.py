@@ -449,6 +449,13 @@ def main():
             itd = tr2.opt.warm_up + 2000 + 1          # 5001: the first step is not a densification step
             for i in range(8):
                 tr2.step(itd + i)
+            # the synthetic targets give smaller view-space gradients than a real scene: the reference's threshold (2e-4) would
+            # select nothing, so it is set to the 95th percentile of the accumulated statistic -- ~5 % of the Gaussians are
+            # cloned or split at each event, the order of magnitude of a real run's early densification steps
+            with torch.no_grad():
+                stat = (tr2.g.xyz_gradient_accum / tr2.g.denom.clamp_min(1.0)).reshape(-1)
+                thr = float(torch.quantile(stat[stat > 0][:1_000_000], 0.95)) if bool((stat > 0).any()) else tr2.opt.densify_grad_threshold
+            tr2.opt.densify_grad_threshold = thr
             P0 = int(tr2.g.get_xyz.shape[0])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -462,9 +469,10 @@ def main():
             torch.cuda.synchronize()
             d_dt = time.perf_counter() - t0
             with_densify = {"value": n_d / d_dt, "unit": "it/s", "ms_per_step": 1e3 * d_dt / n_d, "steps": n_d,
-                            "densify_events": events, "P": P_path,
-                            "note": "densify_and_prune every 100 iterations inside the timed region (amortised); P changes at "
-                                    "each event, so the steps after it are not the headline's workload"}
+                            "densify_events": events, "P": P_path, "densify_grad_threshold": thr,
+                            "note": "densify_and_prune every 100 iterations inside the timed region (amortised); threshold = 95th "
+                                    "percentile of the accumulated view-space gradient statistic (the reference's 2e-4 selects nothing "
+                                    "on synthetic targets); P changes at each event, so the steps after it are not the headline's workload"}
             del tr2
         except Exception as ex:  # an extra must never take the headline down
             with_densify = {"error": str(ex)}
@@ -497,7 +505,7 @@ def main():
 
         gemm_mode = L.lib().dgm_mlp_set_gemm(-1) if mlp_impl == "hip" else -1  # (-1: query, mode unchanged)
         f16x3 = gemm_mode in (2, 3)
-        mfma_per_product = 3.0 if f16x3 else 6.0  # f16x3: 3 MFMAs per fp32 product on the f16 pipe; bf16x6: 6 on the bf16 pipe
+        mfma_per_product = 3.0  # f16x3 / f16x3p: 3 MFMAs per fp32 product on the f16 pipe
         layer_flops = 2.0 * P * 256 * 256                       # one 256 -> 256 layer over N = P rows
         layer_bytes = 2.0 * P * 256 * 4 + P * 32 + 256 * 256 * 4  # A in + C out (fp32) + ReLU mask bits + the weights once
         dw_bytes = 2.0 * P * 256 * 4 + 256 * 256 * 4  # X in + G in + the gradient once (the per-CU partial tiles are overhead)
@@ -554,7 +562,7 @@ def main():
                          "arithmetic": ("f16x3p: activations / gradients stored as 2 binary16 planes with one exponent per 32-row tile, "
                                         "split once by the producer, 3 MFMAs per product" if planes else
                                         "f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
-                                        if f16x3 else "bf16x6: 3 bf16 planes, 6 MFMAs per product")})
+                                        if f16x3 else "native fp32 MFMA")})
         rb_traffic, rb_src = pmc_traffic("r04_pmc_render_bwd4.json")
         out = {
             "metric": ("train-step iters/sec (800x800, ~100k Gaussians)" if WORKLOAD == "cfg2"

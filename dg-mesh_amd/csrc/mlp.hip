@@ -5,10 +5,11 @@
 // [PE(x), t_emb] before layer 5, linear heads -- forward and backward (dX, dW, db, dt_emb) -- plus the single-row
 // time branch timenet(PE(t)).
 //
-// Two arithmetics for the 256-wide GEMMs, selected by dgm_mlp_set_gemm() / DGM_MLP_GEMM:
-//  * bf16x6 (default, mlp_bf16x6.hpp): fp32 operands split exactly into three bf16 numbers, six partial products per
-//    fp32 product on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- an fp32 GEMM to rounding at 2.7x the MFMA
-//    rate of the fp32 instruction;
+// Arithmetics of the 256-wide GEMMs, selected by dgm_mlp_set_gemm() / DGM_MLP_GEMM (the list and the default are further down,
+// at g_gemm_mode):
+//  * f16x3p (mlp_planes.hpp, default) and f16x3 (mlp_f16x3.hpp): power-of-two scaled two-way binary16 split, three partial
+//    products per fp32 product on the f16 matrix cores; the heads of f16x3 use the exact three-way bf16 split of
+//    mlp_bf16x6.hpp (six partial products on v_mfma_f32_32x32x16_bf16);
 //  * f32 (this file): v_mfma_f32_32x32x2_f32; 64 x 128 output tile per 256-thread workgroup, K consumed in 16-deep
 //    register-staged global -> LDS stages (A k-major with row pitch 66 = 2 mod 8: conflict-free transposing stores and
 //    fragment reads), dW as row-chunk x 128-column-slab partial tiles.
@@ -801,16 +802,14 @@ int num_cus() {
     }
     return cache[slot];
 }
-// bf16x6 dW decomposition: about 512 workgroups (two per CU) whatever the layer's K
+// f16x3 dW decomposition (mlp_dw3b / dw3e kernels): one 8-wave workgroup per chunk of rows covers all columns, one chunk per CU
 struct DwPlan {
     int rows, chunks, slabs;
 };
-DwPlan dw6_plan(int N, int Kp, bool x3) {
+DwPlan dw6_plan(int N, int /*Kp*/, bool /*x3*/) {
     DwPlan d;
-    d.slabs = (Kp + DW6_SLAB - 1) / DW6_SLAB;
-    // mlp_dw6b / dw3b / dw3e kernels: one 8-wave workgroup per chunk covers all columns
-    if (Kp == MLP_W || x3) d.slabs = 1;
-    const int target = d.slabs == 1 ? num_cus() : 512 / d.slabs;
+    d.slabs = 1;
+    const int target = num_cus();
     int rows = (N + target - 1) / target;
     rows = (rows + 15) & ~15;
     if (rows < 16) rows = 16;
@@ -821,17 +820,17 @@ DwPlan dw6_plan(int N, int Kp, bool x3) {
 // 2: f16x3 (default; mlp_f16x3.hpp): power-of-two scaled operands split into 2 binary16, 3 partial products on the f16
 //    matrix cores for the 256-wide layers (layer 0 .. 4, 6, 7 forward, all backward-data, their weight gradients); the
 //    skip layer, the heads and the K = 96 / 352 weight gradients run the bf16x6 kernels
-// 0: bf16x6 everywhere (fp32 operands split exactly into 3 bf16, 6 partial products on the bf16 matrix cores)
-// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3|bf16x6|f32.
+// 0: (retired in round 4) bf16x6 for every GEMM -- fp32 operands split exactly into 3 bf16, 6 partial products; the 32-column
+//    GEMM of that arithmetic is still the heads' forward pass of mode 2
+// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3p|f16x3|f32.
 // 3: f16x3p (default; mlp_planes.hpp): the f16x3 arithmetic on plane-format activations -- split once by the producer,
 //    one exponent per 32-row tile; needs a broadcast time embedding (temb_stride == 0), else the call runs mode 2.
 int g_gemm_mode = [] {
     const char* e = getenv("DGM_MLP_GEMM");
     if (e == nullptr) return 3;
-    if (strcmp(e, "bf16x6") == 0) return 0;
     if (strcmp(e, "f32") == 0) return 1;
     if (strcmp(e, "f16x3") == 0) return 2;
-    if (strcmp(e, "f16x3p") != 0) fprintf(stderr, "libdgmesh_hip: unknown DGM_MLP_GEMM=\"%s\" (f16x3p | f16x3 | bf16x6 | f32): using f16x3p\n", e);
+    if (strcmp(e, "f16x3p") != 0) fprintf(stderr, "libdgmesh_hip: unknown DGM_MLP_GEMM=\"%s\" (f16x3p | f16x3 | f32): using f16x3p\n", e);
     return 3;
 }();
 // (the plane kernels keep a workgroup's tile exponents in a 512-entry LDS table: beyond 512 tiles per workgroup -- N > 4 M
@@ -1227,7 +1226,7 @@ extern "C" {
 
 int dgm_mlp_set_gemm(int mode) {
     const int prev = g_gemm_mode;
-    if (mode >= 0 && mode <= 3) g_gemm_mode = mode;
+    if (mode >= 1 && mode <= 3) g_gemm_mode = mode;  // (0 was "bf16x6 for every GEMM", retired in round 4: ignored)
     return prev;
 }
 
@@ -1280,7 +1279,6 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
                                l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
         }
     } else {  // all weight re-layouts of the network in one launch per arithmetic
-        const bool x3 = mode == 2;
         Prep6Batch pb;
         int nj = 0, max_threads = 0;
         auto add = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp,
@@ -1300,30 +1298,23 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         for (int l = 0; l < 8; l++) {
             // the K = 352 planes of the skip layer do not fit the register file: its embedding half (K = 96, planes at the
             // front of Wt3[l]) rides along with layer 0, its trunk half (K = 256, behind them) adds that result in its epilogue
-            if (x3 && l == p->skip_layer) {
+            if (l == p->skip_layer) {
                 add3(0, MLP_EMB, layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_e);
                 add3(0, MLP_W, layer_in(p, l), p->emb_dim, p->W[l], w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l]);
-            } else if (x3) add3(0, layer_kp(p, l), layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_f[l]);
-            else add(0, layer_kp(p, l), MLP_W, layer_in(p, l), 0, 0, MLP_W, p->W[l], w.Wt6[l]);
-            if (l >= 1) {
-                if (x3) add3(1, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, p->W[l], w.Wd3[l], w.wsc_d[l]);
-                else add(1, MLP_W, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l], w.Wd6[l]);
-            }
+            } else add3(0, layer_kp(p, l), layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_f[l]);
+            if (l >= 1) add3(1, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, p->W[l], w.Wd3[l], w.wsc_d[l]);
         }
         add(0, MLP_W, 32, MLP_W, 0, 0, p->n_out, p->Wh, w.Wh6f);
-        if (n3 > 0) {
-            // one launch: every trunk matrix's column maxima + planes, the heads' planes (the only bf16x6 job left in this
-            // mode), and the clearing of cmaxY | cmaxE | cmaxG -- one block of running column maxima for this forward AND its
-            // backward pass (a repeated backward pass finds maxima that are at least as large: still valid scales)
-            hipLaunchKernelGGL(mlp_prep3_all_kernel, dim3(8, n3 + 1), dim3(256), 0, st, p3, n3, pb.job[nj - 1], w.cmaxY,
-                               (9 + 8) * MLP_W);
-            if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_forward: cannot raise the LDS limit of mlp_gemm3r_kernel");
-        } else
-            hipLaunchKernelGGL(mlp_prep6_batch_kernel, dim3((max_threads + 255) / 256, nj), dim3(256), 0, st, pb);
+        // one launch: every trunk matrix's column maxima + planes, the heads' planes (the one bf16x6 job of this mode), and the
+        // clearing of cmaxY | cmaxE | cmaxG -- one block of running column maxima for this forward AND its backward pass (a
+        // repeated backward pass finds maxima that are at least as large: still valid scales)
+        (void)max_threads;
+        hipLaunchKernelGGL(mlp_prep3_all_kernel, dim3(8, n3 + 1), dim3(256), 0, st, p3, n3, pb.job[nj - 1], w.cmaxY, (9 + 8) * MLP_W);
+        if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_forward: cannot raise the LDS limit of mlp_gemm3r_kernel");
     }
     {
         hipLaunchKernelGGL(mlp_embed_kernel, dim3((N + 7) / 8), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.emb);
-        if (mode == 2) {
+        if (!f32) {
             const int nbx = (int)(((size_t)N * 3 + 3071) / 3072), nbt = temb_stride != 0 ? 256 : 1;
             hipLaunchKernelGGL(mlp_embed_cmax_kernel, dim3(nbx + nbt), dim3(256), 0, st, N, nbx, x, temb, temb_stride, p->t_dim,
                                w.cmaxE);
@@ -1343,36 +1334,23 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         }
         if (!f32) {
             const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
-            if (K1 + K2 == MLP_EMB + MLP_W && mode == 2) {
+            if (K1 + K2 == MLP_EMB + MLP_W) {
                 // skip layer, trunk half: Y5 = relu(Y4 * W5[:, emb:]^T + C_in), C_in = emb * W5[:, :emb]^T + b5 already in Y5
                 // (not under the mlp_layer_fwd stage timer: it also reads C_in, 1.5x the bytes of a plain 256 -> 256 layer)
                 hipLaunchKernelGGL((mlp_gemm3p_kernel<2, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A2, lda2,
                                    w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l], (const float*)nullptr, w.mask[l], w.Y[l],
                                    w.cmaxY + l * MLP_W, (unsigned*)nullptr);
-            } else if (K1 + K2 == MLP_EMB + MLP_W) {  // skip layer: bf16x6, weights streamed through LDS
-                hipLaunchKernelGGL((mlp_gemm6_kernel<0, 2, 2, 2, 4, false>), dim3(grid6), dim3(256), 0, st, N, A1, lda1, K1, A2,
-                                   lda2, K2, 0, w.Wt6[l], p->b[l], w.mask[l], w.Y[l], MLP_W, MLP_W);
-            } else if (mode == 2) {
-                if (K1 + K2 == MLP_W) {
-                    dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                    hipLaunchKernelGGL((mlp_gemm3p_kernel<0, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
-                                       w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
-                                       (unsigned*)nullptr);
-                    dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
-                } else {  // layer 0, with the embedding half of the skip layer as second output (into Y[skip], linear + bias)
-                    const int sk = p->skip_layer;
-                    hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1, true>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32,
-                                       A1, lda1, K1, A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l],
-                                       w.cmaxY + l * MLP_W, (const uint4*)w.Wt3[sk], (const float*)w.wsc_e, p->b[sk], w.Y[sk]);
-                }
             } else if (K1 + K2 == MLP_W) {
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
-                                   w.Wt6[l], p->b[l], w.mask[l], w.Y[l]);
+                hipLaunchKernelGGL((mlp_gemm3p_kernel<0, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
+                                   w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W, (unsigned*)nullptr);
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
-            } else
-                hipLaunchKernelGGL((mlp_gemm6r_kernel<0, 6, 2, 4>), dim3(gx), dim3(256), 0, st, N, nt32, A1, lda1, K1, A2, lda2,
-                                   w.Wt6[l], p->b[l], w.mask[l], w.Y[l]);
+            } else {  // layer 0, with the embedding half of the skip layer as second output (into Y[skip], linear + bias)
+                const int sk = p->skip_layer;
+                hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1, true>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32, A1, lda1, K1,
+                                   A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
+                                   (const uint4*)w.Wt3[sk], (const float*)w.wsc_e, p->b[sk], w.Y[sk]);
+            }
             continue;
         }
         hipLaunchKernelGGL(mlp_gemm_kernel<0>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2, w.Wt[l],
@@ -1418,7 +1396,7 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, p->Wh, w.Y[7], w.Ga,
                        w.partial_h, w.partial_hb);
-    const bool x3 = mode == 2;
+    const bool x3 = !f32;  // (mode 2; mode 0 -- bf16x6 for every GEMM -- was retired in round 4)
     if (x3) {  // (the column maxima of the G_l for the weight gradients' scales, accumulated by the backward-data GEMMs, were
                // cleared by the forward pass)
         if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
@@ -1455,13 +1433,10 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
                     hipLaunchKernelGGL((mlp_gemm3p_kernel<1, true>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
                                        w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
                                        w.cmaxG + (l - 1) * MLP_W, w.cmaxG + l * MLP_W);
-                else if (x3)
+                else
                     hipLaunchKernelGGL((mlp_gemm3p_kernel<1, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
                                        w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
                                        w.cmaxG + (l - 1) * MLP_W, (unsigned*)nullptr);
-                else
-                    hipLaunchKernelGGL((mlp_gemm6r_kernel<1, 16, 1, 8>), dim3(gx), dim3(512), 0, st, N, nt32, G, MLP_W, MLP_W,
-                                       (const float*)nullptr, 0, w.Wd6[l], (const float*)nullptr, w.mask[l - 1], Gn);
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
             }
         }
@@ -1477,14 +1452,10 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
             int db_rows = 2 * d.chunks;  // bias-gradient partial rows the kernel leaves
             if (Kp == MLP_W) {
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
-                if (x3)
-                    hipLaunchKernelGGL(mlp_dw3b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G,
-                                       w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial_l[l], w.partial_db_l[l]);
-                else
-                    hipLaunchKernelGGL(mlp_dw6b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G, w.partial_l[l],
-                                       w.partial_db_l[l]);
+                hipLaunchKernelGGL(mlp_dw3b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G,
+                                   w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial_l[l], w.partial_db_l[l]);
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
-            } else if (x3) {  // the layers that consume the embedding: K = 96 (layer 0) / 352 (skip layer), f16x3
+            } else {  // the layers that consume the embedding: K = 96 (layer 0) / 352 (skip layer), f16x3
                 db_rows = d.chunks;
                 if (Kp == MLP_EMB)
                     hipLaunchKernelGGL(mlp_dw3e_kernel<3>, dim3(d.chunks), dim3(512), DW3E_LDS(3), st, N, d.rows, X1, ldx1, K1, X2,
@@ -1493,9 +1464,7 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
                     hipLaunchKernelGGL(mlp_dw3e_kernel<11>, dim3(d.chunks), dim3(512), DW3E_LDS(11), st, N, d.rows, X1, ldx1, K1,
                                        X2, ldx2, G, w.cmaxE, w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial_l[l],
                                        w.partial_db_l[l]);
-            } else
-                hipLaunchKernelGGL(mlp_dw6_kernel, dim3(d.slabs, d.chunks), dim3(256), 0, st, N, d.rows, X1, ldx1, K1, X2, ldx2,
-                                   K2, G, w.partial_l[l], w.partial_db_l[l]);
+            }
             ReduceDwJob& jb = rb.job[l];
             jb.dst_off = 0;
             jb.chunks = d.chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = reduce_dw_blocks(Kp);

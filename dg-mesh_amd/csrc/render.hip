@@ -26,9 +26,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
                   float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out) {
-    __shared__ float4 sA[256];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
-    __shared__ float4 sB[256];  // conic c * -log2(e)/2, opacity, r, g
-    __shared__ float sC[256];   // b
+    // staged splats, 48 bytes each: x, y, conic a * -log2(e)/2, conic b * -log2(e) | conic c * -log2(e)/2, opacity, r, g | b
+    // (one record per splat: the blend loop forms ONE address per entry for its three broadcast reads)
+    __shared__ float4 sR[256 * 3];
     __shared__ unsigned long long sMask[4][4];  // [staging wave][quadrant]
     __shared__ unsigned sMaxC[4];               // per-wave maximum of last_contributor
     const int tile = blockIdx.x;
@@ -72,9 +72,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             // the conic is staged pre-multiplied so that the exponent below comes out times log2(e), ready for v_exp_f32
             // (same sign as the reference's `power`; render_bwd4 stages the same way)
             const float l2e = 1.4426950408889634f;
-            sA[threadIdx.x] = make_float4(r0.x, r0.y, -0.5f * l2e * r0.z, -l2e * r0.w);
-            sB[threadIdx.x] = make_float4(-0.5f * l2e * r1.x, r1.y, r1.z, r1.w);
-            sC[threadIdx.x] = cb;
+            sR[3 * threadIdx.x] = make_float4(r0.x, r0.y, -0.5f * l2e * r0.z, -l2e * r0.w);
+            sR[3 * threadIdx.x + 1] = make_float4(-0.5f * l2e * r1.x, r1.y, r1.z, r1.w);
+            sR[3 * threadIdx.x + 2].x = cb;
             qm = quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx0, ty0);
         }
 #pragma unroll
@@ -106,9 +106,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                 const bool two = m != 0ull;
                 const int jb = two ? (sw << 6) + __builtin_ctzll(m) : ja;
                 m &= m - 1;  // (no-op when m == 0)
-                const float4 Aa = sA[ja], Ab = sA[jb];
-                const float4 Ba = sB[ja], Bb = sB[jb];
-                const float ca = sC[ja], cbb = sC[jb];
+                const float4 Aa = sR[3 * ja], Ab = sR[3 * jb];
+                const float4 Ba = sR[3 * ja + 1], Bb = sR[3 * jb + 1];
+                const float ca = sR[3 * ja + 2].x, cbb = sR[3 * jb + 2].x;
                 const float dxa = Aa.x - pxf, dya = Aa.y - pyf;
                 const float dxb = Ab.x - pxf, dyb = Ab.y - pyf;
                 const float power_a = (Aa.z * dxa + Aa.w * dya) * dxa + (Ba.x * dya) * dya;  // the reference's exponent times log2(e)

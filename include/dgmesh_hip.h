@@ -215,10 +215,11 @@ typedef struct {
 /* Arithmetic of the trunk GEMMs.  3 (default): "f16x3p" -- the f16x3 arithmetic below on plane-format activations: every
  * activation / gradient tensor lives in HBM as its two binary16 planes with one power-of-two exponent per 32-row tile, split once
  * by the kernel that produces it (needs a broadcast time embedding, temb_stride == 0; other calls run mode 2).  2: "f16x3" -- fp32 operands scaled by a power of two and split into two binary16
- * numbers, three partial products accumulated in fp32 on the f16 matrix cores; 0: "bf16x6" -- operands split exactly into
- * three bf16 numbers, six partial products; 1: native fp32 MFMA.  All four are fp32 GEMMs to rounding.  Returns the previous
- * mode; any other value only queries.  Process-wide; the initial value comes from the environment variable
- * DGM_MLP_GEMM=f16x3p|f16x3|bf16x6|f32.  A forward and its backward must run in the same mode. */
+ * numbers, three partial products accumulated in fp32 on the f16 matrix cores (its 32-column heads GEMM: operands split exactly
+ * into three bf16 numbers, six partial products); 1: native fp32 MFMA.  All three are fp32 GEMMs to rounding.  (0, "bf16x6" for
+ * every GEMM, was retired in round 4 and is ignored.)  Returns the previous mode; any other value only queries.  Process-wide;
+ * the initial value comes from the environment variable DGM_MLP_GEMM=f16x3p|f16x3|f32.  A forward and its backward must run in
+ * the same mode. */
 int dgm_mlp_set_gemm(int mode);
 
 /* Bytes of the workspace that forward fills (embedding, the 8 post-ReLU activations, re-laid-out
