@@ -114,43 +114,73 @@ count_tiles_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __res
     for (int t = threadIdx.x; t < tiles; t += DGM_BIN_THREADS) row[t] = lds_hist[t];
 }
 
-// per tile: exclusive prefix down the chunk rows (in place) and the tile total
+// ---- column prefixes, tile totals, tile starts, `ranges` and the sort's worklists in ONE launch ------------------------------
+// (round 3: colscan + a single-workgroup scan + write_ranges, three launches and 22 us for 2 MB of histogram.)
+// A workgroup owns 64 tiles; lane = tile, so every load of a chunk row is a 256-byte segment.  Its four waves take a quarter of
+// the chunk rows each -- all of a wave's rows are loaded before any is used, <= 64 loads in flight per lane -- scan them in
+// registers, exchange their totals through LDS and store prefix + offset.  The workgroup that arrives LAST at the device
+// counter (release fence before it, acquire fence behind) scans the tile totals -- 256 threads, a contiguous run of tiles each --
+// and writes tile starts, `ranges` exactly as the reference leaves them ([start, end) for non-empty tiles, (0, 0) otherwise),
+// and the "big" / "mid" worklists of the tile sort.  `arrive` is one of the words the forward call clears.
 __global__ void __launch_bounds__(256)
-colscan_kernel(int tiles, int nchunks, unsigned* __restrict__ hist, unsigned* __restrict__ tile_count) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= tiles) return;
-    unsigned run = 0;
-    int c = 0;
-    for (; c + 8 <= nchunks; c += 8) {
-        unsigned v[8];
+tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ hist, unsigned* __restrict__ tile_count,
+                 unsigned* __restrict__ tile_offset, uint2* __restrict__ ranges, unsigned* __restrict__ big_list,
+                 unsigned* __restrict__ big_count, unsigned* __restrict__ arrive) {
+    constexpr int MAXC = DGM_MAX_CHUNKS / 4;  // chunk rows per wave
+    __shared__ unsigned wtot[4][64];
+    __shared__ unsigned wave_sum[4];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    {
+        const int t = blockIdx.x * 64 + lane;
+        const int per = (nchunks + 3) / 4, c0 = wv * per, c1 = min(nchunks, c0 + per);
+        unsigned v[MAXC];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = hist[(size_t)(c + u) * tiles + t];
+        for (int u = 0; u < MAXC; u++) v[u] = (t < tiles && c0 + u < c1) ? hist[(size_t)(c0 + u) * tiles + t] : 0u;
+        unsigned run = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            hist[(size_t)(c + u) * tiles + t] = run;
-            run += v[u];
+        for (int u = 0; u < MAXC; u++) {
+            const unsigned x = v[u];
+            v[u] = run;
+            run += x;
+        }
+        wtot[wv][lane] = run;
+        __syncthreads();
+        unsigned off = 0;
+        for (int w = 0; w < wv; w++) off += wtot[w][lane];
+        if (t < tiles) {
+#pragma unroll
+            for (int u = 0; u < MAXC; u++)
+                if (c0 + u < c1) hist[(size_t)(c0 + u) * tiles + t] = v[u] + off;
+            if (wv == 3) tile_count[t] = off + run;
         }
     }
-    for (; c < nchunks; c++) {
-        const unsigned v = hist[(size_t)c * tiles + t];
-        hist[(size_t)c * tiles + t] = run;
-        run += v;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(arrive, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // exclusive scan of the tile totals: thread i owns tiles [i K, (i + 1) K)
+    const int K = (tiles + 255) / 256;
+    const int t0 = (int)threadIdx.x * K, t1 = min(tiles, t0 + K);
+    unsigned mine = 0;
+    for (int t = t0; t < t1; t++) mine += __builtin_nontemporal_load(tile_count + t);
+    const unsigned inc = wave_inclusive_scan_u32(mine);
+    if (lane == 63) wave_sum[wv] = inc;
+    __syncthreads();
+    unsigned start = inc - mine;
+    for (int w = 0; w < wv; w++) start += wave_sum[w];
+    for (int t = t0; t < t1; t++) {
+        const unsigned c = __builtin_nontemporal_load(tile_count + t);
+        tile_offset[t] = start;
+        ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
+        // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
+        if (c > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
+        else if (c > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
+        start += c;
     }
-    tile_count[t] = run;
-}
-
-// ranges exactly as the reference leaves them: [start,end) for non-empty tiles, (0,0) otherwise
-__global__ void __launch_bounds__(256)
-write_ranges_kernel(int tiles, int small_cap, const unsigned* __restrict__ tile_count,
-                    const unsigned* __restrict__ tile_offset, uint2* __restrict__ ranges,
-                    unsigned* __restrict__ big_list, unsigned* __restrict__ big_count) {  // big_count[1] = mid count
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= tiles) return;
-    const unsigned c = tile_count[t], o = tile_offset[t];
-    ranges[t] = c ? make_uint2(o, o + c) : make_uint2(0u, 0u);
-    // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
-    if (c > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
-    else if (c > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
+    if (threadIdx.x == 255) tile_offset[tiles] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 }
 
 __global__ void __launch_bounds__(DGM_BIN_THREADS)
@@ -716,12 +746,9 @@ hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles
 }
 
 void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
-                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count) {
-    hipLaunchKernelGGL(colscan_kernel, dim3((tiles + 255) / 256), dim3(256), 0, st, tiles, nchunks, hist, tile_count);
-    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, st, tiles, tile_count, tile_offset,
-                       tile_offset + tiles);
-    hipLaunchKernelGGL(write_ranges_kernel, dim3((tiles + 255) / 256), dim3(256), 0, st, tiles, kSmallCap, tile_count,
-                       tile_offset, ranges, big_list, big_count);
+                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3((tiles + 63) / 64), dim3(256), 0, st, tiles, nchunks, kSmallCap, hist, tile_count,
+                       tile_offset, ranges, big_list, big_count, arrive);
 }
 
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,

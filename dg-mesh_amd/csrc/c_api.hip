@@ -31,7 +31,7 @@ hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles
                         const unsigned* tiles_touched, float* rec, const unsigned* block_offs, unsigned* offs,
                         unsigned* hist);
 void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
-                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count);
+                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive);
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, uint4* inst);
@@ -397,7 +397,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     tm.end(DGM_STAGE_BIN_COUNT);
 
     tm.begin(DGM_STAGE_BIN_SCAN);
-    launch_tile_scan(st, tiles, L.n_chunks, hist, tile_count, tile_offset, ranges, big_list, counters + 2);
+    launch_tile_scan(st, tiles, L.n_chunks, hist, tile_count, tile_offset, ranges, big_list, counters + 2, counters + 4);
     DGM_CHECK("tile_scan");
     tm.end(DGM_STAGE_BIN_SCAN);
 

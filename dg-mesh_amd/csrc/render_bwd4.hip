@@ -116,9 +116,8 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                    const float4* __restrict__ ckpt, const float4* __restrict__ ckpt64, const unsigned* __restrict__ n_contrib,
                    const float* __restrict__ dL_dpixels, const unsigned* __restrict__ nproc_in,
                    const unsigned* __restrict__ upos, float* __restrict__ slab, uint8_t* __restrict__ live, const int ntiles) {
-    __shared__ float4 sA[64];  // x, y, conic a * -log2(e)/2, conic b * -log2(e)
-    __shared__ float4 sB[64];  // conic c * -log2(e)/2, opacity, r, g
-    __shared__ float sC[64];   // b
+    // staged splats, 48 bytes each: x, y, conic a * -log2(e)/2, conic b * -log2(e) | conic c * -log2(e)/2, opacity, r, g | b
+    __shared__ float4 sR[64 * 3];
     __shared__ float sOut[64 * RB4_RS];
     // Workgroup -> (tile, unit slot).  Consecutive workgroup ids go round the 8 XCDs (id % 8), each with its own L2.  All 16 unit
     // slots of a tile, and 8 horizontally adjacent tiles, are given to ONE XCD and to nearby ids: the tile's pixel state (8 KB: final
@@ -226,9 +225,9 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                 const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * DGM_REC_STRIDE);
                 const float4 r0 = r4[0], r1 = r4[1];
                 const float l2e = 1.4426950408889634f;
-                sA[lane] = make_float4(r0.x, r0.y, -0.5f * l2e * r0.z, -l2e * r0.w);
-                sB[lane] = make_float4(-0.5f * l2e * r1.x, r1.y, r1.z, r1.w);
-                sC[lane] = r4[2].x;
+                sR[3 * lane] = make_float4(r0.x, r0.y, -0.5f * l2e * r0.z, -l2e * r0.w);
+                sR[3 * lane + 1] = make_float4(-0.5f * l2e * r1.x, r1.y, r1.z, r1.w);
+                sR[3 * lane + 2].x = r4[2].x;
                 qm = half_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx0, ty0);
             }
             const unsigned long long m_top = uniform_u64(__ballot(qm & 1u));
@@ -238,9 +237,9 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
             while (m) {
                 const int j = __builtin_ctzll(m);
                 m &= m - 1;
-                const float4 A = sA[j];
-                const float4 B = sB[j];
-                const float cb = sC[j];
+                const float4 A = sR[3 * j];
+                const float4 B = sR[3 * j + 1];
+                const float cb = sR[3 * j + 2].x;
                 const unsigned cidx = (unsigned)(base_pos - j);  // contributor index (backward.cu:486-488)
                 const float dx = A.x - pxf;
                 const float adx2 = A.z * dx * dx, bdx = A.w * dx;

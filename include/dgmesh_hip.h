@@ -129,7 +129,7 @@ typedef struct {
     size_t tile_offset;   /* u32[tiles+1] */
     size_t big_list;      /* u32[tiles] worklists: tiles with more than 4096 instances from the front, tiles with 2049 ..
                              4096 from the end */
-    size_t counters;      /* u32[8]: [0] = num_rendered, [1] = error flags, [2] = big worklist length, [3] = mid worklist length */
+    size_t counters;      /* u32[8]: [0] = num_rendered, [1] = error flags, [2] = big worklist length, [3] = mid worklist length, [4] = arrival counter of the tile scan */
     size_t geometry_bytes;
     /* binning buffer */
     size_t inst;       /* uint4[R] instance records (gaussian, depth bits, offs[g] + k, 0), grouped by tile, in arrival
