@@ -372,7 +372,13 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     // R is needed on the host to size the binning buffer (rasterizer_impl.cu:281 does the same read-back); the
     // "prefiltered but culled" flag of auxiliary.h:156-160 rides in the same 8-byte copy, so it is ALWAYS checked
     // (the reference traps the kernel unconditionally), not only with debug on.
-    unsigned host_words[2] = {0, 0};
+    // (into PINNED host memory, one small buffer per calling thread: a copy to pageable memory is staged through the runtime's
+    // own bounce buffer and costs the GPU a longer idle gap per frame.  Tried on top and not kept: the scan kernel mailing
+    // {R, flags, sequence number} into host-mapped memory with the host polling it -- +0.6 % at cfg2, -3 % at the host-bound cfg1)
+    static thread_local unsigned* pinned_words = nullptr;
+    if (!pinned_words && hipHostMalloc((void**)&pinned_words, 64, hipHostMallocDefault) != hipSuccess) pinned_words = nullptr;
+    unsigned stack_words[2] = {0, 0};
+    unsigned* host_words = pinned_words ? pinned_words : stack_words;
     DGM_HIP(hipMemcpyAsync(host_words, counters, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     DGM_HIP(hipStreamSynchronize(st));
     const unsigned R_host = host_words[0];
