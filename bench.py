@@ -456,6 +456,7 @@ def main():
                 stat = (tr2.g.xyz_gradient_accum / tr2.g.denom.clamp_min(1.0)).reshape(-1)
                 thr = float(torch.quantile(stat[stat > 0][:1_000_000], 0.95)) if bool((stat > 0).any()) else tr2.opt.densify_grad_threshold
             tr2.opt.densify_grad_threshold = thr
+            tr2.freeze_gc()  # (the second scene's set-up objects out of the cyclic collector's way, like the headline's)
             P0 = int(tr2.g.get_xyz.shape[0])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
