@@ -187,6 +187,25 @@ def test_edge_cases(orc, syn):
     check_backward(orc, a2, check_forward(orc, a2, f), f)
 
 
+@pytest.mark.parametrize("P,W,H,scale,opac", [(26000, 32, 32, 0.012, 0.02), (9000, 48, 32, 0.02, 0.015), (3300, 32, 16, 0.05, 0.008)])
+def test_long_lists_blend_and_gradients(orc, syn, P, W, H, scale, opac):
+    """Tile lists on both sides of DGM_SHORT_LIST = 4096 entries WITH contributions deep into them: many small, faint splats,
+    so that every pixel blends hundreds of entries spread over the whole list (a list of opaque or full-screen splats terminates
+    after a few hundred entries, or -- at opacities below 1/255 -- blends nothing, which is all the sort tests above need).
+    Lists beyond 4096 entries take the forward's 256-entry checkpoints and the backward's 256-entry segments over 16
+    workgroups, shorter ones the 64-entry units; image, n_contrib and all eight gradient tensors against the oracle."""
+    a = raster_args(syn, P, W, H, seed=21, kind="init", extent=0.35)
+    a["scales"] = (a["scales"] * 0 + scale).astype(np.float32)
+    a["opacities"] = (a["opacities"] * 0 + opac).astype(np.float32)
+    f_hip = G.hip_forward(a)
+    f_or = check_forward(orc, a, f_hip)
+    n = f_or["binning"]["ranges"][:, 1] - f_or["binning"]["ranges"][:, 0]
+    deep = f_or["img"]["n_contrib"].max()
+    assert n.max() > (4096 if P >= 9000 else 1024), n.max()
+    assert deep > 0.6 * n.max(), (deep, n.max())  # the deepest contributor sits far down the longest list
+    check_backward(orc, a, f_or, f_hip, seed=3)
+
+
 def test_big_tile_lists(orc, syn):
     """> 2048 and > 16384 instances in one tile: LDS big-class sort and the global-memory fallback."""
     for P, W, H in [(3000, 48, 48), (17000, 32, 32)]:
