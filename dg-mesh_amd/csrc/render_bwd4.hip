@@ -110,6 +110,12 @@ __device__ __forceinline__ bool blend_pair4(Pair4& p, const float4 A, const floa
 #ifndef RB4_WAVES_PER_EU
 #define RB4_WAVES_PER_EU 5
 #endif
+#ifndef RB4_TRACE
+#define RB4_TRACE 0  // 1: every wave that had work records (start, end, hardware id, blended entries): tools/raster_bench.py --trace
+#endif
+#if RB4_TRACE
+__device__ unsigned long long rb4_trace[4 * 65536 + 1];
+#endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RB4_WAVES_PER_EU, RB4_WAVES_PER_EU)))
 render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                    const float* __restrict__ bg, const float* __restrict__ rec, const float4* __restrict__ cfin,
@@ -144,6 +150,10 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
     // list entries behind the deepest contributor of the tile are never replayed: dead, no row; the tile's workgroups share them
     for (int pos = nproc + slot * 64 + (int)threadIdx.x; pos < n; pos += RB4_KSPLIT * 64) live[upos[range.x + pos]] = 0;
     if (slot >= nunits) return;
+#if RB4_TRACE
+    const unsigned long long tr_t0 = __builtin_readcyclecounter(), tr_w0 = wall_clock64();
+    unsigned tr_blended = 0;
+#endif
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int lane = threadIdx.x;
     const int px = tile_x * DGM_TILE + (lane & 15);
@@ -253,6 +263,9 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                     if (!any) q.c0 = q.c1 = q.c2 = q.s0 = q.s1 = q.s2 = (f2){0.f, 0.f};  // (only when the top half did not write them)
                     any |= blend_pair4<false>(P[1], A, B, cb, adx2, bdx, cidx, q);
                 }
+#if RB4_TRACE
+                tr_blended += any ? 1u : 0u;
+#endif
                 if (!any) continue;  // wave-uniform: inside the ellipse's reach, but no pixel blends it -- dead, no row
                 alive |= 1ull << j;
                 // the lane's nine values: colour r, g, b | moments dx, dy | dx^2, dx dy, dy^2 | 1
@@ -303,7 +316,26 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
             }
         }
     }
+#if RB4_TRACE
+    if (threadIdx.x == 0) {
+        const unsigned long long tr_t1 = __builtin_readcyclecounter(), tr_w1 = wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        const unsigned long long i = atomicAdd(&rb4_trace[4 * 65536], 1ull) & 65535ull;
+        // (s_memtime is a per-CU counter: durations only; start / end on the constant 100 MHz clock)
+        rb4_trace[4 * i] = tr_w0, rb4_trace[4 * i + 1] = tr_w1, rb4_trace[4 * i + 2] = ((unsigned long long)xcc << 32) | hw;
+        rb4_trace[4 * i + 3] = ((tr_t1 - tr_t0) << 32) | ((unsigned long long)tr_blended << 24) | ((unsigned long long)tile << 4) | (unsigned)(slot & 15);
+    }
+#endif
 }
+#if RB4_TRACE
+extern "C" int dgm_debug_rb4_trace(void* dst, size_t bytes, int reset) {
+    int e = (int)hipDeviceSynchronize();
+    if (!e) e = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rb4_trace), bytes);
+    unsigned long long z = 0;
+    if (!e && reset) e = (int)hipMemcpyToSymbol(HIP_SYMBOL(rb4_trace), &z, 8, 4 * 65536 * 8);
+    return e;
+}
+#endif
 
 void launch_render_bwd4(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--kind", default="init")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--profile", type=int, default=1)
+    ap.add_argument("--trace", action="store_true", help="per-wave timeline of render_bwd4 (needs a library built with -DRB4_TRACE=1)")
+    ap.add_argument("--hist", action="store_true", help="tile-list length / replay-bound statistics of the frame")
     args = ap.parse_args()
     c = syn.CONFIGS[args.cfg]
     P, W, H = c["P"], c["W"], c["H"]
@@ -78,6 +80,54 @@ def main():
     res.update(cfg=args.cfg, kind=args.kind, P=P, W=W, H=H, R=int(n), vis=float((radii > 0).float().mean()),
                meanT=float(0))
     print(json.dumps(res), flush=True)
+    if args.trace:
+        import ctypes
+        fn = L.lib().dgm_debug_rb4_trace
+        fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int], ctypes.c_int
+        buf = np.zeros(4 * 65536 + 1, np.uint64)
+        fn(buf.ctypes.data, buf.nbytes, 1)
+        n2, color, radii, geom, binning, img = R._C.rasterize_gaussians(bg, means3D, e, opac, scales, rots, 1.0, e, vm, pm,
+                                                                       tanx, tany, H, W, sh, 3, campos, False, False)
+        R._C.rasterize_gaussians_backward(bg, means3D, radii, e, scales, rots, 1.0, e, vm, pm, tanx, tany, dL, sh, 3, campos,
+                                          geom, n2, binning, img, False)
+        fn(buf.ctypes.data, buf.nbytes, 0)
+        cnt = int(buf[-1])
+        t = buf[:4 * cnt].reshape(cnt, 4)
+        # start / end on the constant 100 MHz clock (10 ns), duration in shader cycles (s_memtime is per CU: differences only)
+        w0, w1 = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+        hw, xcc = (t[:, 2] & 0xffffffff).astype(np.int64), (t[:, 2] >> 32).astype(np.int64) & 15
+        dur, blended = (t[:, 3] >> 32).astype(np.int64), (t[:, 3] >> 24).astype(np.int64) & 255
+        tile, slot = (t[:, 3] >> 4).astype(np.int64) & 0xfffff, t[:, 3].astype(np.int64) & 15
+        simd, cu, sh_, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+        base = w0.min()
+        us = lambda v: round(float(v) * 0.01, 2)
+        print("waves with work", cnt, "| kernel span", us(w1.max() - base), "us | starts p50/p99/max", [us(np.percentile(w0 - base, p)) for p in (50, 99, 100)],
+              "| ends p10/p50/p90", [us(np.percentile(w1 - base, p)) for p in (10, 50, 90)])
+        print("wave duration (shader cycles) p10/p50/p90/max", [int(np.percentile(dur, p)) for p in (10, 50, 90, 100)], "| blended entries p50/max",
+              int(np.median(blended)), int(blended.max()), "| cycles per blended entry p50", round(float(np.median(dur[blended > 8] / blended[blended > 8]))))
+        key = (((xcc * 8 + se) * 2 + sh_) * 16 + cu) * 4 + simd
+        uniq, inv = np.unique(key, return_inverse=True)
+        per = np.bincount(inv)
+        work = np.bincount(inv, weights=blended)
+        endt = np.zeros(len(uniq)); np.maximum.at(endt, inv, w1 - base)
+        print("SIMDs that got a wave", len(uniq), "| waves per SIMD p10/p50/p90/max", [int(np.percentile(per, p)) for p in (10, 50, 90, 100)],
+              "| blended entries per SIMD p10/p50/p90/max", [int(np.percentile(work, p)) for p in (10, 50, 90, 100)],
+              "| last end per SIMD (us) p10/p50/p90/max", [us(np.percentile(endt, p)) for p in (10, 50, 90, 100)])
+        print("correlation(last end of a SIMD, its blended entries)", round(float(np.corrcoef(endt, work)[0, 1]), 3),
+              "| waves per XCC", np.bincount(xcc, minlength=8).tolist())
+    if args.hist:
+        import ctypes
+        lay = L.StateLayout()
+        L.check(L.lib().dgm_describe_state(P, W, H, int(n), ctypes.byref(lay)))
+        tiles = lay.tiles_x * lay.tiles_y
+        raw = img.cpu().numpy().tobytes()
+        pad = (-img.data_ptr()) % 256
+        rg = np.frombuffer(raw, dtype=np.uint32, count=tiles * 2, offset=pad + lay.ranges).reshape(tiles, 2)
+        ln = (rg[:, 1] - rg[:, 0]).astype(np.int64)
+        npr = np.frombuffer(raw, dtype=np.uint32, count=tiles, offset=pad + lay.nproc).astype(np.int64)
+        q = lambda v: [int(np.percentile(v, p)) for p in (50, 90, 99, 100)]
+        print("tiles", tiles, "empty", int((ln == 0).sum()), "list length p50/p90/p99/max", q(ln), "replayed p50/p90/p99/max", q(npr),
+              "sum replayed", int(npr.sum()), "units64", int(((npr + 63) // 64).sum()), "tiles > 4096:", int((ln > 4096).sum()))
 
 
 if __name__ == "__main__":
