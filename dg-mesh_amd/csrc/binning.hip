@@ -768,6 +768,9 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
 hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint4* inst, uint2* pairs, size_t R,
                             unsigned* point_list, unsigned* upos, const unsigned* big_list, const unsigned* big_count) {
     static_assert(kSmallCap == 8 * 64 * 8, "tile_sort_radix_mid_kernel covers segments up to kSmallCap");
+    // (tried: the mid worklist and the one-tile-per-workgroup class in ONE launch of 512-thread workgroups, short segments on eight
+    // waves with four pairs a thread, so that the mid class's 32 us would run beside the short class: 84 -> 97-100 us at cfg2 --
+    // eight waves pay twice the counter scan and barrier population for a 2048-entry segment)
     hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(768), dim3(512), 0, st, tiles, big_list, big_count + 1, ranges, inst,
                        point_list, upos);
     hipLaunchKernelGGL(tile_sort_radix_kernel, dim3(tiles), dim3(256), 0, st, ranges, inst, point_list, upos);
