@@ -71,6 +71,9 @@ def check_forward(orc, a, f_hip, exact_geom=True):
     return f
 
 
+MAX_TOL = 1e-5
+
+
 def check_backward(orc, a, f_or, f_hip, seed=0, tol=1e-4):
     H, W = a["H"], a["W"]
     dL = np.random.RandomState(seed).randn(3, H, W).astype(np.float32)
@@ -89,6 +92,13 @@ def check_backward(orc, a, f_or, f_hip, seed=0, tol=1e-4):
         bound = tol * np.abs(ref).max() + tol * np.abs(ref)
         bad = err > bound
         assert not bad.any(), f"{k}: {bad.sum()} elements, worst rel-to-max {G.rel_to_max(g_hip[k], ref):.3e}"
+        # ... which is north_star's 1e-4 read per element.  What the kernels actually hold against the oracle's exactly
+        # summed gradients (fp32 per-pixel terms, double accumulation) is two orders tighter: every element within
+        # MAX_TOL of the tensor's largest (measured: 0.3-1.5e-6 on the BASELINE-like scenes, 4.3e-6 at worst over this file's
+        # cases; the reference's own kernels with their float atomics: 0.15-0.8e-6)
+        worst = err.max() / max(np.abs(ref).max(), 1e-30)
+        print(f"[backward] {k}: worst error / max = {worst:.2e}")
+        assert worst <= MAX_TOL, f"{k}: worst error {worst:.2e} of the tensor's maximum"
     return g_hip
 
 

@@ -33,6 +33,7 @@ def compare_forward(ref, other, frag, exact_n=True):
 
 GRAD_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dcolors")
 REL_FLOOR, REL_TOL, REL_TOL_P999 = 1e-3, 2e-2, 2e-3
+MAX_TOL = 1e-5
 
 
 def compare_grads(ref, other, tol=1e-4):
@@ -49,6 +50,9 @@ def compare_grads(ref, other, tol=1e-4):
         mx = np.abs(a64).max()
         bad = err > tol * mx + tol * np.abs(a64)
         assert not bad.any(), f"{k}: {bad.sum()} elements, rel-to-max {G.rel_to_max(b, a):.2e}"
+        # (the literal 1e-4; what holds in fact is ten times tighter -- every element within 1e-5 of the tensor's largest:
+        # the reference's float atomics and this path's fixed-order sums each sit ~1e-6 from the exactly summed gradient)
+        assert err.max() <= MAX_TOL * mx, f"{k}: worst error {err.max() / mx:.2e} of the tensor's maximum"
         big = np.abs(a64) > REL_FLOOR * mx
         if big.any():
             rel = err[big] / np.abs(a64[big])
