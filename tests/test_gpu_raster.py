@@ -64,8 +64,9 @@ def check_forward(orc, a, f_hip, exact_geom=True):
     assert np.array_equal(f_hip["n_contrib"][ok_n], img["n_contrib"][ok_n])
     ok_c = (frag & 1) == 0
     err = np.abs(f_hip["color"] - f["color"])
-    assert err[:, ok_c].max() <= 1e-4, err[:, ok_c].max()
-    assert np.abs(f_hip["final_T"] - img["final_T"])[ok_c].max() <= 1e-4
+    # (north_star's bound is 1e-4; the kernels hold 1e-5 -- measured 2e-7 .. 2e-6 for the colour, <= 3.5e-6 for T over this file)
+    assert err[:, ok_c].max() <= 1e-5, err[:, ok_c].max()
+    assert np.abs(f_hip["final_T"] - img["final_T"])[ok_c].max() <= 1e-5
     # fragile pixels may differ by one threshold decision: bounded by alpha*T <= ~1/255 per decision
     assert err.max() <= 0.05
     return f
