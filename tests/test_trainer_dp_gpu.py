@@ -163,7 +163,7 @@ def test_mesh_phase_step_runs_the_dpsr_chain_and_moves_every_network():
     torch.cuda.synchronize()
     assert torch.isfinite(la) and abs(float(la) - float(lb)) < 1e-5 * abs(float(la))
     for x, y in zip(a.params, b.params):  # (Adam turns a rounding-level gradient difference into at most +-lr per step)
-        assert float((x - y).abs().max()) <= 5e-3
+        assert float((x.detach() - y.detach()).abs().max()) <= 5e-3
     moved = [not torch.equal(x.detach(), y) for x, y in zip(a.params, before)]
     off = 6
     for m in [a.deform, a.deform_back] + a.mesh.networks():
