@@ -413,6 +413,9 @@ __device__ __forceinline__ void reduce_heads_body(int bx, int o, int chunks, int
 // the piece is written transposed into the PyTorch (out, in) layout.  With eight layers in the grid there are enough
 // workgroups (>= 2048) to read in segments of 256+ bytes and still fill the chip, which a single layer's launch could not.
 // The first 32 workgroups of a layer also reduce eight columns each of its bias-gradient rows (db_rows of them).
+// (round 4, measured at N = 100 k: 86-88 us whatever the piece shape -- RDW_KT = 1, 2, 4, 8, i.e. segments of 1 KB .. 128 B --
+// and whatever the distance between consecutive chunks' tiles -- 256 KB, or padded by 256 B / 4 KB / 8.25 KB against channel
+// aliasing: 323 MB of L2 misses at 3.7 TB/s is what a read of tiles the previous launches just wrote gets here)
 #ifndef RDW_KT
 #define RDW_KT 4
 #endif
