@@ -338,7 +338,7 @@ def main():
     tr, (P, W, H) = build_scene(dev, rank, world, mlp_impl, phase=args.phase, dpsr_res=args.dpsr_res, n_verts=args.verts)
     it0 = tr.opt.warm_up + 2000  # "deformation MLP on" phase (warm_up <= it < dpsr_iter)
     if args.phase == "mesh":     # every network on, positions unfrozen (it >= dpsr_iter + max(normal_warm_up, 2000))
-        it0 = tr.opt.dpsr_iter + tr.opt.normal_deform_delay + 1000
+        it0 = tr.opt.dpsr_iter + importlib.import_module("dg-mesh_amd.trainer").normal_deform_delay(tr.opt) + 1000
 
     for i in range(10):  # allocator / code-object / clock priming (untimed)
         tr.step(it0)

@@ -87,6 +87,15 @@ class FlatGradBucket:
 
 _PERM_CACHE = {}
 
+# R/train.py:127: deform_normal / deform_back_normal start this many iterations after dpsr_iter.  A module constant in the
+# reference, not a field of its OptimizationParams -- so a reference config object does not carry it.
+NORMAL_WARMUP_ITER = 2000
+
+
+def normal_deform_delay(opt):
+    """`opt.normal_deform_delay` when the config object has one (this repo's OptimizationParams), else the reference's constant."""
+    return getattr(opt, "normal_deform_delay", NORMAL_WARMUP_ITER)
+
 
 def frame_schedule(n_frames, step, rank, world, seed=0):
     """Index of the camera rank `rank` renders at `step`: a shared-seed shuffle per epoch, strided by rank."""
@@ -378,7 +387,7 @@ class Trainer:
         g, opt, ms = self.g, self.opt, self.mesh
         N = g.get_xyz.shape[0]
         xyz_d = g.get_xyz.detach()
-        normal_nets = iteration >= opt.dpsr_iter + opt.normal_deform_delay
+        normal_nets = iteration >= opt.dpsr_iter + normal_deform_delay(opt)
         d_normal = ms.deform_normal.step(xyz_d, t_fwd) if normal_nets else None         # R/train.py:170-175
         if normal_nets:                                                                   # R/train.py:225-235: cycle / 4
             d_normal_back = ms.deform_back_normal.step(xyz_d, t_back)

@@ -41,7 +41,17 @@ for src, name in ((R + "/gaussian_renderer/__init__.py", "gaussian_renderer.pyc"
                   (R + "/utils/rigid_utils.py", "rigid_utils.pyc"),
                   # the networks and the image loss of the train step, for bench.py's cpu_baseline leg (the reference's own modules
                   # on the host cores; pure torch, they import nothing but utils.rigid_utils)
-                  (R + "/utils/time_utils.py", "time_utils.pyc"), (R + "/utils/loss_utils.py", "loss_utils.pyc")):
+                  (R + "/utils/time_utils.py", "time_utils.pyc"), (R + "/utils/loss_utils.py", "loss_utils.pyc"),
+                  # the configuration objects of train.py:858-906 (argparse groups + the YAML merge), for
+                  # tests/test_reference_configs.py: the reference's own OptimizationParams / PipelineParams / ModelParams
+                  # merged with its shipped YAML files drive Trainer.step
+                  (R + "/arguments/__init__.py", "arguments.pyc"), (R + "/utils/system_utils.py", "system_utils.pyc")):
     py_compile.compile(src, cfile=os.path.join(out, name), dfile=os.path.basename(src), doraise=True)
 print("build_ref: wrote pyref/", sorted(os.listdir(out)))
+# the reference's shipped YAML configs (data files read by the test above at run time; oracle/_ref is git-ignored)
+import shutil
+cfg_out = os.path.join(os.path.dirname(out), "configs")
+shutil.rmtree(cfg_out, ignore_errors=True)
+shutil.copytree(R + "/configs", cfg_out)
+print("build_ref: copied configs/", sum(len(f) for _, _, f in os.walk(cfg_out)), "files")
 PY
