@@ -12,10 +12,11 @@ Frames shard across ranks (weak scaling: every rank renders its own 800x800 fram
 
 Rank 0 prints ONE JSON line.  `value` = frames trained per second over all ranks, inputs resident in HBM.
 `roofline` describes the DOMINANT hand-written kernel of the step -- chosen at run time as the instrumented kernel
-with the largest (average launch time x launches per step); today one 256 -> 256 trunk-layer GEMM of the deformation
-MLP (mlp_gemm3p_kernel) -- timed with hipEvents recorded on the launch stream inside the timed region (deferred
-read-out, no extra sync) and priced against BOTH roofs it can hit: HBM (algorithmic bytes / 8 TB/s) and the f16
-matrix pipe it issues on (3 MFMAs per fp32 product: 3 x flops / 2.5 PFLOP/s); `bound` is the nearer one.
+with the largest (average launch time x launches per step); today the paired backward launch of a 256 -> 256 trunk layer
+(mlp_bwd_pair_kernel: backward data + weight gradient on plane-format activations) -- timed with hipEvents recorded on
+the launch stream inside the timed region (deferred read-out, no extra sync) and priced against BOTH roofs it can hit:
+HBM (algorithmic bytes / 8 TB/s) and the f16 matrix pipe it issues on (3 MFMAs per fp32 product: 3 x flops /
+2.5 PFLOP/s); `bound` is the nearer one.
 `roofline_render_bwd` is the rasterizer backward, the kernel group BASELINE.json's north_star grades against HBM.
 `kernels` lists the same two fractions for every instrumented kernel.  When K < 200 a second, 200-step steady-state
 region is timed and reported as `steady_state` (SURVEY.md section 8d asks for >= 200 iterations).
@@ -26,8 +27,11 @@ carries the RCCL world size observed and the all-reduce of the step's gradient b
 region at N = 1.  `roofline_render_bwd_trained` = the rasterizer backward on SURVEY.md section 8(d)'s trained-like scene (the
 distribution on which north_star's HBM target is approachable), measured here with the library's stage timers; `frac_valu` of
 the blend kernels comes from the committed PMC pass (VALU lane operations / 78.6 T lane-op/s).
-`cpu_baseline` = the same step on the host cores (oracle rasterizer + PyTorch-CPU MLPs; a port of the reference's CPU
-path, not the reference itself, which is not on the GPU box), rank 0 at N=1 only, on a bounded sample.
+`cpu_baseline` = the same step on the host cores: the reference's OWN network and loss modules (utils/time_utils.py,
+utils/loss_utils.py, byte-compiled by oracle/build_ref.sh; `kind: "reference modules + oracle rasterizer"`) around the
+oracle rasterizer (the reference has no CPU rasterizer); this repo's torch restatement of the modules (`kind: "port"`)
+only when the byte-compiled files are absent or do not load.  Rank 0 at N=1 only, on a bounded sample; its scene is the
+freshly initialised one (frame 0), the GPU headline's has taken ~35 Adam steps -- the two R values differ and `sample` says so.
 """
 import argparse
 import importlib
@@ -127,6 +131,8 @@ def reference_host_modules():
         sys.modules["utils"] = types.ModuleType("utils")
         load("utils.rigid_utils", "rigid_utils.pyc")
         return load("ref_time_utils", "time_utils.pyc"), load("ref_loss_utils", "loss_utils.pyc")
+    except Exception:  # present but unloadable (another Python's magic number, a missing import): the port is timed instead
+        return None
     finally:
         for k, v in saved.items():
             if v is None:
@@ -135,7 +141,7 @@ def reference_host_modules():
                 sys.modules[k] = v
 
 
-def cpu_baseline(P, W, H, max_threads=32):
+def cpu_baseline(P, W, H, max_threads=32, headline_R=None):
     """The same train step on the host: the reference's own network and loss modules on PyTorch-CPU (this repo's torch
     restatement of them only if the byte-compiled modules are absent) around the oracle rasterizer (C, OpenMP; the reference
     has no CPU rasterizer).  A few steps of the full cfg2 workload are the bounded sample."""
@@ -205,7 +211,9 @@ def cpu_baseline(P, W, H, max_threads=32):
     return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": kind,
             "sample": f"{n_steps} full {WORKLOAD} train steps ({W}x{H}, P={P}, R={f['num_rendered']}): oracle rasterizer "
                       f"fwd+bwd (C/OpenMP; the reference has no CPU rasterizer) + {what} + torch.optim.Adam on PyTorch-CPU, "
-                      f"{dt:.1f} s each"}
+                      f"{dt:.1f} s each.  Inputs are NOT identical to the GPU headline's: fresh networks and frame 0 here "
+                      f"(R={f['num_rendered']}), the headline's scene after its warm-up Adam steps"
+                      + (f" (R={headline_R})" if headline_R else "")}
 
 
 def trained_like_render_bwd(dev, iters=12):
@@ -408,6 +416,7 @@ def main():
         steady = {"steps": STEADY_STEPS, "value": STEADY_STEPS * world / s_dt, "ms_per_step": 1e3 * s_dt / STEADY_STEPS}
 
     n_inst_timed = int(RZ.LAST_NUM_RENDERED)  # tile instances R of the timed workload's last frame (the extras below render other scenes)
+    n_live_timed = RZ.live_rows() if rank == 0 else None  # gradient rows its backward wrote (what preprocess_bwd reads)
     # the gradient buckets' all-reduce on its own (what one step exchanges; in the step the larger bucket runs under the MLP
     # backward passes)
     allreduce = None
@@ -527,7 +536,9 @@ def main():
             "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r04_pmc_render_bwd4.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
             "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
-            "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 48.0 * n_inst, None),
+            # 559 B per Gaussian + the 36-byte rows some pixel blended (live rows; the others are neither written nor read)
+            "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 36.0 * (n_live_timed if n_live_timed is not None else n_inst),
+                               "r04_pmc_preprocess_bwd.json"),
             "preprocess_fwd": ("preprocess_fwd_kernel", 0.0, 311.0 * P, None),
         }
         kernels, best, best_ms = {}, None, -1.0
@@ -583,7 +594,7 @@ def main():
                                     "field is small as after convergence (default init triples every splat's extent)") if WORKLOAD == "cfg2" else
                                    f"{WORKLOAD} of BASELINE.json: {W}x{H}, P={P} Gaussians, deformation MLP on, 1 frame per rank per "
                                    "step, fixed P",
-                       "P": P, "W": W, "H": H, "num_rendered": n_inst, "visible": R, "mlp_impl": mlp_impl,
+                       "P": P, "W": W, "H": H, "num_rendered": n_inst, "live_rows": n_live_timed, "visible": R, "mlp_impl": mlp_impl,
                        "parallelism": f"dp{world} (frame-parallel, flat-bucket all-reduce {tr.grad_bytes() / 1e6:.1f} MB)"},
             "roofline": roof,
             # the rasterizer backward, graded against HBM by BASELINE.json's north_star (VALU-bound in practice:
@@ -620,7 +631,7 @@ def main():
             out["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(P, W, H)
+                out["cpu_baseline"] = cpu_baseline(P, W, H, headline_R=n_inst)
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         if WORKLOAD == "cfg2":  # informational, offline: the reference's own step on this GPU model (a -m gpu test measures it)

@@ -21,9 +21,9 @@ Data parallelism (absent in the reference; BASELINE.json north_star): one proces
 ranks, every rank holds a full replica of the Gaussians and MLPs.
   * all ranks derive the same shuffled camera order from a shared seed; rank r takes entries r, r+W, ... so one
     step consumes W frames (effective batch W);
-  * gradients are exchanged as flat fp32 buckets over RCCL/xGMI.  Default: ONE bucket (Gaussian + MLP gradients, 35 MB at
+  * gradients are exchanged as flat fp32 buckets over RCCL/xGMI.  Default: ONE bucket (Gaussian + MLP gradients, 27.8 MB at
     P=100k) all-reduced after backward on the current stream.  `overlap=True` (opt-in): two buckets -- the Gaussian gradients
-    (25 MB), whose all-reduce is launched from an autograd hook as soon as they are final and runs (on RCCL's own queue) under
+    (23.6 MB), whose all-reduce is launched from an autograd hook as soon as they are final and runs (on RCCL's own queue) under
     the two MLP backward passes, and the MLP gradients after backward.  It is opt-in until a multi-GPU run has shown the
     replicas bit-identical with it on (bench.py prints `replicas_identical` for both forms); DESIGN.md section 6.
     On the GPU the step's fresh gradients are packed into the bucket by one multi-tensor copy ("pack" mode; no per-tensor
@@ -228,7 +228,7 @@ class Trainer:
         self.params = [p for p in params if p.requires_grad]
         # "pack": gradients are fresh tensors every step (no accumulate kernels); "views": .grad lives in the bucket
         self.bucket = FlatGradBucket(params, attach=not self.pack) if (not self.pack or self.world > 1) else None
-        # Overlap (pack mode, world > 1): the Gaussian gradients (6 tensors, 25 MB at P = 100k) are final as soon as the
+        # Overlap (pack mode, world > 1): the Gaussian gradients (6 tensors, 23.6 MB at P = 100k) are final as soon as the
         # rasterizer / glue backward has run, long before the two MLP backward passes finish.  A post-accumulate hook
         # counts them down and launches their all-reduce asynchronously (RCCL's own stream) while autograd is still in the
         # MLPs; the MLP bucket follows after backward, and both are awaited right before the Adam launch.
