@@ -59,7 +59,8 @@ SYMBOLS = {
     "dgm_get_stage_ms": (_i, [_c.POINTER(_f), _i]),
     "dgm_collect_stage_ms": (_i, [_c.POINTER(_f), _c.POINTER(_i), _i]),
     "dgm_stage_name": (_c.c_char_p, [_i]),
-    "dgm_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp]),
+    "dgm_knn_scratch_bytes": (_c.c_size_t, [_i]),
+    "dgm_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp, _vp]),
     "dgm_image_loss_workspace_bytes": (_c.c_size_t, [_i, _i, _i]),
     "dgm_image_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "dgm_image_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
@@ -92,6 +93,7 @@ SYMBOLS = {
 }
 
 _LIB = None
+ABI_VERSION = 3  # DGM_ABI_VERSION of include/dgmesh_hip.h
 
 
 def build(force=False, verbose=False):
@@ -121,8 +123,8 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header and library out of sync
             fn.restype = res
             fn.argtypes = args
-        if handle.dgm_abi_version() != 2 and not (os.environ.get("DGM_LIB_PATH") and os.environ.get("DGM_ABI_ANY") == "1"):
-            raise RuntimeError("libdgmesh_hip.so ABI version mismatch")  # (DGM_ABI_ANY: A/B timing of an older build, tools/ only)
+        if handle.dgm_abi_version() != ABI_VERSION:  # no bypass: struct layouts and argtypes below belong to exactly this version
+            raise RuntimeError(f"libdgmesh_hip.so ABI version {handle.dgm_abi_version()} != {ABI_VERSION} (rebuild: __graft_entry__.build())")
         _LIB = handle
     return _LIB
 

@@ -203,11 +203,6 @@ int check_launch(const char* what, bool debug, hipStream_t st) {
         if (check_launch(what, debug != 0, st)) return 1; \
     } while (0)
 
-// knn scratch arena (grow-only, one per device; simple-knn is an init-time / anchoring-time call)
-std::mutex g_knn_mu;
-char* g_knn_scratch_dev[DGM_MAX_DEVICES] = {nullptr};
-size_t g_knn_cap_dev[DGM_MAX_DEVICES] = {0};
-
 }  // namespace
 
 extern "C" {
@@ -527,26 +522,13 @@ int dgm_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     return 0;
 }
 
-int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, void* stream) {
+size_t dgm_knn_scratch_bytes(int P) { return P > 0 ? knn_scratch_bytes(P) : 0; }
+
+int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, char* scratch, void* stream) {
     if (P <= 0) return 0;
-    if (!points || !mean_dists) return fail("knn_mean_dist2: NULL pointer");
-    hipStream_t st = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lk(g_knn_mu);
-    const int slot = current_device_slot();
-    char*& g_knn_scratch = g_knn_scratch_dev[slot];
-    size_t& g_knn_cap = g_knn_cap_dev[slot];
-    const size_t need = knn_scratch_bytes(P);
-    if (need > g_knn_cap) {
-        if (g_knn_scratch) {
-            DGM_HIP(hipDeviceSynchronize());
-            DGM_HIP(hipFree(g_knn_scratch));
-            g_knn_scratch = nullptr;
-            g_knn_cap = 0;
-        }
-        DGM_HIP(hipMalloc((void**)&g_knn_scratch, need));
-        g_knn_cap = need;
-    }
-    launch_knn(st, P, points, mean_dists, g_knn_scratch);
+    if (!points || !mean_dists || !scratch) return fail("knn_mean_dist2: NULL pointer");
+    if ((uintptr_t)scratch & 255) return fail("knn_mean_dist2: scratch must be 256-byte aligned");
+    launch_knn((hipStream_t)stream, P, points, mean_dists, scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("knn_mean_dist2: %s", hipGetErrorString(e));
     return 0;

@@ -15,7 +15,10 @@ def distCUDA2(points):
     pts = points.contiguous().float()
     means = torch.zeros((P,), dtype=torch.float32, device=points.device)  # torch::full({P}, 0.0), spatial.cu:21
     if P:
+        L = _lib.lib()
+        # scratch is caller-owned like every buffer of the C ABI: a torch allocation (256-byte aligned by the caching allocator)
+        scratch = torch.empty((int(L.dgm_knn_scratch_bytes(P)),), dtype=torch.uint8, device=points.device)
         with _lib.device_guard(points.device):
-            _lib.check(_lib.lib().dgm_knn_mean_dist2(P, ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(means.data_ptr()),
-                                                     _lib.stream_ptr()))
+            _lib.check(L.dgm_knn_mean_dist2(P, ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(means.data_ptr()),
+                                            ctypes.c_void_p(scratch.data_ptr()), _lib.stream_ptr()))
     return means

@@ -81,6 +81,14 @@ class MultiAdam:
         the bound state every 64 calls)."""
         f32, ptrs = torch.float32, []
         params, shapes = pl["params"], pl["shapes"]
+        # the bound state must still be the live one: in-place surgery on an unchanged Parameter (state[p] replaced, a moment or
+        # the step tensor swapped, p.data re-pointed) sends the call down the general path, which binds again
+        entries, slots, mom, Pp = pl["entries"], pl["slots"], pl["mom"], pl["P"]
+        for k_, i in enumerate(pl["act"]):
+            sl, m = slots[i], mom[i]
+            if entries[i][0].state.get(params[i]) is not sl or sl.get("exp_avg") is not m[0] or sl.get("exp_avg_sq") is not m[1] \
+                    or sl.get("step") is not m[2] or params[i].data_ptr() != Pp[k_]:
+                return False
         try:
             if grads is None:
                 for i in pl["act"]:
@@ -158,6 +166,7 @@ class MultiAdam:
             keep = []    # gradient tensors made contiguous for this call
             active = []  # entries that take part in this call
             pos = pl["pos"]  # array position each entry had in the previous call (-1: took no part): the cached pointers at a
+            host_steps = pl["steps"].tolist()  # (the step tensors are views into this host tensor: an in-place edit of one shows here)
             for i, (o, g, p) in enumerate(entries):  # position are valid as long as the same entry lands there again
                 gr = grads.get(id(p)) if grads is not None else p.grad
                 if gr is None:
@@ -172,10 +181,12 @@ class MultiAdam:
                 # the state dict entry, its moment tensors and its step tensor must still be the ones bound last time
                 # (optimizer surgery on an unchanged Parameter, load_state_dict ...): otherwise bind again
                 if s is None or pos[i] != k or o.state.get(p) is not s or s.get("exp_avg") is not mom[i][0] \
-                        or s.get("exp_avg_sq") is not mom[i][1] or s.get("step") is not mom[i][2]:
+                        or s.get("exp_avg_sq") is not mom[i][1] or s.get("step") is not mom[i][2] or p.data_ptr() != P[k]:
                     s = self._bind(pl, i)
                     P[k], M[k], V[k], N[k] = p.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel()
                     pos[i] = k
+                else:
+                    cnt[i] = int(host_steps[i])
                 G[k], LR[k] = gr.data_ptr(), g["lr"]
                 cnt[i] += 1
                 ST[k] = cnt[i]

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define DGM_ABI_VERSION 2
+#define DGM_ABI_VERSION 3
 
 /* Allocator callback: must return a device pointer to at least `bytes` bytes (128-byte aligned),
  * valid until the matching backward has run.  Mirrors resizeFunctional, rasterize_points.cu:27-33. */
@@ -190,8 +190,13 @@ const char* dgm_stage_name(int stage);
 
 /* ---- simple-knn --------------------------------------------------------------------------- */
 
-/* points: (P,3) fp32 device; mean_dists: (P) fp32 device = mean of the 3 smallest squared distances. */
-int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, void* stream);
+/* points: (P,3) fp32 device; mean_dists: (P) fp32 device = mean of the 3 smallest squared distances.
+ * scratch: dgm_knn_scratch_bytes(P) bytes of caller-owned device memory, 256-byte aligned (Morton codes, the sort's
+ * ping-pong buffers, the sorted points and the box table; contents are meaningless between calls).  Like every other entry
+ * point the library neither allocates nor synchronises here (the reference's SimpleKNN::knn allocates five thrust vectors per
+ * call, simple_knn.cu:187-210). */
+size_t dgm_knn_scratch_bytes(int P);
+int dgm_knn_mean_dist2(int P, const float* points, float* mean_dists, char* scratch, void* stream);
 
 /* ---- deformation / appearance MLP trunk ---------------------------------------------------------- */
 

@@ -25,7 +25,7 @@ def test_build_and_exports():
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dgm_abi_version() == 2
+    assert lib.dgm_abi_version() == 3
     names = [lib.dgm_stage_name(i).decode() for i in range(L.STAGE_COUNT)]
     assert names[0] == "preprocess_fwd" and names[7] == "preprocess_bwd" and names[-2] == "mlp_layer_dw" and names[-1] == "mlp_bwd_pair"
 
@@ -66,8 +66,9 @@ def test_c_abi_argument_errors_without_gpu():
                                    None, 1.0, None, None, None, None, None, 1.0, 1.0, 0, None, None, 0, None,
                                    ctypes.byref(n))
     assert st != 0 and b"allocator" in lib.dgm_last_error()
-    assert lib.dgm_knn_mean_dist2(0, None, None, None) == 0      # P == 0 is a no-op
-    assert lib.dgm_knn_mean_dist2(5, None, None, None) != 0
+    assert lib.dgm_knn_mean_dist2(0, None, None, None, None) == 0      # P == 0 is a no-op
+    assert lib.dgm_knn_mean_dist2(5, None, None, None, None) != 0
+    assert lib.dgm_knn_scratch_bytes(0) == 0 and lib.dgm_knn_scratch_bytes(100000) > 100000 * 16  # caller-owned scratch, sized by the library
     assert lib.dgm_mark_visible(0, None, None, None, None, None) == 0
 
 

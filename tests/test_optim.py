@@ -138,6 +138,52 @@ def test_multi_adam_state_lives_in_the_optimizer_and_survives_surgery():
 
 
 @pytest.mark.gpu
+def test_multi_adam_fast_path_sees_in_place_surgery():
+    """Between two repeated calls (the cached-pointer fast path) the state of an UNCHANGED Parameter is edited in place: a moment
+    tensor replaced, the step tensor replaced, the parameter's storage re-pointed.  Every edit must reach the next step, as it
+    would with torch.optim.Adam."""
+    O = pkg("optim")
+    dev = "cuda"
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(50, 3, device=dev)), torch.nn.Parameter(torch.randn(7, device=dev))]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = torch.optim.Adam([{"params": [ps[0]], "lr": 0.01}, {"params": [ps[1]], "lr": 0.02}], eps=1e-15)
+    ref = torch.optim.Adam([{"params": [rs[0]], "lr": 0.01}, {"params": [rs[1]], "lr": 0.02}], eps=1e-15)
+    ma = O.MultiAdam([opt])
+
+    def both(k):
+        for p, r in zip(ps, rs):
+            g = torch.full_like(p, 0.1 * (k + 1))
+            p.grad, r.grad = g, g.clone()
+        ma.step()
+        ref.step()
+
+    for k in range(3):      # the third call runs on cached pointers
+        both(k)
+    # (1) reset one moment by replacing the tensor (what replace_tensor_to_optimizer does to a kept Parameter)
+    opt.state[ps[0]]["exp_avg"] = torch.zeros_like(ps[0])
+    ref.state[rs[0]]["exp_avg"] = torch.zeros_like(rs[0])
+    both(3)
+    # (2) rewind the step count by replacing the step tensor
+    opt.state[ps[1]]["step"] = torch.tensor(1.0)
+    ref.state[rs[1]]["step"] = torch.tensor(1.0)
+    both(4)
+    both(5)
+    # (3) re-point the parameter's storage
+    ps[0].data = ps[0].data.clone() * 0.5
+    rs[0].data = rs[0].data.clone() * 0.5
+    both(6)
+    # (4) edit the step count in place
+    opt.state[ps[1]]["step"].fill_(10.0)
+    ref.state[rs[1]]["step"].fill_(10.0)
+    for k in range(7, 7 + 70):  # past the 64-call revalidation of the general path
+        both(k)
+    for p, r in zip(ps, rs):
+        assert torch.allclose(p, r, rtol=2e-6, atol=1e-7), (p - r).abs().max()
+    assert int(opt.state[ps[1]]["step"]) == int(ref.state[rs[1]]["step"])
+
+
+@pytest.mark.gpu
 def test_adam_step_more_than_64_tensors_with_empty_ones():
     """dgm_adam_step batches 64 tensors per launch; empty tensors are skipped without disturbing the batching (each
     tensor must be updated exactly once)."""
