@@ -1244,6 +1244,84 @@ int dgm_p4_timing(unsigned long long* out) {  // (variant builds only: phase tim
 }
 #endif
 
+#ifdef P4_PROBE
+// (variant builds only, tools/power_probe.py: ONE plane-path kernel in a loop on synthetic operands, for clock / power telemetry)
+//   kind 0: forward layer GEMM (mlp_gemm4_kernel<16,1024,512,0>)   1: weight gradient alone (mlp_dw4_kernel<8,8>)
+//   kind 2: the paired backward launch (mlp_bwd_pair_kernel, the production split)        3: backward-data GEMM alone
+// zero != 0: all operands zero (same instruction stream, no data toggling).  The buffers are this probe's own.
+namespace {
+__global__ void p4_probe_fill_kernel(unsigned* __restrict__ p, size_t n, unsigned seed, int zero) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15, x *= 0x2c1b3c6du, x ^= x >> 12;
+        // two binary16 values of magnitude < 2: sign | exponent <= 15 | mantissa
+        p[i] = zero ? 0u : (x & 0xbfffbfffu);
+    }
+}
+}  // namespace
+int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const P4Plan pl = p4_plan(N);
+    const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
+    static unsigned char *A = nullptr, *C = nullptr, *G = nullptr;
+    static int* ex = nullptr;
+    static uint4* Bp = nullptr;
+    static float *binv = nullptr, *bias = nullptr, *partial = nullptr, *pdb = nullptr;
+    static unsigned* mask = nullptr;
+    static int cap = 0;
+    const size_t rows = (size_t)nt * 32;
+    if (cap < nt) {
+        if (hipMalloc((void**)&A, rows * 1024) != hipSuccess || hipMalloc((void**)&C, rows * 1024) != hipSuccess ||
+            hipMalloc((void**)&G, rows * 1024) != hipSuccess || hipMalloc((void**)&ex, (size_t)nt * 4 * 4) != hipSuccess ||
+            hipMalloc((void**)&Bp, 16 * 4 * 256 * 16) != hipSuccess || hipMalloc((void**)&binv, 256) != hipSuccess ||
+            hipMalloc((void**)&bias, 1024) != hipSuccess || hipMalloc((void**)&mask, (size_t)nt * 1024) != hipSuccess ||
+            hipMalloc((void**)&partial, (size_t)256 * 256 * 256 * 4) != hipSuccess || hipMalloc((void**)&pdb, (size_t)256 * 8 * 256 * 4) != hipSuccess)
+            return mlp_fail("p4_probe: hipMalloc failed");
+        cap = nt;
+    }
+    hipLaunchKernelGGL(p4_probe_fill_kernel, dim3(1024), dim3(256), 0, st, (unsigned*)A, rows * 256, 1u, zero);
+    hipLaunchKernelGGL(p4_probe_fill_kernel, dim3(1024), dim3(256), 0, st, (unsigned*)G, rows * 256, 2u, zero);
+    hipLaunchKernelGGL(p4_probe_fill_kernel, dim3(64), dim3(256), 0, st, (unsigned*)Bp, (size_t)16 * 4 * 256 * 4, 3u, zero);
+    hipLaunchKernelGGL(p4_probe_fill_kernel, dim3(256), dim3(256), 0, st, mask, (size_t)nt * 256, 4u, 0);
+    (void)hipMemsetAsync(ex, 0, (size_t)nt * 4 * 4, st);
+    (void)hipMemsetAsync(bias, 0, 1024, st);
+    const float one = 1.0f / 65536.0f;
+    (void)hipMemcpyAsync(binv, &one, 4, hipMemcpyHostToDevice, st);
+    Gemm4Args a;
+    memset(&a, 0, sizeof(a));
+    a.ntiles = nt, a.M = N, a.A = kind == 0 ? A : G, a.Aexp = ex, a.Bp = Bp, a.b_inv = binv, a.bias = bias, a.mask_in = mask,
+    a.mask_out = mask + (size_t)0, a.C = C, a.Cexp = ex + nt;
+    Dw4Args d;
+    memset(&d, 0, sizeof(d));
+    d.ntiles = nt, d.tiles_per_chunk = pl.tiles_per_chunk, d.X = A, d.Xexp = ex + 2 * nt, d.G = G, d.Gexp = ex + 3 * nt, d.partial = partial,
+    d.chunk_stride = (size_t)256 * 256, d.partial_db = pdb;
+    int n_dw = p4_pair_split(nt, gx);
+    if (n_dw > pl.chunks) n_dw = pl.chunks;
+    for (int it = 0; it < iters; it++) {
+        if (kind == 0) {
+            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>), CfgFwd::LDS, gx, st, a)
+        } else if (kind == 3) {
+            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
+        } else if (kind == 1) {
+            P4_LAUNCH((mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>), CfgDw::LDS, pl.chunks, st, d)
+        } else {
+            if (n_dw <= 0) return mlp_fail("p4_probe: no pair split at this size");
+            static bool done_[DGM_MAX_DEVICES] = {false};
+            constexpr int LDS_PAIR = CfgBwd::LDS > CfgDw::LDS ? CfgBwd::LDS : CfgDw::LDS;
+            if (p4_lds_attr(mlp_bwd_pair_kernel, LDS_PAIR, &done_[current_device_slot()]) != hipSuccess) return mlp_fail("p4_probe: LDS attribute");
+            Dw4Args dp = d;
+            dp.tiles_per_chunk = (nt + n_dw - 1) / n_dw;
+            const int grid = n_dw + (gx - n_dw > 0 ? gx - n_dw : 1);
+            const int chunked = (grid - n_dw == n_dw && (n_dw % 8) == 0) ? 1 : 0;
+            hipLaunchKernelGGL(mlp_bwd_pair_kernel, dim3(grid), dim3(512), LDS_PAIR, st, a, dp, n_dw, chunked);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
+    return 0;
+}
+#endif
+
 int dgm_mlp_describe_workspace(int N, size_t* offs, int capacity) {
     Ws w = carve(nullptr, N > 0 ? N : 0);
     const char* base = nullptr;
