@@ -22,8 +22,8 @@ class StateLayout(_c.Structure):
     _fields_ = [(n, _c.c_size_t) for n in (
         "rec", "depth", "radii", "tiles_touched", "offs", "cov3D", "clamped", "block_sums", "block_offs", "hist",
         "tile_count", "tile_offset", "big_list", "counters", "geometry_bytes",
-        "inst", "point_list", "upos", "slab", "live", "ckpt", "ckpt64", "binning_bytes",
-        "final_T", "n_contrib", "ranges", "nproc", "cfin", "image_bytes")] + [
+        "inst", "point_list", "upos", "slab", "live", "ckpt", "ckpt64", "ulist_full", "binning_bytes",
+        "final_T", "n_contrib", "ranges", "nproc", "cfin", "ulist_last", "image_bytes")] + [
         (n, _c.c_int) for n in ("tiles_x", "tiles_y", "n_chunks", "chunk_size")]
 
 

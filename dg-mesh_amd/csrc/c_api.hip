@@ -40,12 +40,12 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc);
-// render_bwd3.hip
-void launch_render_bwd4(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, size_t R, unsigned* uctl,
+                       uint4* ulist_full, uint4* ulist_last, uint8_t* live);
+void launch_render_bwd4(hipStream_t st, int tiles, size_t R, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
-                        const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* nproc,
-                        const unsigned* upos, float* slab, uint8_t* live);
+                        const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* upos, float* slab,
+                        uint8_t* live, const unsigned* uctl, const uint4* ulist_full, const uint4* ulist_last);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
                            const float* shs, const float* shs_rest, const uint8_t* clamped, const float* scales,
@@ -351,7 +351,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     unsigned* counters = (unsigned*)(geom + L.counters);
 
     StageTimer tm(st);
-    DGM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), st));
+    DGM_HIP(hipMemsetAsync(counters, 0, (8 + DGM_UCTL_WORDS) * sizeof(unsigned), st));  // (+ the replay units' control block)
 
     tm.begin(DGM_STAGE_PREPROCESS);
     launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
@@ -420,7 +420,8 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
 
     tm.begin(DGM_STAGE_RENDER_FWD);
     launch_render_fwd(st, tiles, ranges, point_list, width, height, gridx, rec, background, out_color, final_T,
-                      n_contrib, ckpt, cfin, ckpt64, nproc);
+                      n_contrib, ckpt, cfin, ckpt64, nproc, (size_t)R, counters + 8, (uint4*)(bin + L.ulist_full),
+                      (uint4*)(img + L.ulist_last), (uint8_t*)(bin + L.live));
     DGM_CHECK("render_fwd");
     tm.end(DGM_STAGE_RENDER_FWD);
     tm.finish();
@@ -480,7 +481,6 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
     uint8_t* live = (uint8_t*)(bin + L.live);
     const unsigned* n_contrib = (const unsigned*)(img + L.n_contrib);
     const uint2* ranges = (const uint2*)(img + L.ranges);
-    const unsigned* nproc = (const unsigned*)(img + L.nproc);
     const float4* cfin = (const float4*)(img + L.cfin);
     const float4* ckpt = (const float4*)(bin + L.ckpt);
     const float4* ckpt64 = (const float4*)(bin + L.ckpt64);
@@ -491,8 +491,9 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
 
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
-    launch_render_bwd4(st, tiles, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, ckpt64, n_contrib,
-                       dL_dpix, nproc, upos, slab, live);
+    launch_render_bwd4(st, tiles, (size_t)R, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, ckpt64,
+                       n_contrib, dL_dpix, upos, slab, live, (const unsigned*)(geom + L.counters) + 8, (const uint4*)(bin + L.ulist_full),
+                       (const uint4*)(img + L.ulist_last));
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);
 

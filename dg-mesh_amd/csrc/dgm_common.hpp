@@ -12,6 +12,14 @@
 #define DGM_SLAB_STRIDE 9    // floats per per-instance gradient row (36 B, dword-aligned); 12 = padded to 48 B, 16-byte aligned
 #endif
 #define DGM_SHORT_LIST 4096  // tiles with at most this many list entries get 64-entry checkpoints / backward units
+// ... and 32-entry ones on sparse frames: with fewer 64-entry units than the ~5 k waves the backward keeps resident, its duration is
+// that of the unit with the most blended entries (render_bwd4.hip); finer units give the ticket scheduler something to balance.
+// A function of R alone, so the forward, the backward and the binning-buffer layout agree without further state.
+#define DGM_FINE_UNITS_BELOW (1u << 20)
+// u32 words of the replay-unit control block behind `counters` (render_bwd4.hip): word 0 = full units listed, word 32 = last units
+// listed -- each on its own 128-byte line: atomics on ONE line serialise (~88 per us), whatever the word
+#define DGM_UCTL_WORDS 64
+#define DGM_UCTL_LINE 32
 #define DGM_PRE_BLOCK 256    // Gaussians per preprocess workgroup (also the granularity of block_sums)
 #define DGM_BIN_THREADS 512  // threads of a binning chunk workgroup
 #define DGM_MAX_CHUNKS 256   // chunk workgroups = rows of the per-chunk tile histogram
@@ -22,6 +30,7 @@ namespace dgm {
 struct Layout : dgm_state_layout {};
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int replay_unit_log2(size_t R) { return R < (size_t)DGM_FINE_UNITS_BELOW ? 5 : 6; }
 
 // Pure function of (P, W, H, R): backward re-derives every pointer from the same three chunks.
 static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* L) {
@@ -58,7 +67,7 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->tile_count = take(tiles * 4);
     L->tile_offset = take((tiles + 1) * 4);
     L->big_list = take(tiles * 4);
-    L->counters = take(8 * 4);
+    L->counters = take((8 + DGM_UCTL_WORDS) * 4);  // (the replay-unit control block rides behind them: one memset clears both)
     L->geometry_bytes = o + A;
     o = 0;
     L->inst = take(Rz * 16);
@@ -67,7 +76,9 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->slab = take(Rz * (DGM_SLAB_STRIDE * 4 > 16 ? DGM_SLAB_STRIDE * 4 : 16));  // (>= 16 B per entry: the tile sort's scratch)
     L->live = take(Rz + 8);  // (+8: flags are read eight at a time)
     L->ckpt = take((Rz / 256 + 1) * 256 * 16);  // per (tile, 256-entry round boundary): (T, C) of the tile's 256 pixels
-    L->ckpt64 = take((Rz / 64 + 1) * 256 * 16);  // short tiles: per (tile, 64-entry boundary) instead
+    const int ulog = replay_unit_log2(Rz);
+    L->ckpt64 = take(((Rz >> ulog) + 1) * 256 * 16);  // short tiles: per (tile, 64- or 32-entry boundary) instead
+    L->ulist_full = take(((Rz >> ulog) + 1) * 16);  // the backward's work list: full replay units, a tile's run contiguous
     L->binning_bytes = o + A;
     o = 0;
     L->final_T = take((size_t)W * H * 4);
@@ -75,6 +86,7 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->ranges = take(tiles * 8);
     L->nproc = take(tiles * 4);
     L->cfin = take(tiles * 256 * 16);  // final (T, C) per pixel, tile-major in the backward's lane order
+    L->ulist_last = take((tiles + 1) * 16);  // ... and the tiles' last (shorter) units
     L->image_bytes = o + A;
 }
 

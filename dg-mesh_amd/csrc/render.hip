@@ -21,16 +21,20 @@
 
 namespace dgm {
 
+template <bool PREFETCH>
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
-                  float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out) {
+                  float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out, const int ulog,
+                  unsigned* __restrict__ uctl, uint4* __restrict__ ulist_full, uint4* __restrict__ ulist_last,
+                  uint8_t* __restrict__ live) {
     // staged splats, 48 bytes each: x, y, conic a * -log2(e)/2, conic b * -log2(e) | conic c * -log2(e)/2, opacity, r, g | b
     // (one record per splat: the blend loop forms ONE address per entry for its three broadcast reads)
     __shared__ float4 sR[256 * 3];
     __shared__ unsigned long long sMask[4][4];  // [staging wave][quadrant]
     __shared__ unsigned sMaxC[4];               // per-wave maximum of last_contributor
+    __shared__ unsigned sUnitBase;              // first slot of this tile's run of full units in the backward's work list
     const int tile = blockIdx.x;
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -42,16 +46,30 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int rounds = (n + 255) >> 8;
-    // short lists: the blend state is left after every 64 entries (slot (first + 64 s) / 64: unique per (tile, s)) instead of
-    // every 256, so that the backward can replay such a tile in 64-entry units on several waves (render_bwd4.hip)
+    // liveness bytes of the backward's per-instance gradient rows (render_bwd4.hip sets the ones it writes): the tiles' list
+    // ranges partition the row index space, so each tile clears a stretch as long as its list
+    for (int i = threadIdx.x; i < n; i += 256) live[range.x + i] = 0;
+    // short lists: the blend state is left after every u = 64 entries (u = 32 on sparse frames, `ulog` = log2 u; slot
+    // (first + u s) / u: unique per (tile, s)) instead of every 256, so that the backward can replay such a tile in u-entry
+    // units on several waves (render_bwd4.hip)
     const bool shortlist = n <= DGM_SHORT_LIST;
+    const int nsub = 256 >> ulog;  // checkpoint intervals per staged round
     const int lxy = (((wv >> 1) * 8 + (lane >> 3)) >> 2) * 64 + ((((wv >> 1) * 8 + (lane >> 3)) & 3) << 4) + (wv & 1) * 8 + (lane & 7);
-    float4* const c64 = ckpt64 + (size_t)(range.x >> 6) * 256 + lxy;  // + s * 256: (range.x + 64 s) >> 6 = (range.x >> 6) + s
+    float4* const c64 = ckpt64 + (size_t)(range.x >> ulog) * 256 + lxy;  // + s * 256: (range.x + u s) >> ulog = (range.x >> ulog) + s
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     unsigned last_contributor = 0;
     unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);  // lanes whose pixel is finished (wave-uniform lane mask)
 
+    // A round's staging is two dependent gathers (list slice -> records).  On a sparse (trained) frame a tile is one serial chain of
+    // rounds with about one wave per SIMD to hide them behind, so PREFETCH software-pipelines them: the next round's list entry is
+    // asked for at the top of a round's blend loop and its record half way through (by then the entry has arrived), and the next
+    // round starts from registers (trained-like 0.097 -> 0.092 ms).  It costs 19 registers -- 5 waves per SIMD instead of 6 -- which
+    // a dense frame, VALU-bound with every slot busy, pays for (0.217 -> 0.221 ms): the launch picks by R, like the unit length.
+    unsigned g_next = 0u;
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+    float ncb = 0.f;
+    bool fetched = false;  // (workgroup-uniform)
     for (int i = 0; i < rounds; i++) {
         if (__syncthreads_and(done_m == ~0ull)) break;  // also orders the previous round's LDS reads before the refill
         if (i > 0 && !shortlist) {
@@ -65,10 +83,13 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         const int at = (i << 8) + threadIdx.x;
         unsigned qm = 0;
         if (at < n) {
-            const unsigned g = point_list[range.x + at];
-            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * DGM_REC_STRIDE);
-            const float4 r0 = r4[0], r1 = r4[1];
-            const float cb = r4[2].x;
+            float4 r0 = n0, r1 = n1;
+            float cb = ncb;
+            if (!fetched) {
+                const unsigned g = point_list[range.x + at];
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * DGM_REC_STRIDE);
+                r0 = r4[0], r1 = r4[1], cb = r4[2].x;
+            }
             // the conic is staged pre-multiplied so that the exponent below comes out times log2(e), ready for v_exp_f32
             // (same sign as the reference's `power`; render_bwd4 stages the same way)
             const float l2e = 1.4426950408889634f;
@@ -84,17 +105,30 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         }
         __syncthreads();
         const unsigned base = (unsigned)(i << 8);
+        const int at_next = ((i + 1) << 8) + (int)threadIdx.x;
+        fetched = PREFETCH && i + 1 < rounds;
+        if (fetched && at_next < n) g_next = point_list[range.x + at_next];
         if (done_m == ~0ull) {  // whole quadrant finished: keep helping with staging only
             if (shortlist)
-                for (int sw = 0; sw < 4; sw++) {
-                    const int s = 4 * i + sw + 1;
-                    if (64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+                for (int sb = 0; sb < nsub; sb++) {
+                    const int s = nsub * i + sb + 1;
+                    if ((s << ulog) < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
                 }
+            if (fetched && at_next < n) {
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g_next * DGM_REC_STRIDE);
+                n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
+            }
             continue;
         }
 #pragma unroll 1
-        for (int sw = 0; sw < 4; sw++) {
+        for (int sb = 0; sb < nsub; sb++) {
+            if (sb == (nsub >> 1) && fetched && at_next < n) {  // (the list entry asked for at the top has arrived by now)
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g_next * DGM_REC_STRIDE);
+                n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
+            }
+            const int sw = ulog == 6 ? sb : sb >> 1;  // staging wave = 64-entry block of the round
             unsigned long long m = sMask[sw][wv];
+            if (ulog == 5) m &= (sb & 1) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
             m = uniform_u64(m);
             // Two list entries per trip: the second one's geometry (exponent, exp, alpha) does not depend on the first one's
             // blend, so a lone wave -- a trained scene leaves about one per SIMD -- overlaps the two dependency chains instead of
@@ -153,8 +187,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                 }
             }
             if (shortlist) {
-                const int s = 4 * i + sw + 1;
-                if (64 * s < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+                const int s = nsub * i + sb + 1;
+                if ((s << ulog) < n) c64[(size_t)s * 256] = make_float4(T, C0, C1, C2);
             }
         }
     }
@@ -162,7 +196,25 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         const unsigned m = wave_max_u32(inside ? last_contributor : 0u);
         if (lane == 0) sMaxC[wv] = m;
         __syncthreads();
-        if (threadIdx.x == 0) nproc_out[tile] = min(max(max(sMaxC[0], sMaxC[1]), max(sMaxC[2], sMaxC[3])), (unsigned)n);
+        const unsigned np = min(max(max(sMaxC[0], sMaxC[1]), max(sMaxC[2], sMaxC[3])), (unsigned)n);
+        if (threadIdx.x == 0) nproc_out[tile] = np;
+        // ... and the tile's entries of the backward's work list (render_bwd4.hip): it is replayed in units of u list entries
+        // (256 beyond DGM_SHORT_LIST), all of them full except the last; a tile with entries but nothing to replay keeps one unit
+        // (its rows have to be marked dead).  Tiles are listed in the order they finish: a tile's full units as one contiguous run
+        // of ulist_full, its last unit in ulist_last (the backward starts the long units first); two counters, each on its own
+        // 128-byte line.  Record: (tile | short flag, unit, first slot, bound).
+        if (n > 0) {
+            const unsigned nunits = max(1u, shortlist ? (np + (1u << ulog) - 1u) >> ulog : (np + 255u) >> 8);
+            const unsigned tag = (unsigned)tile | (shortlist ? 0x80000000u : 0u);
+            if (threadIdx.x == 0) {
+                sUnitBase = nunits > 1u ? atomicAdd(&uctl[0], nunits - 1u) : 0u;
+                const unsigned bl = atomicAdd(&uctl[DGM_UCTL_LINE], 1u);
+                ulist_last[bl] = make_uint4(tag, nunits - 1u, range.x, np);
+            }
+            __syncthreads();
+            uint4* dst = ulist_full + sUnitBase;
+            for (unsigned k = threadIdx.x; k + 1u < nunits; k += 256u) dst[k] = make_uint4(tag, k, range.x, np);
+        }
     }
     {   // final state (T, C without background) in the backward's pixel order, for every lane of the tile
         const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
@@ -181,9 +233,15 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
-                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc) {
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                       out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc);
+                       unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, size_t R, unsigned* uctl,
+                       uint4* ulist_full, uint4* ulist_last, uint8_t* live) {
+    const int ulog = replay_unit_log2(R);
+    if (ulog == 5)  // sparse frame
+        hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
+                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
+    else
+        hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
+                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
 }
 
 }  // namespace dgm

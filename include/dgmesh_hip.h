@@ -129,7 +129,9 @@ typedef struct {
     size_t tile_offset;   /* u32[tiles+1] */
     size_t big_list;      /* u32[tiles] worklists: tiles with more than 4096 instances from the front, tiles with 2049 ..
                              4096 from the end */
-    size_t counters;      /* u32[8]: [0] = num_rendered, [1] = error flags, [2] = big worklist length, [3] = mid worklist length, [4] = arrival counter of the tile scan */
+    size_t counters;      /* u32[8 + 64]: [0] = num_rendered, [1] = error flags, [2] = big worklist length, [3] = mid worklist length,
+                             [4] = arrival counter of the tile scan; [8] = full replay units listed, [8 + 32] = last replay units
+                             listed (the backward's work list, written by the forward; one 128-byte line each) */
     size_t geometry_bytes;
     /* binning buffer */
     size_t inst;       /* uint4[R] instance records (gaussian, depth bits, offs[g] + k, 0), grouped by tile, in arrival
@@ -143,8 +145,12 @@ typedef struct {
     size_t live;       /* u8[R] live[row] = 1 iff some pixel blended the instance, i.e. slab[row] was written by this backward */
     size_t ckpt;       /* float4[R/256 + 1][256]: (T, C.rgb) of a tile's pixels after each 256 list entries (forward ->
                           segment-parallel backward) */
-    size_t ckpt64;     /* float4[R/64 + 1][256]: tiles with <= 4096 list entries leave (T, C.rgb) after each 64 entries instead
-                          (slot (first + 64 i) / 64), so that the backward replays them in 64-entry units on more waves */
+    size_t ckpt64;     /* float4[R/u + 1][256], u = 64 (32 when R < 2^20: sparse frames): tiles with <= 4096 list entries leave
+                          (T, C.rgb) after each u entries instead (slot (first + u i) / u), so that the backward replays them in
+                          u-entry units on more waves */
+    size_t ulist_full; /* uint4[R/u + 1]: the backward's work list, full u-entry units (256-entry ones for lists beyond 4096) in the
+                          order the forward's tiles finished, a tile's run contiguous: (tile | short-list flag << 31, unit index,
+                          first list slot, replay bound) */
     size_t binning_bytes;
     /* image buffer */
     size_t final_T;   /* float[H*W] */
@@ -152,6 +158,7 @@ typedef struct {
     size_t ranges;    /* uint2[tiles] */
     size_t nproc;     /* u32[tiles] list entries the backward has to replay (deepest contributor of the tile) */
     size_t cfin;      /* float4[tiles][256]: final (T, C.rgb without background) per pixel, backward lane order */
+    size_t ulist_last; /* uint4[tiles + 1]: the tiles' last (partial) replay units, same record */
     size_t image_bytes;
     int tiles_x, tiles_y, n_chunks, chunk_size;
 } dgm_state_layout;

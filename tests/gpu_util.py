@@ -49,12 +49,16 @@ def hip_forward(a, debug=False):
         depths=view(geom, lay.depth, np.float32, P), radii_int=view(geom, lay.radii, np.int32, P),
         tiles_touched=view(geom, lay.tiles_touched, np.uint32, P), offs=view(geom, lay.offs, np.uint32, P),
         cov3D=view(geom, lay.cov3D, np.float32, P * 6).reshape(P, 6), clamped=view(geom, lay.clamped, np.uint8, P),
-        counters=view(geom, lay.counters, np.uint32, 8),
+        counters=view(geom, lay.counters, np.uint32, 8), uctl=view(geom, lay.counters + 32, np.uint32, 64),
+        nproc=view(img, lay.nproc, np.uint32, tiles), ulist_last=view(img, lay.ulist_last, np.uint32, tiles * 4).reshape(tiles, 4),
         final_T=view(img, lay.final_T, np.float32, W * H).reshape(H, W),
         n_contrib=view(img, lay.n_contrib, np.uint32, W * H).reshape(H, W),
         ranges=view(img, lay.ranges, np.uint32, tiles * 2).reshape(tiles, 2))
     if n > 0:
-        out.update(point_list=view(binning, lay.point_list, np.uint32, n), upos=view(binning, lay.upos, np.uint32, n))
+        ulog = 5 if n < (1 << 20) else 6
+        cap = (n >> ulog) + 1
+        out.update(point_list=view(binning, lay.point_list, np.uint32, n), upos=view(binning, lay.upos, np.uint32, n),
+                   ulist_full=view(binning, lay.ulist_full, np.uint32, cap * 4).reshape(cap, 4), unit_log2=ulog)
     else:
         out.update(point_list=np.zeros(0, np.uint32), upos=np.zeros(0, np.uint32))
     return out

@@ -116,6 +116,46 @@ def test_forward_backward_parity(orc, syn, kind, P, W, H, seed):
     check_backward(orc, a, f_or, f_hip, seed=seed)
 
 
+@pytest.mark.parametrize("kind,P,W,H,seed", [("init", 3000, 200, 136, 1), ("trained", 4000, 160, 160, 3), ("init", 20000, 400, 400, 0)])
+def test_replay_unit_lists_and_repeated_backward(orc, syn, kind, P, W, H, seed):
+    """The backward's work list (written by render_fwd as its tiles finish, mapped statically onto the workgroups of render_bwd4):
+    every replay unit of every tile is listed exactly once -- a tile's full units as one contiguous run of ulist_full, its last
+    unit in ulist_last -- with the record (tile | short flag, unit, first slot, replay bound); the replay bound is the tile's
+    deepest contributor.  The backward only reads the list: a second backward over the same forward state returns bit-identical
+    gradients."""
+    a = raster_args(syn, P, W, H, seed=seed, kind=kind)
+    f = G.hip_forward(a)
+    ty, tx = (H + 15) // 16, (W + 15) // 16
+    nc = np.zeros((ty * 16, tx * 16), np.int64)
+    nc[:H, :W] = f["n_contrib"]
+    deepest = nc.reshape(ty, 16, tx, 16).max(axis=(1, 3)).reshape(-1)
+    ln = f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0]
+    assert np.array_equal(f["nproc"], np.minimum(deepest, ln))
+    u = 1 << f["unit_log2"]
+    assert f["unit_log2"] == (5 if f["num_rendered"] < (1 << 20) else 6)
+    units = np.where(ln == 0, 0, np.maximum(1, np.where(ln <= 4096, (f["nproc"] + u - 1) // u, (f["nproc"] + 255) // 256)))
+    n_full, n_last = int(f["uctl"][0]), int(f["uctl"][32])
+    want_full, want_last = set(), set()
+    for t in range(tx * ty):
+        if units[t]:
+            rec = (t | (0x80000000 if ln[t] <= 4096 else 0), int(f["ranges"][t, 0]), int(f["nproc"][t]))
+            want_last.add((rec[0], int(units[t]) - 1, rec[1], rec[2]))
+            for k in range(int(units[t]) - 1):
+                want_full.add((rec[0], k, rec[1], rec[2]))
+    got_full = [tuple(int(v) for v in r) for r in f["ulist_full"][:n_full]]
+    got_last = [tuple(int(v) for v in r) for r in f["ulist_last"][:n_last]]
+    assert n_full == len(want_full) and n_last == len(want_last)  # (so: no duplicates)
+    assert set(got_full) == want_full and set(got_last) == want_last
+    for i in range(1, n_full):  # a tile's run is contiguous and in unit order
+        if got_full[i][0] == got_full[i - 1][0]:
+            assert got_full[i][1] == got_full[i - 1][1] + 1
+    dL = np.random.RandomState(seed).randn(3, H, W).astype(np.float32)
+    g1 = G.hip_backward(a, f, dL)
+    g2 = G.hip_backward(a, f, dL)
+    for k in g1:
+        assert np.array_equal(g1[k], g2[k]), k
+
+
 def test_cfg2_full_size(orc, syn):
     """BASELINE cfg2 (800x800, 100k Gaussians): full-size parity against the oracle."""
     c = syn.CONFIGS["cfg2"]

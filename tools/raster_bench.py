@@ -96,15 +96,17 @@ def main():
         # start / end on the constant 100 MHz clock (10 ns), duration in shader cycles (s_memtime is per CU: differences only)
         w0, w1 = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
         hw, xcc = (t[:, 2] & 0xffffffff).astype(np.int64), (t[:, 2] >> 32).astype(np.int64) & 15
-        dur, blended = (t[:, 3] >> 32).astype(np.int64), (t[:, 3] >> 24).astype(np.int64) & 255
-        tile, slot = (t[:, 3] >> 4).astype(np.int64) & 0xfffff, t[:, 3].astype(np.int64) & 15
+        # (round 5: one record per PERSISTENT wave: its lifetime, the list entries it blended and the units it pulled)
+        dur, blended = (t[:, 3] >> 32).astype(np.int64), (t[:, 3] >> 16).astype(np.int64) & 0xffff
+        units = t[:, 3].astype(np.int64) & 0xffff
         simd, cu, sh_, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
         base = w0.min()
         us = lambda v: round(float(v) * 0.01, 2)
-        print("waves with work", cnt, "| kernel span", us(w1.max() - base), "us | starts p50/p99/max", [us(np.percentile(w0 - base, p)) for p in (50, 99, 100)],
+        print("units per wave p10/p50/p90/max", [int(np.percentile(units, p)) for p in (10, 50, 90, 100)], "| waves without a unit", int((units == 0).sum()))
+        print("waves", cnt, "| kernel span", us(w1.max() - base), "us | starts p50/p99/max", [us(np.percentile(w0 - base, p)) for p in (50, 99, 100)],
               "| ends p10/p50/p90", [us(np.percentile(w1 - base, p)) for p in (10, 50, 90)])
         print("wave duration (shader cycles) p10/p50/p90/max", [int(np.percentile(dur, p)) for p in (10, 50, 90, 100)], "| blended entries p50/max",
-              int(np.median(blended)), int(blended.max()), "| cycles per blended entry p50", round(float(np.median(dur[blended > 8] / blended[blended > 8]))))
+              int(np.median(blended)), int(blended.max()), "| cycles per blended entry p50", round(float(np.median(dur[blended > 8] / blended[blended > 8]))) if (blended > 8).any() else None)
         key = (((xcc * 8 + se) * 2 + sh_) * 16 + cu) * 4 + simd
         uniq, inv = np.unique(key, return_inverse=True)
         per = np.bincount(inv)
@@ -112,7 +114,8 @@ def main():
         endt = np.zeros(len(uniq)); np.maximum.at(endt, inv, w1 - base)
         print("SIMDs that got a wave", len(uniq), "| waves per SIMD p10/p50/p90/max", [int(np.percentile(per, p)) for p in (10, 50, 90, 100)],
               "| blended entries per SIMD p10/p50/p90/max", [int(np.percentile(work, p)) for p in (10, 50, 90, 100)],
-              "| last end per SIMD (us) p10/p50/p90/max", [us(np.percentile(endt, p)) for p in (10, 50, 90, 100)])
+              "| last end per SIMD (us) p10/p50/p90/max", [us(np.percentile(endt, p)) for p in (10, 50, 90, 100)],
+              "| entry spread max / p50", round(float(work.max() / max(np.median(work), 1.0)), 3))
         print("correlation(last end of a SIMD, its blended entries)", round(float(np.corrcoef(endt, work)[0, 1]), 3),
               "| waves per XCC", np.bincount(xcc, minlength=8).tolist())
     if args.hist:
