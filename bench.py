@@ -514,7 +514,7 @@ def main():
             return None, None
 
         gemm_mode = L.lib().dgm_mlp_set_gemm(-1) if mlp_impl == "hip" else -1  # (-1: query, mode unchanged)
-        f16x3 = gemm_mode in (2, 3)
+        f16x3 = gemm_mode == 3
         mfma_per_product = 3.0  # f16x3 / f16x3p: 3 MFMAs per fp32 product on the f16 pipe
         layer_flops = 2.0 * P * 256 * 256                       # one 256 -> 256 layer over N = P rows
         layer_bytes = 2.0 * P * 256 * 4 + P * 32 + 256 * 256 * 4  # A in + C out (fp32) + ReLU mask bits + the weights once
@@ -522,10 +522,9 @@ def main():
         planes = gemm_mode == 3
         kn = {3: ("mlp_gemm4_kernel<16,1024,512,0> (256->256 layer forward on planes, N rows)",
                   "mlp_gemm4_kernel<16,1024,512,1> (256->256 layer backward-data on planes, N rows)",
-                  "mlp_dw4_kernel<8,8> (256x256 weight gradient over N rows, planes)"),
-              2: ("mlp_gemm3p_kernel<0> (256->256 layer forward, N rows)", "mlp_gemm3p_kernel<1> (256->256 layer backward-data, N rows)",
-                  "mlp_dw3b_kernel (256x256 weight gradient over N rows)")}.get(gemm_mode, ("mlp_gemm6r_kernel<0,16,1,8>", "mlp_gemm6r_kernel<1,16,1,8>", "mlp_dw6b_kernel"))
-        pm = ("r03_pmc_gemm4_fwd.json", "r03_pmc_gemm4_bwd.json", "r03_pmc_dw4.json") if planes else ("pmc_gemm3r_fwd.json", "pmc_gemm3r_bwd.json", "pmc_dw3b.json")
+                  "mlp_dw4_kernel<8,8> (256x256 weight gradient over N rows, planes)")}.get(
+            gemm_mode, ("mlp_gemm_kernel<0> (fp32 MFMA)", "mlp_gemm_kernel<1> (fp32 MFMA)", "mlp_dw_kernel (fp32 MFMA)"))
+        pm = ("r03_pmc_gemm4_fwd.json", "r03_pmc_gemm4_bwd.json", "r03_pmc_dw4.json") if planes else (None, None, None)
         kern = {  # stage -> (kernel name, algorithmic flops, algorithmic bytes, committed PMC file)
             "mlp_layer_fwd": (kn[0], layer_flops, layer_bytes, pm[0]),
             "mlp_layer_bwd": (kn[1], layer_flops, layer_bytes, pm[1]),
@@ -572,9 +571,7 @@ def main():
                          "algorithmic_bytes": by, "algorithmic_flops": fl, "avg_ms": r["avg_ms"], "launches_per_step": r["launches_per_step"],
                          "ms_per_step": r["ms_per_step"], "frac_hbm": r["frac_hbm"], "frac_mfma_pipe": r.get("frac_mfma_pipe"),
                          "arithmetic": ("f16x3p: activations / gradients stored as 2 binary16 planes with one exponent per 32-row tile, "
-                                        "split once by the producer, 3 MFMAs per product" if planes else
-                                        "f16x3: fp32 operands as 2 power-of-two-scaled binary16 planes, 3 MFMAs per product"
-                                        if f16x3 else "native fp32 MFMA")})
+                                        "split once by the producer, 3 MFMAs per product" if planes else "native fp32 MFMA")})
         rb_traffic, rb_src = pmc_traffic("r04_pmc_render_bwd4.json")
         out = {
             "metric": ("train-step iters/sec (800x800, ~100k Gaussians)" if WORKLOAD == "cfg2"

@@ -161,26 +161,29 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
     __syncthreads();
     if (!last) return;
     __threadfence();
-    // exclusive scan of the tile totals: thread i owns tiles [i K, (i + 1) K)
-    const int K = (tiles + 255) / 256;
-    const int t0 = (int)threadIdx.x * K, t1 = min(tiles, t0 + K);
-    unsigned mine = 0;
-    for (int t = t0; t < t1; t++) mine += __builtin_nontemporal_load(tile_count + t);
-    const unsigned inc = wave_inclusive_scan_u32(mine);
-    if (lane == 63) wave_sum[wv] = inc;
-    __syncthreads();
-    unsigned start = inc - mine;
-    for (int w = 0; w < wv; w++) start += wave_sum[w];
-    for (int t = t0; t < t1; t++) {
-        const unsigned c = __builtin_nontemporal_load(tile_count + t);
-        tile_offset[t] = start;
-        ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
-        // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
-        if (c > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
-        else if (c > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
-        start += c;
+    // exclusive scan of the tile totals, 256 tiles a pass: thread i takes tile base + i, so every access is one 1 KiB segment
+    // per wave whatever the tile count (the first version gave each thread a contiguous run of ceil(tiles / 256) tiles: fine at
+    // 2 500 tiles, a serial walk of 127 strided loads and stores per thread at 4K-class images)
+    unsigned run_total = 0;
+    for (int base = 0; base < tiles; base += 256) {
+        const int t = base + (int)threadIdx.x;
+        const unsigned c = t < tiles ? __builtin_nontemporal_load(tile_count + t) : 0u;
+        const unsigned inc = wave_inclusive_scan_u32(c);
+        if (lane == 63) wave_sum[wv] = inc;
+        __syncthreads();
+        unsigned start = run_total + inc - c;
+        for (int w = 0; w < wv; w++) start += wave_sum[w];
+        if (t < tiles) {
+            tile_offset[t] = start;
+            ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
+            // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
+            if (c > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
+            else if (c > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
+        }
+        run_total += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();  // (wave_sum is rewritten by the next pass)
     }
-    if (threadIdx.x == 255) tile_offset[tiles] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    if (threadIdx.x == 0) tile_offset[tiles] = run_total;
 }
 
 __global__ void __launch_bounds__(DGM_BIN_THREADS)

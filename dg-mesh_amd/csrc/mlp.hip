@@ -7,12 +7,13 @@
 //
 // Arithmetics of the 256-wide GEMMs, selected by dgm_mlp_set_gemm() / DGM_MLP_GEMM (the list and the default are further down,
 // at g_gemm_mode):
-//  * f16x3p (mlp_planes.hpp, default) and f16x3 (mlp_f16x3.hpp): power-of-two scaled two-way binary16 split, three partial
-//    products per fp32 product on the f16 matrix cores; the heads of f16x3 use the exact three-way bf16 split of
-//    mlp_bf16x6.hpp (six partial products on v_mfma_f32_32x32x16_bf16);
+//  * f16x3p (mlp_planes.hpp, default): power-of-two scaled two-way binary16 split, three partial products per fp32 product on the
+//    f16 matrix cores, activations and gradients kept in HBM as their two planes;
 //  * f32 (this file): v_mfma_f32_32x32x2_f32; 64 x 128 output tile per 256-thread workgroup, K consumed in 16-deep
 //    register-staged global -> LDS stages (A k-major with row pitch 66 = 2 mod 8: conflict-free transposing stores and
 //    fragment reads), dW as row-chunk x 128-column-slab partial tiles.
+// (Rounds 1-4 also shipped "bf16x6" and "f16x3" -- the same split arithmetic on fp32 rows, re-split by every consumer; round 5
+// retired them: the plane path now takes per-row time inputs and batches of any size itself.)
 // Common to both:
 //  * the skip layer reads its input as TWO K-segments ([emb | h4]) -- the concatenation is never materialised;
 //  * bias + ReLU are the forward epilogue, which also saves the ReLU mask as bits; the backward-data epilogue applies
@@ -25,8 +26,6 @@
 #include <string.h>
 
 #include "dgm_common.hpp"
-#include "mlp_bf16x6.hpp"
-#include "mlp_f16x3.hpp"
 #include "mlp_planes.hpp"
 
 namespace dgm {
@@ -94,69 +93,6 @@ mlp_embed_kernel(int N, const float* __restrict__ x, const float* __restrict__ t
             e[MLP_XE + t] = t < T ? temb[(size_t)r * temb_stride + t] : 0.f;
         }
     }
-}
-
-// Column maxima of |emb| (float bits) -- the scales of the f16x3 weight gradients of the two layers that consume the
-// embedding -- without a pass over it: the sin / cos columns are bounded by 1, the x and time columns are reduced from their
-// sources.  Blocks [0, nbx): x read as a flat array, twelve floats (four rows) per thread in three coalesced 16-byte loads,
-// so a thread's float k is column k % 3; blocks [nbx, ..): the time embedding, thread = one of its T columns, sixteen rows
-// per batch (a broadcast time embedding is a single row).  One atomic per column and workgroup; cmax zeroed by the caller.
-__global__ void __launch_bounds__(256)
-mlp_embed_cmax_kernel(int N, int nbx, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
-                      unsigned* __restrict__ cmax) {
-    __shared__ float smax[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if ((int)blockIdx.x < nbx) {
-        const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 12, tot = (size_t)N * 3;
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-        if (e0 + 12 <= tot && (((uintptr_t)x) & 15) == 0) {
-            const float4* p = reinterpret_cast<const float4*>(x + e0);
-            const float4 a = p[0], b = p[1], c = p[2];  // columns 0 1 2 0 | 1 2 0 1 | 2 0 1 2
-            m0 = fmaxf(fmaxf(fabsf(a.x), fabsf(a.w)), fmaxf(fabsf(b.z), fabsf(c.y)));
-            m1 = fmaxf(fmaxf(fabsf(a.y), fabsf(b.x)), fmaxf(fabsf(b.w), fabsf(c.z)));
-            m2 = fmaxf(fmaxf(fabsf(a.z), fabsf(b.y)), fmaxf(fabsf(c.x), fabsf(c.w)));
-        } else {
-            for (int i = 0; i < 12; i++) {
-                if (e0 + i < tot) {
-                    const float v = fabsf(x[e0 + i]);
-                    if (i % 3 == 0) m0 = fmaxf(m0, v);
-                    else if (i % 3 == 1) m1 = fmaxf(m1, v);
-                    else m2 = fmaxf(m2, v);
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            m0 = fmaxf(m0, __shfl_xor(m0, d, 64)), m1 = fmaxf(m1, __shfl_xor(m1, d, 64)), m2 = fmaxf(m2, __shfl_xor(m2, d, 64));
-        }
-        if (lane == 0) smax[wv][0] = m0, smax[wv][1] = m1, smax[wv][2] = m2;
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            const int j = threadIdx.x;
-            atomicMax(cmax + j, __float_as_uint(fmaxf(fmaxf(smax[0][j], smax[1][j]), fmaxf(smax[2][j], smax[3][j]))));
-        }
-        if (blockIdx.x == 0 && threadIdx.x >= 3 && threadIdx.x < MLP_XE) cmax[threadIdx.x] = __float_as_uint(1.0f);
-        return;
-    }
-    const int nr = temb_stride != 0 ? N : 1;
-    const int tb = (int)blockIdx.x - nbx, ntb = (int)gridDim.x - nbx;
-    float mx = 0.f;
-    if (lane < T) {
-        for (int rb = (tb * 4 + wv) * 16; rb < nr; rb += ntb * 64) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                v[i] = 0.f;
-                if (rb + i < nr) v[i] = temb[(size_t)(rb + i) * temb_stride + lane];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) mx = fmaxf(mx, fabsf(v[i]));
-        }
-    }
-    smax[wv][lane] = mx;
-    __syncthreads();
-    if (wv == 0 && lane < T)
-        atomicMax(cmax + MLP_XE + lane, __float_as_uint(fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]))));
 }
 
 // ---- the 256-wide GEMM: C[M x 256] = [A1 | A2][M x (K1+K2)] * Bt[(K1+K2) x 256] ------------------------------------
@@ -777,14 +713,12 @@ int mlp_fail(const char* msg) {
 struct Ws {
     float *emb, *Y[8], *Wt[8], *Wd[8], *Ga, *Gb, *partial, *partial_db, *partial_h, *partial_hb;
     float *partial_l[8], *partial_db_l[8];  // per layer: the weight-gradient partial tiles wait for the pass's one reduction
-    uint4 *Wt6[8], *Wd6[8], *Wh6f;  // bf16x6 weight planes
-    uint4 *Wt3[8], *Wd3[8];                // f16x3 weight planes
-    float *wsc_f[8], *wsc_d[8], *wsc_e;    // their inverse column scales (wsc_e: the embedding half of the skip layer)
-    unsigned *cmaxY, *cmaxG;               // [8][256] column maxima (float bits) of Y_l / G_l for the dW scales
-    unsigned* cmaxE;                       // [256] column maxima of the embedding (right behind cmaxY: one memset clears both)
     unsigned* mask[8];
-    // plane path (mlp_planes.hpp): tile exponents of the embedding / Y_l / dOut / the two gradient buffers, the lane-native
-    // fp32 half of the skip layer, the dOut planes, per-matrix maxima, the heads' planes and the per-matrix inverse scales
+    // plane path (mlp_planes.hpp): weight planes and their inverse scales (wsc_e: the embedding half of the skip layer), tile
+    // exponents of the embedding / Y_l / dOut / the two gradient buffers, the lane-native fp32 half of the skip layer, the dOut
+    // planes, per-matrix maxima, the heads' planes and inverse scales
+    uint4 *Wt3[8], *Wd3[8];
+    float *wsc_f[8], *wsc_d[8], *wsc_e;
     int *Eexp, *Yexp[8], *Dexp, *Gexp[2];
     float4* Cin;
     unsigned char* Dp;
@@ -805,40 +739,17 @@ int num_cus() {
     }
     return cache[slot];
 }
-// f16x3 dW decomposition (mlp_dw3b / dw3e kernels): one 8-wave workgroup per chunk of rows covers all columns, one chunk per CU
-struct DwPlan {
-    int rows, chunks, slabs;
-};
-DwPlan dw6_plan(int N, int /*Kp*/, bool /*x3*/) {
-    DwPlan d;
-    d.slabs = 1;
-    const int target = num_cus();
-    int rows = (N + target - 1) / target;
-    rows = (rows + 15) & ~15;
-    if (rows < 16) rows = 16;
-    d.rows = rows;
-    d.chunks = (N + rows - 1) / rows;
-    return d;
-}
-// 2: f16x3 (default; mlp_f16x3.hpp): power-of-two scaled operands split into 2 binary16, 3 partial products on the f16
-//    matrix cores for the 256-wide layers (layer 0 .. 4, 6, 7 forward, all backward-data, their weight gradients); the
-//    skip layer, the heads and the K = 96 / 352 weight gradients run the bf16x6 kernels
-// 0: (retired in round 4) bf16x6 for every GEMM -- fp32 operands split exactly into 3 bf16, 6 partial products; the 32-column
-//    GEMM of that arithmetic is still the heads' forward pass of mode 2
-// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3p|f16x3|f32.
-// 3: f16x3p (default; mlp_planes.hpp): the f16x3 arithmetic on plane-format activations -- split once by the producer,
-//    one exponent per 32-row tile; needs a broadcast time embedding (temb_stride == 0), else the call runs mode 2.
+// 3: f16x3p (default; mlp_planes.hpp): power-of-two scaled operands split into 2 binary16, 3 partial products on the f16 matrix
+//    cores, on plane-format activations -- split once by the producer, one exponent per 32-row tile.
+// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3p|f32.
+// (0 = "bf16x6 for every GEMM" was retired in round 4, 2 = "f16x3" on fp32 rows in round 5: both are ignored by dgm_mlp_set_gemm.)
 int g_gemm_mode = [] {
     const char* e = getenv("DGM_MLP_GEMM");
     if (e == nullptr) return 3;
     if (strcmp(e, "f32") == 0) return 1;
-    if (strcmp(e, "f16x3") == 0) return 2;
-    if (strcmp(e, "f16x3p") != 0) fprintf(stderr, "libdgmesh_hip: unknown DGM_MLP_GEMM=\"%s\" (f16x3p | f16x3 | f32): using f16x3p\n", e);
+    if (strcmp(e, "f16x3p") != 0) fprintf(stderr, "libdgmesh_hip: unknown DGM_MLP_GEMM=\"%s\" (f16x3p | f32): using f16x3p\n", e);
     return 3;
 }();
-// (the plane kernels keep a workgroup's tile exponents in a 512-entry LDS table: beyond 512 tiles per workgroup -- N > 4 M
-// rows on 256 CUs -- the call runs mode 2 as well)
-int effective_mode(int temb_stride, int N);
 // arithmetic the last forward pass on a workspace ran in: the backward pass must match (its scales and masks were produced by
 // that forward pass).  A small host-side table keyed by the workspace pointer; an unknown workspace is not checked.
 struct WsMode {
@@ -860,21 +771,6 @@ int recall_ws_mode(const void* ws) {
         if (e.ws == ws) return e.mode;
     return -1;
 }
-#define G3R_LDS(K_) (2 * 32 * (4 * (K_) + 16) + 256 + 2 * 8 * 32 * 4)  // A planes (double buffered) + row scales + mask words
-#define DW3E_LDS(MT_) (2 * (4 * (MT_) * 32 + DW3_U) * 16)  // X and G stages, two planes each, double buffered
-hipError_t gemm3r_attr() {  // dynamic LDS above 48 KB needs the attribute once per device
-    static bool done[DGM_MAX_DEVICES] = {false};
-    bool& d = done[current_device_slot()];
-    if (d) return hipSuccess;
-    hipError_t e = hipSuccess;
-    const void* fns[4] = {(const void*)mlp_gemm3p_kernel<0, false>, (const void*)mlp_gemm3p_kernel<2, false>,
-                          (const void*)mlp_gemm3p_kernel<1, false>, (const void*)mlp_gemm3p_kernel<1, true>};
-    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, G3R_LDS(256));
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)mlp_dw3e_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, DW3E_LDS(11));
-    if (e == hipSuccess) d = true;
-    return e;
-}
 // plane path: a weight-gradient chunk is a run of whole 32-row tiles, one chunk per CU (or fewer)
 struct P4Plan {
     int ntiles, tiles_per_chunk, chunks;
@@ -887,11 +783,6 @@ P4Plan p4_plan(int N) {
     d.chunks = (d.ntiles + d.tiles_per_chunk - 1) / d.tiles_per_chunk;
     return d;
 }
-int effective_mode(int temb_stride, int N) {
-    if (g_gemm_mode != 3) return g_gemm_mode;
-    if (temb_stride != 0 || (long long)(N + 31) / 32 > 512LL * num_cus()) return 2;
-    return 3;
-}
 Ws carve(char* base, int N) {
     Ws w;
     char* p = align_ptr(base);
@@ -902,7 +793,8 @@ Ws carve(char* base, int N) {
     };
     const size_t n = ((size_t)N + 31) / 32 * 32;  // every per-row tensor is padded to whole 32-row tiles (plane path)
     const size_t ntiles = n / 32;
-    const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
+    const size_t chunks = ((size_t)N + DW_ROWS - 1) / DW_ROWS;   // fp32-MFMA path: 512-row chunks
+    const P4Plan pp = p4_plan(N > 0 ? N : 1);                     // plane path: chunks of whole tiles, at most one per CU
     w.emb = take(n * MLP_EMB * 4);
     for (int l = 0; l < 8; l++) w.Y[l] = take(n * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.mask[l] = (unsigned*)take(n * 8 * 4);
@@ -910,49 +802,25 @@ Ws carve(char* base, int N) {
     for (int l = 0; l < 8; l++) w.Wd[l] = take((size_t)MLP_W * MLP_W * 4);
     w.Ga = take(n * MLP_W * 4);
     w.Gb = take(n * MLP_W * 4);
-    size_t pfl = (size_t)chunks * (MLP_EMB + MLP_W), pdb = (size_t)chunks;
-    for (int Kp : {MLP_EMB, MLP_W, MLP_EMB + MLP_W}) {
-        for (int x3 = 0; x3 < 2; x3++) {  // the workspace does not depend on the arithmetic selected later
-            const DwPlan d = dw6_plan(N > 0 ? N : 1, Kp, x3 != 0);
-            if ((size_t)d.chunks * Kp > pfl) pfl = (size_t)d.chunks * Kp;
-            if ((size_t)d.chunks * 2 > pdb) pdb = (size_t)d.chunks * 2;
-        }
-    }
     for (int l = 0; l < 8; l++) {  // (geometry is fixed: layer 0 consumes the embedding, layer 5 embedding | trunk)
         const int Kp = l == 0 ? MLP_EMB : (l == 5 ? MLP_EMB + MLP_W : MLP_W);
-        size_t rows = 0, dbr = 0;
-        for (int x3 = 0; x3 < 2; x3++) {
-            const DwPlan d = dw6_plan(N > 0 ? N : 1, Kp, x3 != 0);
-            if ((size_t)d.chunks * Kp > rows) rows = (size_t)d.chunks * Kp;
-            if ((size_t)d.chunks * 8 > dbr) dbr = (size_t)d.chunks * 8;  // (plane path: 8 bias-gradient rows per chunk)
+        size_t rows = (size_t)pp.chunks * Kp, dbr = (size_t)pp.chunks * 8;  // (plane path: 8 bias-gradient rows per chunk)
+        if (l == 5) {  // the fp32-MFMA path reduces layer by layer through this one: room for its widest layer
+            if (chunks * (MLP_EMB + MLP_W) > rows) rows = chunks * (MLP_EMB + MLP_W);
+            if (chunks > dbr) dbr = chunks;
         }
-        {   // plane path: chunks of whole tiles, at most one per CU
-            const P4Plan pp = p4_plan(N > 0 ? N : 1);
-            if ((size_t)pp.chunks * Kp > rows) rows = (size_t)pp.chunks * Kp;
-            if ((size_t)pp.chunks * 8 > dbr) dbr = (size_t)pp.chunks * 8;
-        }
-        if (l == 5 && pfl > rows) rows = pfl;  // the fp32-MFMA path reduces layer by layer through this one
-        if (l == 5 && pdb > dbr) dbr = pdb;
         w.partial_l[l] = take(rows * MLP_W * 4);
         w.partial_db_l[l] = take(dbr * MLP_W * 4);
     }
     w.partial = w.partial_l[5];
     w.partial_db = w.partial_db_l[5];
-    for (int l = 0; l < 8; l++) w.Wt6[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 6);
-    for (int l = 0; l < 8; l++) w.Wd6[l] = (uint4*)take((size_t)MLP_W * MLP_W * 6);
-    w.Wh6f = (uint4*)take((size_t)MLP_W * 32 * 6);
     for (int l = 0; l < 8; l++) w.Wt3[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.Wd3[l] = (uint4*)take((size_t)MLP_W * MLP_W * 4);
-    for (int l = 0; l < 8; l++) w.wsc_f[l] = take(MLP_W * 4);
-    for (int l = 0; l < 8; l++) w.wsc_d[l] = take(MLP_W * 4);
-    w.wsc_e = take(MLP_W * 4);
-    // one block, cleared by the weight-preparation launch at the start of the forward pass (the backward pass of a network
-    // always follows its own forward pass on the same workspace): cmaxY [8] | cmaxE [1] | cmaxG [8], 256 words each
-    w.cmaxY = (unsigned*)take((9 + 8) * MLP_W * 4);
-    w.cmaxE = w.cmaxY + 8 * MLP_W;
-    w.cmaxG = w.cmaxY + 9 * MLP_W;
-    size_t hchunks = (N + HD_ROWS - 1) / HD_ROWS;
-    if ((size_t)p4_plan(N > 0 ? N : 1).chunks > hchunks) hchunks = p4_plan(N > 0 ? N : 1).chunks;
+    for (int l = 0; l < 8; l++) w.wsc_f[l] = take(256);
+    for (int l = 0; l < 8; l++) w.wsc_d[l] = take(256);
+    w.wsc_e = take(256);
+    size_t hchunks = ((size_t)N + HD_ROWS - 1) / HD_ROWS;
+    if ((size_t)pp.chunks > hchunks) hchunks = pp.chunks;
     w.partial_h = take(hchunks * 16 * MLP_W * 4);
     w.partial_hb = take((hchunks > ntiles ? hchunks : ntiles) * 16 * 4);
     w.Eexp = (int*)take(ntiles * 4);
@@ -1021,6 +889,17 @@ typedef Dw4Cfg<8, 1, 1024, 512, 128, 64> CfgDwH;
 #define P4_PAIR_SHARE_DEN 256
 #endif
 
+// Tiles per workgroup whose exponents the layer GEMM keeps in its LDS table (512: N <= 4 M rows on 256 CUs; the rest are read from
+// HBM as they come).  DGM_P4_EXPS_LIMIT=<n> lowers it so that a test reaches the second path at an ordinary batch size.
+int p4_exps_limit() {
+    static int v = [] {
+        const char* e = getenv("DGM_P4_EXPS_LIMIT");
+        const int n = e ? atoi(e) : 512;
+        return n < 1 ? 1 : (n > 512 ? 512 : n);
+    }();
+    return v;
+}
+
 // workgroups of a backward launch that run the weight gradient (mlp_bwd_pair_kernel); 0 = two separate launches.
 // DGM_MLP_PAIR=<n> overrides (0 disables); default: a fixed share of the CUs, chosen by measurement at N = 100 k.
 int p4_pair_split(int ntiles, int gx) {
@@ -1034,7 +913,8 @@ int p4_pair_split(int ntiles, int gx) {
     return n;
 }
 
-int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* temb, const Ws& w, float* out, hipStream_t st) {
+int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* temb, int temb_stride, const Ws& w, float* out,
+                   hipStream_t st) {
     const P4Plan pl = p4_plan(N);
     const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
     const int sk = p->skip_layer;
@@ -1043,7 +923,7 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     am.n_jobs = 9;
     for (int l = 0; l < 8; l++) am.job[l].W = p->W[l], am.job[l].n = MLP_W * layer_in(p, l);
     am.job[8].W = p->Wh, am.job[8].n = p->n_out * MLP_W;
-    hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, 0, p->t_dim,
+    hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, temb_stride, p->t_dim,
                        (unsigned char*)w.emb, w.Eexp, am, w.matmax);
     // every weight matrix as two binary16 planes, one power-of-two scale per matrix
     Prep4Batch pb;
@@ -1068,7 +948,7 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
 
     Gemm4Args a;
     memset(&a, 0, sizeof(a));
-    a.ntiles = nt, a.M = N;
+    a.ntiles = nt, a.M = N, a.exps_limit = p4_exps_limit();
     // layer 0 (K = 96) with the embedding half of the skip layer as second output
     a.A = (const unsigned char*)w.emb, a.Aexp = w.Eexp, a.Bp = w.Wt3[0], a.b_inv = w.wsc_f[0], a.bias = p->b[0];
     a.mask_out = w.mask[0], a.C = (unsigned char*)w.Y[0], a.Cexp = w.Yexp[0];
@@ -1098,8 +978,8 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     return 0;
 }
 
-int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws& w, float* const* dW, float* const* db, float* dWh,
-                    float* dbh, float* dtemb, hipStream_t st, const float* x_in = nullptr, float* dX = nullptr) {
+int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, const Ws& w, float* const* dW, float* const* db,
+                    float* dWh, float* dbh, float* dtemb, hipStream_t st, const float* x_in = nullptr, float* dX = nullptr) {
     const P4Plan pl = p4_plan(N);
     const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
     const int sk = p->skip_layer;
@@ -1110,7 +990,7 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     int *Ge = w.Gexp[0], *Gne = w.Gexp[1];
     Gemm4Args a;
     memset(&a, 0, sizeof(a));
-    a.ntiles = nt, a.M = N;
+    a.ntiles = nt, a.M = N, a.exps_limit = p4_exps_limit();
     // G_7 = (dOut Wh) masked by layer 7's ReLU
     a.A = w.Dp, a.Aexp = w.Dexp, a.Bp = w.Wh4b, a.b_inv = w.wsc_hb, a.mask_in = w.mask[7], a.C = G, a.Cexp = Ge;
     {   // one K step per tile: nothing to hide the epilogue's barriers under, so two workgroups per CU (104 VGPRs, 54 KB of LDS)
@@ -1141,6 +1021,8 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     // skip layer's gradient stay a launch of their own over all CUs (own partial tiles, own reduction job).
     int n_dw = p4_pair_split(nt, gx);
     if (n_dw > pl.chunks) n_dw = pl.chunks;  // (the skip layer's partial buffer is carved for pl.chunks tiles of 352 rows)
+    const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
+    if (per_row_t && dX) return mlp_fail("mlp_backward: position gradients need a broadcast time row");
     for (int l = 7; l >= 0; l--) {
         const int Kp = layer_kp(p, l);
         const bool paired = n_dw > 0 && l >= 1;
@@ -1154,7 +1036,11 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
         d.G = G, d.Gexp = Ge;
         if (dX && (l == sk || l == 0))  // gradient w.r.t. the positions: G_5 W_5[:, :63] into scratch (the forward's Cin, idle now), then + G_0 W_0[:, :63] and PE'
             hipLaunchKernelGGL(mlp_dx4_kernel, dim3(nt), dim3(256), 0, st, N, (const unsigned char*)G, (const int*)Ge, p->W[l],
-                               layer_in(p, l), reinterpret_cast<float*>(w.Cin), l == 0 ? 1 : 0, x_in, dX);
+                               layer_in(p, l), 0, MLP_XE, reinterpret_cast<float*>(w.Cin), l == 0 ? 1 : 0, x_in, dX, 0);
+        if (per_row_t && (l == sk || l == 0))  // a time input per row: dL/dt_emb[r] = G_5[r] W_5[:, 63:63+T] + G_0[r] W_0[:, 63:63+T]
+            hipLaunchKernelGGL(mlp_dx4_kernel, dim3(nt), dim3(256), 0, st, N, (const unsigned char*)G, (const int*)Ge, p->W[l],
+                               layer_in(p, l), MLP_XE, p->t_dim, reinterpret_cast<float*>(w.Cin), l == 0 ? 2 : 0, (const float*)nullptr,
+                               dtemb, p->t_dim);
         // partial tiles of the layer: [chunk][Kp][256]; paired skip layer: trunk rows [n_dw][256][256], then embedding rows [chunks][96][256]
         float* part_emb = w.partial_l[l];
         float* part_trunk = w.partial_l[l] + (l == sk ? (size_t)MLP_EMB * MLP_W : 0);
@@ -1216,7 +1102,7 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, const Ws&
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
     rb.h_dW = dWh, rb.h_db = dbh;
     hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, rb.n_jobs + 1), dim3(256), 0, st, rb);
-    if (dtemb != nullptr)
+    if (dtemb != nullptr && !per_row_t)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
                            db[sk], p->W[sk], layer_in(p, sk), dtemb);
     hipError_t e = hipGetLastError();
@@ -1229,7 +1115,7 @@ extern "C" {
 
 int dgm_mlp_set_gemm(int mode) {
     const int prev = g_gemm_mode;
-    if (mode >= 1 && mode <= 3) g_gemm_mode = mode;  // (0 was "bf16x6 for every GEMM", retired in round 4: ignored)
+    if (mode == 1 || mode == 3) g_gemm_mode = mode;  // (0, "bf16x6 for every GEMM", and 2, "f16x3" on fp32 rows, are retired: ignored)
     return prev;
 }
 
@@ -1289,6 +1175,7 @@ int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
     (void)hipMemcpyAsync(binv, &one, 4, hipMemcpyHostToDevice, st);
     Gemm4Args a;
     memset(&a, 0, sizeof(a));
+    a.exps_limit = 512;
     a.ntiles = nt, a.M = N, a.A = kind == 0 ? A : G, a.Aexp = ex, a.Bp = Bp, a.b_inv = binv, a.bias = bias, a.mask_in = mask,
     a.mask_out = mask + (size_t)0, a.C = C, a.Cexp = ex + nt;
     Dw4Args d;
@@ -1348,61 +1235,18 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     if (!x || !temb || !workspace || !out) return mlp_fail("mlp_forward: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
-    const int mode = effective_mode(temb_stride, N);
+    const int mode = g_gemm_mode;
     remember_ws_mode(workspace, mode);
-    if (mode == 3) return forward_planes(p, N, x, temb, w, out, st);
-    const bool f32 = mode == 1;
-    if (f32) {
-        for (int l = 0; l < 8; l++) {
-            const int Kp = layer_kp(p, l);
-            const int n = (Kp > MLP_W ? Kp : MLP_W) * MLP_W;
-            hipLaunchKernelGGL(mlp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, layer_in(p, l), Kp, p->emb_dim,
-                               l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
-        }
-    } else {  // all weight re-layouts of the network in one launch per arithmetic
-        Prep6Batch pb;
-        int nj = 0, max_threads = 0;
-        auto add = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp,
-                       uint4* Bp) {
-            Prep6Job& j = pb.job[nj++];
-            j.mode = mode, j.Kp = Kp, j.ncols = ncols, j.in_features = in_features, j.emb_dim = p->emb_dim, j.hoff = hoff;
-            j.k_valid = k_valid, j.col_valid = col_valid, j.W = Wp, j.Bp = Bp;
-            if (Kp / 8 * ncols > max_threads) max_threads = Kp / 8 * ncols;
-        };
-        Prep3Batch p3;
-        int n3 = 0;
-        auto add3 = [&](int mode, int Kp, int in_features, int hoff, const float* Wp, uint4* Bp, float* inv_scale) {
-            Prep3Job& j = p3.job[n3++];
-            j.mode = mode, j.Kp = Kp, j.ncols = MLP_W, j.in_features = in_features, j.emb_dim = p->emb_dim, j.hoff = hoff;
-            j.k_valid = MLP_W, j.col_valid = MLP_W, j.W = Wp, j.Bp = Bp, j.inv_scale = inv_scale;
-        };
-        for (int l = 0; l < 8; l++) {
-            // the K = 352 planes of the skip layer do not fit the register file: its embedding half (K = 96, planes at the
-            // front of Wt3[l]) rides along with layer 0, its trunk half (K = 256, behind them) adds that result in its epilogue
-            if (l == p->skip_layer) {
-                add3(0, MLP_EMB, layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_e);
-                add3(0, MLP_W, layer_in(p, l), p->emb_dim, p->W[l], w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l]);
-            } else add3(0, layer_kp(p, l), layer_in(p, l), 0, p->W[l], w.Wt3[l], w.wsc_f[l]);
-            if (l >= 1) add3(1, MLP_W, layer_in(p, l), l == p->skip_layer ? p->emb_dim : 0, p->W[l], w.Wd3[l], w.wsc_d[l]);
-        }
-        add(0, MLP_W, 32, MLP_W, 0, 0, p->n_out, p->Wh, w.Wh6f);
-        // one launch: every trunk matrix's column maxima + planes, the heads' planes (the one bf16x6 job of this mode), and the
-        // clearing of cmaxY | cmaxE | cmaxG -- one block of running column maxima for this forward AND its backward pass (a
-        // repeated backward pass finds maxima that are at least as large: still valid scales)
-        (void)max_threads;
-        hipLaunchKernelGGL(mlp_prep3_all_kernel, dim3(8, n3 + 1), dim3(256), 0, st, p3, n3, pb.job[nj - 1], w.cmaxY, (9 + 8) * MLP_W);
-        if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_forward: cannot raise the LDS limit of mlp_gemm3r_kernel");
+    if (mode == 3) return forward_planes(p, N, x, temb, temb_stride, w, out, st);
+    // ---- native fp32 MFMA
+    for (int l = 0; l < 8; l++) {
+        const int Kp = layer_kp(p, l);
+        const int n = (Kp > MLP_W ? Kp : MLP_W) * MLP_W;
+        hipLaunchKernelGGL(mlp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, layer_in(p, l), Kp, p->emb_dim,
+                           l == p->skip_layer ? 1 : 0, p->W[l], w.Wt[l], l >= 1 ? w.Wd[l] : nullptr);
     }
-    {
-        hipLaunchKernelGGL(mlp_embed_kernel, dim3((N + 7) / 8), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.emb);
-        if (!f32) {
-            const int nbx = (int)(((size_t)N * 3 + 3071) / 3072), nbt = temb_stride != 0 ? 256 : 1;
-            hipLaunchKernelGGL(mlp_embed_cmax_kernel, dim3(nbx + nbt), dim3(256), 0, st, N, nbx, x, temb, temb_stride, p->t_dim,
-                               w.cmaxE);
-        }
-    }
+    hipLaunchKernelGGL(mlp_embed_kernel, dim3((N + 7) / 8), dim3(256), 0, st, N, x, temb, temb_stride, p->t_dim, w.emb);
     const int grid = (N + GM - 1) / GM;
-    const int grid6 = (N + 127) / 128;
     for (int l = 0; l < 8; l++) {
         const float *A1, *A2 = nullptr;
         int lda1, K1, lda2 = 0, K2 = 0;
@@ -1413,36 +1257,11 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
         } else {
             A1 = w.Y[l - 1], lda1 = MLP_W, K1 = MLP_W;
         }
-        if (!f32) {
-            const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
-            if (K1 + K2 == MLP_EMB + MLP_W) {
-                // skip layer, trunk half: Y5 = relu(Y4 * W5[:, emb:]^T + C_in), C_in = emb * W5[:, :emb]^T + b5 already in Y5
-                // (not under the mlp_layer_fwd stage timer: it also reads C_in, 1.5x the bytes of a plain 256 -> 256 layer)
-                hipLaunchKernelGGL((mlp_gemm3p_kernel<2, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A2, lda2,
-                                   w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l], (const float*)nullptr, w.mask[l], w.Y[l],
-                                   w.cmaxY + l * MLP_W, (unsigned*)nullptr);
-            } else if (K1 + K2 == MLP_W) {
-                dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                hipLaunchKernelGGL((mlp_gemm3p_kernel<0, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, A1, lda1,
-                                   w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W, (unsigned*)nullptr);
-                dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
-            } else {  // layer 0, with the embedding half of the skip layer as second output (into Y[skip], linear + bias)
-                const int sk = p->skip_layer;
-                hipLaunchKernelGGL((mlp_gemm3r_kernel<0, 6, 1, true>), dim3(gx), dim3(512), G3R_LDS(96), st, N, nt32, A1, lda1, K1,
-                                   A2, lda2, w.Wt3[l], w.wsc_f[l], p->b[l], w.mask[l], w.Y[l], w.cmaxY + l * MLP_W,
-                                   (const uint4*)w.Wt3[sk], (const float*)w.wsc_e, p->b[sk], w.Y[sk]);
-            }
-            continue;
-        }
         hipLaunchKernelGGL(mlp_gemm_kernel<0>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, A1, lda1, K1, A2, lda2, K2, w.Wt[l],
                            p->b[l], w.mask[l], w.Y[l]);
     }
-    if (f32)
-        hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, p->n_out, w.Y[7], p->Wh, 1,
-                           MLP_W, p->bh, out, p->n_out, 0);
-    else  // heads: out = Y7 * Wh^T + bh as a 32-column GEMM (HBM-bound: one pass over Y7)
-        hipLaunchKernelGGL((mlp_gemm6_kernel<2, 4, 1, 1, 1, false>), dim3(grid6), dim3(256), 0, st, N, w.Y[7], MLP_W, MLP_W,
-                           (const float*)nullptr, 0, 0, 0, w.Wh6f, p->bh, (unsigned*)nullptr, out, p->n_out, p->n_out);
+    hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, p->n_out, w.Y[7], p->Wh, 1,
+                       MLP_W, p->bh, out, p->n_out, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
     return 0;
@@ -1459,8 +1278,8 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
     if (N <= 0) return 0;
     if (!dOut || !workspace || !dW || !db || !dWh || !dbh) return mlp_fail("mlp_backward: NULL pointer");
     if ((x == nullptr) != (dX == nullptr)) return mlp_fail("mlp_backward: x and dX come together");
-    const int mode = effective_mode(temb_stride, N);
-    if (dX && mode != 3)
+    const int mode = g_gemm_mode;
+    if (dX && (mode != 3 || temb_stride != 0))
         return mlp_fail("mlp_backward: the gradient w.r.t. the positions exists in the plane arithmetic only (f16x3p, broadcast time row)");
     {
         const int fm = recall_ws_mode(workspace);
@@ -1469,28 +1288,19 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
     }
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
-    if (mode == 3) return backward_planes(p, N, dOut, w, dW, db, dWh, dbh, dtemb, st, x, dX);
+    if (mode == 3) return backward_planes(p, N, dOut, temb_stride, w, dW, db, dWh, dbh, dtemb, st, x, dX);
+    // ---- native fp32 MFMA
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
     const int grid = (N + GM - 1) / GM;
-    const bool f32 = mode == 1;
     // heads: G7 (masked by layer 7's ReLU, read off Y7 itself) and the partial sums of dWh / dbh in one pass over Y7
     const int hchunks = (N + HD_ROWS - 1) / HD_ROWS;
     hipLaunchKernelGGL(mlp_heads_bwd_kernel, dim3(hchunks), dim3(256), 0, st, N, p->n_out, dOut, p->Wh, w.Y[7], w.Ga,
                        w.partial_h, w.partial_hb);
-    const bool x3 = !f32;  // (mode 2; mode 0 -- bf16x6 for every GEMM -- was retired in round 4)
-    if (x3) {  // (the column maxima of the G_l for the weight gradients' scales, accumulated by the backward-data GEMMs, were
-               // cleared by the forward pass)
-        if (gemm3r_attr() != hipSuccess) return mlp_fail("mlp_backward: cannot raise the LDS limit of mlp_gemm3r_kernel");
-    }
-    if (f32)  // (the matrix-core paths fold this into their one reduction launch at the end of the pass)
-        hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3(8, p->n_out), dim3(256), 0, st, hchunks, p->n_out, w.partial_h,
-                           w.partial_hb, dWh, dbh);
+    hipLaunchKernelGGL(mlp_reduce_heads_kernel, dim3(8, p->n_out), dim3(256), 0, st, hchunks, p->n_out, w.partial_h,
+                       w.partial_hb, dWh, dbh);
     float* G = w.Ga;
     float* Gn = w.Gb;
     const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
-    ReduceDwBatch rb;
-    rb.emb_dim = p->emb_dim, rb.n_jobs = 8;
-    int rb_blocks = 0;
     for (int l = 7; l >= 0; l--) {
         const float *X1, *X2 = nullptr;
         int ldx1, K1, ldx2 = 0, K2 = 0;
@@ -1501,57 +1311,16 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
         } else {
             X1 = w.Y[l - 1], ldx1 = MLP_W, K1 = MLP_W;
         }
-        // backward data first: G_{l-1} = (G_l W_l) masked, into the other buffer -- it also delivers the column maxima the
-        // weight gradient below needs (of G_7 through CMAX_IN, of the later G_l through the previous launch's epilogue)
-        if (l >= 1) {
-            if (f32)
-                hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W,
-                                   (const float*)nullptr, 0, 0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
-            else {
-                const int nt32 = (N + 31) / 32, gx = nt32 < num_cus() ? nt32 : num_cus();
-                dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
-                if (x3 && l == 7)  // G_7 comes from the heads kernel without column maxima: accumulated while it is read here
-                    hipLaunchKernelGGL((mlp_gemm3p_kernel<1, true>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
-                                       w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
-                                       w.cmaxG + (l - 1) * MLP_W, w.cmaxG + l * MLP_W);
-                else
-                    hipLaunchKernelGGL((mlp_gemm3p_kernel<1, false>), dim3(gx), dim3(512), G3R_LDS(256), st, N, nt32, G, MLP_W,
-                                       w.Wd3[l], w.wsc_d[l], (const float*)nullptr, w.mask[l - 1], Gn,
-                                       w.cmaxG + (l - 1) * MLP_W, (unsigned*)nullptr);
-                dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
-            }
-        }
+        // backward data first: G_{l-1} = (G_l W_l) masked, into the other buffer
+        if (l >= 1)
+            hipLaunchKernelGGL(mlp_gemm_kernel<1>, dim3(grid, MLP_W / GN), dim3(256), 0, st, N, G, MLP_W, MLP_W,
+                               (const float*)nullptr, 0, 0, w.Wd[l], (const float*)nullptr, w.mask[l - 1], Gn);
         const int Kp = K1 + K2;
-        if (f32) {
-            const int slabs = (Kp + DW_SLAB - 1) / DW_SLAB;
-            hipLaunchKernelGGL(mlp_dw_kernel, dim3(slabs, chunks), dim3(512), 0, st, N, X1, ldx1, K1, X2, ldx2, K2, G, w.partial,
-                               w.partial_db);
-            hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, chunks, chunks, Kp,
-                               layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
-        } else {
-            const DwPlan d = dw6_plan(N, Kp, x3);
-            int db_rows = 2 * d.chunks;  // bias-gradient partial rows the kernel leaves
-            if (Kp == MLP_W) {
-                dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
-                hipLaunchKernelGGL(mlp_dw3b_kernel, dim3(d.chunks), dim3(512), 0, st, N, d.rows, X1, ldx1, G,
-                                   w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial_l[l], w.partial_db_l[l]);
-                dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
-            } else {  // the layers that consume the embedding: K = 96 (layer 0) / 352 (skip layer), f16x3
-                db_rows = d.chunks;
-                if (Kp == MLP_EMB)
-                    hipLaunchKernelGGL(mlp_dw3e_kernel<3>, dim3(d.chunks), dim3(512), DW3E_LDS(3), st, N, d.rows, X1, ldx1, K1, X2,
-                                       ldx2, G, w.cmaxE, (const unsigned*)nullptr, w.cmaxG + l * MLP_W, w.partial_l[l], w.partial_db_l[l]);
-                else
-                    hipLaunchKernelGGL(mlp_dw3e_kernel<11>, dim3(d.chunks), dim3(512), DW3E_LDS(11), st, N, d.rows, X1, ldx1, K1,
-                                       X2, ldx2, G, w.cmaxE, w.cmaxY + (l - 1) * MLP_W, w.cmaxG + l * MLP_W, w.partial_l[l],
-                                       w.partial_db_l[l]);
-            }
-            ReduceDwJob& jb = rb.job[l];
-            jb.dst_off = 0;
-            jb.chunks = d.chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = layer_in(p, l), jb.nblocks = reduce_dw_blocks(Kp);
-            jb.partial = w.partial_l[l], jb.partial_db = w.partial_db_l[l], jb.dW = dW[l], jb.db = db[l];
-            if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;
-        }
+        const int slabs = (Kp + DW_SLAB - 1) / DW_SLAB;
+        hipLaunchKernelGGL(mlp_dw_kernel, dim3(slabs, chunks), dim3(512), 0, st, N, X1, ldx1, K1, X2, ldx2, K2, G, w.partial,
+                           w.partial_db);
+        hipLaunchKernelGGL(mlp_reduce_dw_kernel, dim3((Kp * MLP_W + 255) / 256), dim3(256), 0, st, chunks, chunks, Kp,
+                           layer_in(p, l), p->emb_dim, w.partial, w.partial_db, dW[l], db[l]);
         if (per_row_t && (l == p->skip_layer || l == 0))  // dL/dt_emb[r] += G_l[r] . W_l[:, 63:63+T]
             for (int c0 = 0; c0 < p->t_dim; c0 += 16)     // the small kernel handles 16 output columns per pass
                 hipLaunchKernelGGL(mlp_rows_small_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N,
@@ -1562,11 +1331,6 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
             G = Gn;
             Gn = t;
         }
-    }
-    if (!f32) {  // the weight gradients of all eight layers and of the heads: one reduction of their partial tiles
-        rb.h_chunks = hchunks, rb.h_bchunks = hchunks, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
-        rb.h_dW = dWh, rb.h_db = dbh;
-        hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, 9), dim3(256), 0, st, rb);
     }
     if (!per_row_t && dtemb != nullptr)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),

@@ -19,9 +19,83 @@
 #include <type_traits>
 
 #include "dgm_common.hpp"
-#include "mlp_f16x3.hpp"
 
 namespace dgm {
+
+// ---- the split itself (rounds 2-4 kept these in mlp_f16x3.hpp, the row-format predecessor of this file, retired in round 5):
+// every fp32 operand is scaled by a power of two (exact) and split into two binary16 numbers
+//     s x = h + l + e        h = rne16(s x),  l = rne16(s x - h),  |e| <= 2^-23 |s x|   (or 2^-25 absolute when l is subnormal)
+// and a product is evaluated as the three partial products  ah*bh + ah*bl + al*bh  on v_mfma_f32_32x32x16_f16 (each product of two
+// binary16 numbers is exact in fp32, accumulation in fp32).  What is dropped (al*bl) is below 2^-22 |a b|; measured against
+// fp64 the split error is 4e-8 of sum |a||b| -- an order below the rounding error of an fp32 GEMM itself
+// (tests/test_mlp.py::test_split_arithmetics_are_fp32_gemms).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef DGM_F32X16_DEFINED
+#define DGM_F32X16_DEFINED
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
+
+__device__ __forceinline__ f16x8 as_f16x8(const uint4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// two already-scaled floats -> (h, l) dwords, first element in the low half (v_cvt_pk_f16_f32: round to nearest even)
+__device__ __forceinline__ void split2h(float a0, float a1, unsigned& h, unsigned& l) {
+    const f16x2 hh = __builtin_convertvector((f32x2){a0, a1}, f16x2);
+    const float r0 = a0 - (float)hh.x, r1 = a1 - (float)hh.y;
+    const f16x2 ll = __builtin_convertvector((f32x2){r0, r1}, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// scale = 2^(14 - floor(log2 max)) from the bits of a non-negative float maximum; the exponent is clamped so that both
+// the scale and its inverse are normal numbers (an all-zero row / column gets a harmless finite scale)
+__device__ __forceinline__ void scale_from_max_bits(unsigned bits, float& scale, float& inv) {
+    int e = (int)((bits >> 23) & 0xffu);
+    e = e < 20 ? 20 : (e > 250 ? 250 : e);
+    scale = __uint_as_float((unsigned)(268 - e) << 23);  // 2^(127 + 14 - e - 127 + 127 ...): exponent field 268 - e
+    inv = __uint_as_float((unsigned)(e - 14) << 23);     // its reciprocal
+}
+
+// wave-wide maximum of a non-negative float; the result is valid in lane 63 (DPP row_shr 1,2,4,8 + row_bcast 15,31)
+__device__ __forceinline__ float wave_max_nonneg_lane63(float v) {
+#define DGM_MAXDPP(ctrl_, rmask_)                                                                                      \
+    v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl_, rmask_, 0xf, false)))
+    DGM_MAXDPP(0x111, 0xf);
+    DGM_MAXDPP(0x112, 0xf);
+    DGM_MAXDPP(0x114, 0xf);
+    DGM_MAXDPP(0x118, 0xf);
+    DGM_MAXDPP(0x142, 0xa);
+    DGM_MAXDPP(0x143, 0xc);
+#undef DGM_MAXDPP
+    return v;
+}
+
+// ---- weight planes ------------------------------------------------------------------------------------------------
+// Bp[((stage*2 + plane)*2 + g)*ncols + col] holds the 8 halves B[k = stage*16 + g*8 + e][col] * scale[col], e = 0..7;
+// inv_scale[col] = 1 / scale[col].  Source mapping as in mlp_bf16x6.hpp (mode 0: forward, B = W^T through the trunk's K
+// mapping; mode 1: backward data, B = W[:, hoff:hoff+ncols]).
+struct Prep3Job {
+    int mode, Kp, ncols, in_features, emb_dim, hoff, k_valid, col_valid;
+    const float* W;
+    uint4* Bp;
+    float* inv_scale;
+};
+static constexpr int PREP3_MAX_JOBS = 16;
+struct Prep3Batch {
+    Prep3Job job[PREP3_MAX_JOBS];
+};
+
+__device__ __forceinline__ float prep3_src(const Prep3Job& j, int k, int col) {
+    if (j.mode == 0) {
+        int src = k + j.hoff;  // (hoff: first input feature of a K = 256 slice -- the skip layer's trunk half)
+        if (j.Kp == 96) src = k < j.emb_dim ? k : -1;
+        else if (j.Kp == 352) src = k < 96 ? (k < j.emb_dim ? k : -1) : k - 96 + j.emb_dim;
+        return (src >= 0 && col < j.col_valid) ? j.W[(size_t)col * j.in_features + src] : 0.f;
+    }
+    return k < j.k_valid ? j.W[(size_t)k * j.in_features + j.hoff + col] : 0.f;
+}
+
 
 // exponent e of a tile from the float bits of its non-negative maximum: stored = value * 2^e, maximum -> [2^14, 2^15).
 // Clamped so that 2^e and 2^-e are normal floats (an all-zero tile gets a harmless finite scale).
@@ -323,6 +397,7 @@ struct Gemm4Args {
     float4* out2;               // DUAL: [ntiles][8][4][64] float4
     float* out;                 // EPI 3
     int ldo, n_valid;
+    int exps_limit;             // tiles of a workgroup whose input exponents come from its LDS table (<= Gemm4Cfg::EXPS); later ones from HBM
 };
 
 template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
@@ -566,7 +641,7 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
         const int e_prev = e_next;
         const unsigned mh_prev = mh_next;
         if (HM.value) {  // for the next step's E1 (tile j)
-            e_next = exps[j < Cfg::EXPS ? j : 0];
+            e_next = j < a.exps_limit ? exps[j] : a.Aexp[tile];  // (beyond the 512-entry table -- N > 4 M rows -- straight from HBM)
             if (EPI == 1) mh_next = reinterpret_cast<const unsigned short*>(Mibuf + ab * 1024)[(li * 8 + wv) * 2 + g];
         }
         const float c = binv * p4_pow2(-e_prev);
@@ -1048,9 +1123,13 @@ mlp_bwd_pair_kernel(const Gemm4Args ga, const Dw4Args da, const int n_dw, const 
 // G is in plane format; the products run in fp32 on the vector ALU: K = 256, 63 columns -- 2 x 3.3 GFLOP at N = 100 k, a small
 // fraction of a network pass, and the vertex count of the mesh phase is smaller still.  One 32-row tile per workgroup, thread
 // (ty, tx) owns rows {2 ty, 2 ty + 1} x columns {4 tx .. 4 tx + 3}; G and W go through LDS in K chunks of 32.
+// The same kernel serves a time input PER ROW (temb_stride != 0): dL/dt_emb[r] = G_5[r] W_5[:, 63:63+T] + G_0[r] W_0[:, 63:63+T],
+// columns [col0, col0 + ncol) of W with ncol <= 64; finish 0: product into scratch, 1: + scratch, derivative of PE -> dX (N, 3),
+// 2: + scratch -> out rows of `ldo` floats (dX = out).
 __global__ void __launch_bounds__(256)
 mlp_dx4_kernel(int N, const unsigned char* __restrict__ G, const int* __restrict__ Gexp, const float* __restrict__ W, int in_features,
-               float* __restrict__ scratch, int finish, const float* __restrict__ x, float* __restrict__ dX) {
+               int col0, int ncol, float* __restrict__ scratch, int finish, const float* __restrict__ x, float* __restrict__ dX,
+               int ldo) {
     __shared__ float sG[32][32 + 1];
     __shared__ float sW[32][64 + 1];
     __shared__ float sE[32][64 + 1];
@@ -1073,7 +1152,7 @@ mlp_dx4_kernel(int N, const unsigned char* __restrict__ G, const int* __restrict
         }
         for (int i = tid; i < 32 * 64; i += 256) {  // W chunk: rows k0 .. k0 + 31 (output units), columns 0 .. 62 (+ one zero)
             const int kk = i >> 6, c = i & 63;
-            sW[kk][c] = c < 63 ? W[(size_t)(k0 + kk) * in_features + c] : 0.f;
+            sW[kk][c] = c < ncol ? W[(size_t)(k0 + kk) * in_features + col0 + c] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -1102,6 +1181,14 @@ mlp_dx4_kernel(int N, const unsigned char* __restrict__ G, const int* __restrict
         }
     }
     if (!finish) return;
+    if (finish == 2) {  // per-row time gradient: the sums as they are
+        __syncthreads();
+        for (int i = tid; i < 32 * ncol; i += 256) {
+            const int rl = i / ncol, c = i - rl * ncol;
+            if (r0 + rl < N) dX[(size_t)(r0 + rl) * ldo + c] = sE[rl][c];
+        }
+        return;
+    }
     __syncthreads();
     if (tid < 96) {
         const int rl = tid / 3, d = tid - 3 * rl, r = r0 + rl;

@@ -212,6 +212,41 @@ def test_large_configs_binning_exact(orc, syn, cfg):
         assert np.array_equal(g1[k], g2[k]), f"{k} not bit-reproducible"
 
 
+def test_4k_image_binning_exact(orc, syn):
+    """A 4K-class image (3840 x 2160 = 32 400 tiles, near the 36 864-tile capacity of the per-chunk LDS histograms): the tile scan of
+    the last-arriving workgroup runs 127 passes of 256 tiles instead of 10 -- `ranges`, `point_list`, the worklists and the
+    backward's unit lists exact against the oracle's binning, blend through size-independent properties, gradients finite
+    and bit-reproducible."""
+    P, W, H = 60000, 3840, 2160
+    cam = syn.make_camera(W, H)
+    d2 = np.full(P, (2.6 / P ** (1 / 3.0)) ** 2 * 0.3, np.float32)
+    g = syn.make_gaussians(P, seed=5, dist2=d2)
+    act = syn.activate(g)
+    a = dict(bg=np.ones(3, np.float32), means3D=act["means3D"], colors_precomp=None, opacities=act["opacities"],
+             scales=act["scales"], rotations=act["rotations"], scale_modifier=1.0, cov3D_precomp=None,
+             viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+             tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2), H=H, W=W, sh=act["shs"], degree=3,
+             campos=cam.camera_center)
+    f_hip = G.hip_forward(a)
+    geom = orc.preprocess_fwd(P, 3, 16, a["means3D"], a["scales"], 1.0, a["rotations"], a["opacities"], a["sh"], None,
+                              None, a["viewmatrix"], a["projmatrix"], a["campos"], W, H, a["tanfovx"], a["tanfovy"])
+    b = orc.bin_tiles(P, W, H, geom)
+    assert (W + 15) // 16 * ((H + 15) // 16) == 32400
+    assert f_hip["num_rendered"] == b["num_rendered"] and b["num_rendered"] > 0
+    assert np.array_equal(f_hip["radii"], geom["radii"])
+    assert np.array_equal(f_hip["ranges"], b["ranges"])
+    assert np.array_equal(f_hip["point_list"], b["point_list"])
+    ln = b["ranges"][:, 1].astype(np.int64) - b["ranges"][:, 0]
+    assert int(f_hip["uctl"][32]) == int((ln > 0).sum())  # one last unit per non-empty tile
+    assert np.all((f_hip["final_T"] >= 0) & (f_hip["final_T"] <= 1))
+    dL = np.random.RandomState(0).randn(3, H, W).astype(np.float32)
+    g1 = G.hip_backward(a, f_hip, dL)
+    g2 = G.hip_backward(a, f_hip, dL)
+    for k in g1:
+        assert np.isfinite(g1[k]).all()
+        assert np.array_equal(g1[k], g2[k]), f"{k} not bit-reproducible"
+
+
 def test_edge_cases(orc, syn):
     W = H = 64
     a = raster_args(syn, 500, W, H, seed=4)
