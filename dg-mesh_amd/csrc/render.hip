@@ -21,7 +21,7 @@
 
 namespace dgm {
 
-template <bool PREFETCH>
+template <bool SPARSE>
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                   const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
@@ -61,11 +61,15 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     unsigned last_contributor = 0;
     unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);  // lanes whose pixel is finished (wave-uniform lane mask)
 
-    // A round's staging is two dependent gathers (list slice -> records).  On a sparse (trained) frame a tile is one serial chain of
-    // rounds with about one wave per SIMD to hide them behind, so PREFETCH software-pipelines them: the next round's list entry is
+    // SPARSE (frames with R < 2^20, picked by the launch like the unit length): a tile is one serial chain with about one wave per
+    // SIMD to hide anything behind.  A round's staging is two dependent gathers (list slice -> records); they are software-pipelined: the next round's list entry is
     // asked for at the top of a round's blend loop and its record half way through (by then the entry has arrived), and the next
     // round starts from registers (trained-like 0.097 -> 0.092 ms).  It costs 19 registers -- 5 waves per SIMD instead of 6 -- which
     // a dense frame, VALU-bound with every slot busy, pays for (0.217 -> 0.221 ms): the launch picks by R, like the unit length.
+    // (Also tried for sparse frames and dropped: four list entries per trip blended speculatively -- the running products formed
+    // for all four as if nothing stopped, the stop tests and contributions selected afterwards, bit-identical results without the
+    // ballot -> scalar mask -> inverse ballot round trip per entry: 0.102 ms against 0.091, and 0.266 against 0.218 on a dense frame.
+    // The per-entry decision chain is not what a trained tile waits for.)
     unsigned g_next = 0u;
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
     float ncb = 0.f;
@@ -106,7 +110,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         __syncthreads();
         const unsigned base = (unsigned)(i << 8);
         const int at_next = ((i + 1) << 8) + (int)threadIdx.x;
-        fetched = PREFETCH && i + 1 < rounds;
+        fetched = SPARSE && i + 1 < rounds;
         if (fetched && at_next < n) g_next = point_list[range.x + at_next];
         if (done_m == ~0ull) {  // whole quadrant finished: keep helping with staging only
             if (shortlist)

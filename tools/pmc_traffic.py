@@ -10,18 +10,16 @@ import os
 import sys
 
 fetch_csv, write_csv, out_dir, workload = sys.argv[1:5]
-KERNELS = {"gemm3r_fwd": "mlp_gemm3p_kernel<0, false>", "gemm3r_bwd": "mlp_gemm3p_kernel<1, false>", "dw3b": "mlp_dw3b_kernel",
-           "render_bwd4": "render_bwd4_kernel", "render_fwd": "render_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
-           "tile_sort_radix": "tile_sort_radix_kernel", "heads_bwd": "mlp_heads_bwd_kernel", "reduce_dw": "mlp_reduce_dw_all_kernel",
-           "dw3e_352": "mlp_dw3e_kernel<11>", "dw3e_96": "mlp_dw3e_kernel<3>", "gemm3p_skip": "mlp_gemm3p_kernel<2, false>",
-           "gemm3r_dual": "mlp_gemm3r_kernel<0, 6, 1, true>", "scatter": "dgm::scatter_kernel",
-           # the plane arithmetic (mode 3, round 3)
+KERNELS = {"render_bwd4": "render_bwd4_kernel", "render_fwd": "render_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
+           "tile_sort_radix": "tile_sort_radix_kernel", "reduce_dw": "mlp_reduce_dw_all_kernel", "scatter": "dgm::scatter_kernel",
+           "count_tiles": "count_tiles_kernel", "tile_scan": "tile_scan_kernel",
+           # the plane arithmetic
            "gemm4_fwd": "mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>", "gemm4_bwd": "mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>",
            "dw4": "mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>", "gemm4_skip": "mlp_gemm4_kernel<16, 1024, 512, 2, false, 8>",
            "gemm4_l0": "mlp_gemm4_kernel<6, 384, 192, 0, true, 8>", "dw4_emb": "mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>",
            "embed4": "mlp_embed4_kernel", "bwd_pair": "mlp_bwd_pair_kernel"}
 # kernels whose reads are gathers of short records: the x2 streaming-read correction of FETCH_SIZE is not calibrated for them
-GATHER = {"render_bwd4", "render_fwd", "preprocess_bwd", "tile_sort_radix", "scatter"}
+GATHER = {"render_bwd4", "render_fwd", "preprocess_bwd", "tile_sort_radix", "scatter", "count_tiles", "tile_scan"}
 
 
 def per_kernel(path, counter):
@@ -41,8 +39,7 @@ for short, pat in KERNELS.items():
     fk = [k for k in f if pat in k]
     wk = [k for k in w if pat in k]
     if not fk or not wk:
-        print("missing", short)
-        continue
+        continue  # (not in this run, e.g. the unpaired layer kernels)
     fetch_kb, write_kb = f[fk[0]], w[wk[0]]
     gather = short in GATHER
     rec = {"workload": workload, "kernel": pat, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
