@@ -62,9 +62,12 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
         const size_t first = offs[idx];
         const uint8_t* fl = live + first;
         const float* row = slab + first * DGM_SLAB_STRIDE;
+        // eight flags in ONE load (byte-aligned 8-byte access; up to 7 bytes past the Gaussian's own flags, inside the array's padding);
+        // the next eight are asked for before this batch's rows, so that a batch costs one dependent round trip, not two
+        unsigned long long f8_next = n ? *reinterpret_cast<const dgm_u64u*>(fl) : 0ull;
         for (unsigned k0 = 0; k0 < n; k0 += 8) {
-            // eight flags in ONE load (byte-aligned 8-byte access; up to 7 bytes past the Gaussian's own flags, inside the array's padding)
-            const unsigned long long f8 = *reinterpret_cast<const dgm_u64u*>(fl + k0);
+            const unsigned long long f8 = f8_next;
+            if (k0 + 8 < n) f8_next = *reinterpret_cast<const dgm_u64u*>(fl + k0 + 8);
             bool on[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) on[j] = k0 + j < n && ((f8 >> (8 * j)) & 0xffull) != 0;
