@@ -524,20 +524,20 @@ def main():
                   "mlp_gemm4_kernel<16,1024,512,1> (256->256 layer backward-data on planes, N rows)",
                   "mlp_dw4_kernel<8,8> (256x256 weight gradient over N rows, planes)")}.get(
             gemm_mode, ("mlp_gemm_kernel<0> (fp32 MFMA)", "mlp_gemm_kernel<1> (fp32 MFMA)", "mlp_dw_kernel (fp32 MFMA)"))
-        pm = ("r03_pmc_gemm4_fwd.json", "r03_pmc_gemm4_bwd.json", "r03_pmc_dw4.json") if planes else (None, None, None)
+        pm = ("r05_pmc_gemm4_fwd.json", "r03_pmc_gemm4_bwd.json", "r03_pmc_dw4.json") if planes else (None, None, None)
         kern = {  # stage -> (kernel name, algorithmic flops, algorithmic bytes, committed PMC file)
             "mlp_layer_fwd": (kn[0], layer_flops, layer_bytes, pm[0]),
             "mlp_layer_bwd": (kn[1], layer_flops, layer_bytes, pm[1]),
             "mlp_layer_dw": (kn[2], layer_flops, dw_bytes, pm[2]),
             # backward data + weight gradient of one layer in one launch (plane arithmetic): G_l read once algorithmically
             "mlp_bwd_pair": ("mlp_bwd_pair_kernel (256->256 backward-data on part of the CUs + 256x256 weight gradient on the rest)",
-                             2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r04_pmc_bwd_pair.json"),
-            "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r04_pmc_render_bwd4.json"),
-            "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "pmc_render_fwd.json"),
-            "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
+                             2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r05_pmc_bwd_pair.json"),
+            "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r05_pmc_render_bwd4.json"),
+            "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "r05_pmc_render_fwd.json"),
+            "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "r05_pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
             # 559 B per Gaussian + the 36-byte rows some pixel blended (live rows; the others are neither written nor read)
             "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 36.0 * (n_live_timed if n_live_timed is not None else n_inst),
-                               "r04_pmc_preprocess_bwd.json"),
+                               "r05_pmc_preprocess_bwd.json"),
             "preprocess_fwd": ("preprocess_fwd_kernel", 0.0, 311.0 * P, None),
         }
         kernels, best, best_ms = {}, None, -1.0
@@ -572,7 +572,7 @@ def main():
                          "ms_per_step": r["ms_per_step"], "frac_hbm": r["frac_hbm"], "frac_mfma_pipe": r.get("frac_mfma_pipe"),
                          "arithmetic": ("f16x3p: activations / gradients stored as 2 binary16 planes with one exponent per 32-row tile, "
                                         "split once by the producer, 3 MFMAs per product" if planes else "native fp32 MFMA")})
-        rb_traffic, rb_src = pmc_traffic("r04_pmc_render_bwd4.json")
+        rb_traffic, rb_src = pmc_traffic("r05_pmc_render_bwd4.json")
         out = {
             "metric": ("train-step iters/sec (800x800, ~100k Gaussians)" if WORKLOAD == "cfg2"
                        else f"train-step iters/sec ({WORKLOAD}: {W}x{H}, P={P}; informational, the metric is quoted on cfg2)"),
@@ -633,9 +633,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         if WORKLOAD == "cfg2":  # informational, offline: the reference's own step on this GPU model (a -m gpu test measures it)
             try:
-                r = json.load(open(os.path.join(ROOT, "profiles", "r04_ref_vs_ours_step.json")))
+                r = json.load(open(os.path.join(ROOT, "profiles", "r05_ref_vs_ours_step.json")))
                 out["reference_same_gpu"] = {"value": r["reference_shaped_it_s"], "unit": "it/s",
-                                             "source": "profiles/r04_ref_vs_ours_step.json (committed measurement of "
+                                             "source": "profiles/r05_ref_vs_ours_step.json (committed measurement of "
                                                        "tests/test_gpu_vs_reference.py, not taken in this run)"}
             except Exception:
                 pass
