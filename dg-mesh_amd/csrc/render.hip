@@ -130,9 +130,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                 const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g_next * DGM_REC_STRIDE);
                 n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
             }
-            const int sw = ulog == 6 ? sb : sb >> 1;  // staging wave = 64-entry block of the round
+            const int sw = sb >> (6 - ulog);  // staging wave = 64-entry block of the round
             unsigned long long m = sMask[sw][wv];
-            if (ulog == 5) m &= (sb & 1) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+            if (ulog < 6) m &= ((1ull << (1 << ulog)) - 1ull) << ((sb & ((1 << (6 - ulog)) - 1)) << ulog);  // this sub-block's entries
             m = uniform_u64(m);
             // Two list entries per trip: the second one's geometry (exponent, exp, alpha) does not depend on the first one's
             // blend, so a lone wave -- a trained scene leaves about one per SIMD -- overlaps the two dependency chains instead of
@@ -240,7 +240,7 @@ void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const uns
                        unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, size_t R, unsigned* uctl,
                        uint4* ulist_full, uint4* ulist_last, uint8_t* live) {
     const int ulog = replay_unit_log2(R);
-    if (ulog == 5)  // sparse frame
+    if (ulog < 6)  // sparse frame
         hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
                            out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
     else

@@ -121,6 +121,10 @@ __device__ unsigned long long rb4_trace[4 * 65536 + 1];
 // workgroups had nothing to do and sat between the working ones in dispatch order, working waves landed 4 to 8 per SIMD where 5
 // fit, and the kernel lasted as long as the SIMD that drew the most list entries (p50 174, max 286).  A unit's rows do not depend on
 // who computes them, nor on the order of the list: results are bit-identical whatever the schedule.
+// Also measured on top of this form and not kept: the forward leaving every list entry's record in list order (+ its row index) on
+// sparse frames, so that a unit reads one contiguous 1.5 KB instead of list slice -> record gathers (a dependent round trip less):
+// 0.0628 against 0.0637 ms, forward +3 us; 16-entry units there: 0.0632, forward +9 us.  On a trained-like frame the kernel is bound by
+// the VALU work of the SIMD that draws the most blended entries (p50 170, max 240 of ~455 issue cycles each), not by its loads.
 // Built first and measured slower (tools/exp/render_bwd4_tickets_r5.hip.txt): atomic tickets over per-XCD lists
 // with stealing -- (i) a persistent grid of 4 / 5 waves per SIMD pulling unit after unit, next ticket and descriptor prefetched:
 // 0.354 / 0.415 ms on the initial scene (0.27 before), 0.126 / 0.163 trained-like (0.078): gfx9 has ONE in-order counter for loads
