@@ -1198,6 +1198,18 @@ int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
             if (p4_lds_attr(mlp_bwd_pair_kernel, LDS_PAIR, &done_[current_device_slot()]) != hipSuccess) return mlp_fail("p4_probe: LDS attribute");
             Dw4Args dp = d;
             dp.tiles_per_chunk = (nt + n_dw - 1) / n_dw;
+#ifdef P4_XCD_REDUCE
+            {
+                static unsigned* xs = nullptr;
+                static float* xp = nullptr;
+                static int gen = 0;
+                if (!xs) {
+                    if (hipMalloc((void**)&xs, 8 * 128) != hipSuccess || hipMalloc((void**)&xp, (size_t)8 * 65536 * 4) != hipSuccess) return mlp_fail("p4_probe: hipMalloc");
+                    (void)hipMemsetAsync(xs, 0, 8 * 128, st);
+                }
+                dp.xsync = getenv("DGM_P4_XCD_OFF") ? nullptr : xs, dp.xpartial = xp, dp.xgen = gen++, dp.xchunks = (nt + dp.tiles_per_chunk - 1) / dp.tiles_per_chunk;
+            }
+#endif
             const int grid = n_dw + (gx - n_dw > 0 ? gx - n_dw : 1);
             const int chunked = (grid - n_dw == n_dw && (n_dw % 8) == 0) ? 1 : 0;
             hipLaunchKernelGGL(mlp_bwd_pair_kernel, dim3(grid), dim3(512), LDS_PAIR, st, a, dp, n_dw, chunked);

@@ -899,6 +899,11 @@ struct Dw4Args {
     float* partial;       // + row offset already applied
     size_t chunk_stride;  // floats between chunks
     float* partial_db;    // may be NULL
+#ifdef P4_XCD_REDUCE      // (experiment, variant builds only: see dw4_body)
+    unsigned* xsync;      // one arrival word per group of chunks (c % 8), 128 bytes apart, zeroed once; counts up over launches
+    float* xpartial;      // [8][256][256]: the groups' pre-reduced tiles
+    int xgen, xchunks;    // launches before this one on these words; chunks of this launch
+#endif
 };
 
 __device__ __forceinline__ int dw4_pos(int col) { return (col & ~7) | ((col ^ (col >> 3)) & 7); }
@@ -1068,6 +1073,39 @@ __device__ __forceinline__ void dw4_body(const Dw4Args& a, const int chunk, unsi
                 out[(size_t)k * 256 + col] = ldexpf(acc[mt][r], -eref);
             }
         }
+#ifdef P4_XCD_REDUCE
+        // EXPERIMENT (measured with tools/power_probe.py, not in the product): the chunks of one XCD (c % 8 --
+        // consecutive workgroup ids go round the XCDs) meet at a device counter once their partial tiles are written, and each
+        // then sums its 1 / members share of the group's tiles in fixed chunk order into ONE tile per group, so that the final
+        // reduction would read 8 tiles per layer instead of 128.
+        if (MT == 8 && a.xsync != nullptr) {
+            const int grp = chunk & 7, member = chunk >> 3;
+            const int members = (a.xchunks - grp + 7) >> 3;
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                atomicAdd(&a.xsync[grp * 32], 1u);
+                const unsigned want = (unsigned)members * (unsigned)(a.xgen + 1);
+                for (int spin = 0; spin < (1 << 20); spin++) {  // (bounded: a probe must not hang the box)
+                    if (__hip_atomic_load(&a.xsync[grp * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            // this member's rows of the 256-row tile: [r0, r1); 64 float4 per row
+            const int rows_per = (256 + members - 1) / members, r0 = member * rows_per, r1 = min(256, r0 + rows_per);
+            for (int i = r0 * 64 + tid; i < r1 * 64; i += 512) {
+                float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int m = 0; m < members; m++) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.partial + (size_t)(grp + 8 * m) * a.chunk_stride + (size_t)i * 4);
+                    sacc.x += v.x, sacc.y += v.y, sacc.z += v.z, sacc.w += v.w;
+                }
+                *reinterpret_cast<float4*>(a.xpartial + ((size_t)grp * 65536 + (size_t)i * 4)) = sacc;
+            }
+        }
+#endif
     } else {
         if (li < 16) {
 #pragma unroll
