@@ -24,8 +24,8 @@
 //     the tiles empty) the kernel's duration was that of ONE 256-entry segment -- 0.9 waves resident per SIMD, VALU busy 0.26
 //     (`profiles/r04_rasterbench_sq_trained_ksplit8.json`) -- and on the initial scene the shorter units trim the tail as well.  Longer
 //     lists keep 256-entry segments (16 bytes of checkpoints per entry);
-//   * rows.  36 bytes (9 floats), written only for instances some pixel blended; `live[row]` (one byte per instance,
-//     always written) tells preprocess_bwd which rows to read.  No zero rows are written or read.
+//   * rows.  36 bytes (9 floats), written only for instances some pixel blended; `live[row]` (one byte per instance, cleared by
+//     render_fwd, set here for the rows written) tells preprocess_bwd which rows to read.  No zero rows are written or read.
 // No atomics, bit-reproducible (fixed reduction and summation order).
 #include "dgm_common.hpp"
 #include "render_common.hpp"
