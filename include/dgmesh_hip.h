@@ -224,14 +224,12 @@ typedef struct {
     const float* bh;
 } dgm_mlp_params;
 
-/* Arithmetic of the trunk GEMMs.  3 (default): "f16x3p" -- the f16x3 arithmetic below on plane-format activations: every
- * activation / gradient tensor lives in HBM as its two binary16 planes with one power-of-two exponent per 32-row tile, split once
- * by the kernel that produces it (needs a broadcast time embedding, temb_stride == 0; other calls run mode 2).  2: "f16x3" -- fp32 operands scaled by a power of two and split into two binary16
- * numbers, three partial products accumulated in fp32 on the f16 matrix cores (its 32-column heads GEMM: operands split exactly
- * into three bf16 numbers, six partial products); 1: native fp32 MFMA.  All three are fp32 GEMMs to rounding.  (0, "bf16x6" for
- * every GEMM, was retired in round 4 and is ignored.)  Returns the previous mode; any other value only queries.  Process-wide;
- * the initial value comes from the environment variable DGM_MLP_GEMM=f16x3p|f16x3|f32.  A forward and its backward must run in
- * the same mode. */
+/* Arithmetic of the trunk GEMMs.  3 (default): "f16x3p" -- every fp32 operand scaled by a power of two and split into two binary16
+ * numbers, three partial products accumulated in fp32 on the f16 matrix cores, on plane-format activations: every activation /
+ * gradient tensor lives in HBM as its two binary16 planes with one power-of-two exponent per 32-row tile, split once by the kernel
+ * that produces it.  1: native fp32 MFMA.  Both are fp32 GEMMs to rounding.  (0, "bf16x6", and 2, "f16x3" on fp32 rows, were
+ * retired in rounds 4 / 5 and are ignored.)  Returns the previous mode; any other value only queries.  Process-wide; the initial
+ * value comes from the environment variable DGM_MLP_GEMM=f16x3p|f32.  A forward and its backward must run in the same mode. */
 int dgm_mlp_set_gemm(int mode);
 
 /* Bytes of the workspace that forward fills (embedding, the 8 post-ReLU activations, re-laid-out
@@ -257,7 +255,8 @@ int dgm_mlp_backward(const dgm_mlp_params* p, int N, const float* dOut, int temb
 /* The same, plus dX (N, 3) = dL/dx through both uses of PE(x) (layer 0 and the skip layer) and the derivative of the positional
  * encoding; x is the forward pass's input.  For networks whose input carries a gradient -- the appearance network on mesh
  * vertices moved by deform_back (dgmesh/utils/renderer.py:179-181, dgmesh/utils/time_utils.py:269-323).  x and dX may both be
- * NULL (= dgm_mlp_backward).  Plane arithmetic (the default) only: other modes return an error rather than drop the gradient. */
+ * NULL (= dgm_mlp_backward).  Plane arithmetic (the default) with a broadcast time row only: otherwise an error is returned rather
+ * than the gradient dropped. */
 int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, char* workspace,
                         float* const* dW, float* const* db, float* dWh, float* dbh, float* dtemb, const float* x, float* dX,
                         void* stream);
