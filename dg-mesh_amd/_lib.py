@@ -80,6 +80,9 @@ SYMBOLS = {
     "dgm_dpsr_interp_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "dgm_dpsr_interp_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgm_dpsr_spectral": (_i, [_i, _f, _vp, _vp, _i, _vp]),
+    "dgm_laplace_scratch_floats": (_c.c_size_t, [_i]),
+    "dgm_laplace_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dgm_laplace_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dgm_opacity_field_scratch_bytes": (_c.c_size_t, [_i]),
     "dgm_opacity_field": (_i, [_i, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "dgm_mlp_set_gemm": (_i, [_i]),

@@ -168,6 +168,75 @@ dpsr_spectral_kernel(int R, float sig, const float2* __restrict__ in, float2* __
     }
 }
 
+// ---- umbrella-operator Laplacian regulariser of a triangle mesh (R/nvdiffrast_utils/regularizer.py:40-60) -------------------
+//   term[v] = sum over the faces at v of (a - v) + (b - v)   (a, b the face's other corners; an interior edge counts twice)
+//   norm[v] = 2 x (faces at v);   loss = mean over the 3 V components of (term / max(norm, 1))^2
+// Three launches forward (per face: 9 + 3 fp32 atomics, like the reference's scatter_add_; per vertex: normalise, square, block
+// sums; one workgroup: the sum), one backward (per face: the transposed stencil of d loss / d term, 9 atomics).  acc = [term (V, 3)
+// | norm (V)], zeroed by the caller's entry point; the normalised term overwrites term for the backward.
+__global__ void __launch_bounds__(256)
+laplace_face_fwd_kernel(int F, const float* __restrict__ v, const int* __restrict__ f, float* __restrict__ term, float* __restrict__ norm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F) return;
+    const int i0 = f[3 * i], i1 = f[3 * i + 1], i2 = f[3 * i + 2];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float a = v[3 * i0 + c], b = v[3 * i1 + c], d = v[3 * i2 + c];
+        atomicAdd(&term[3 * i0 + c], (b - a) + (d - a));
+        atomicAdd(&term[3 * i1 + c], (a - b) + (d - b));
+        atomicAdd(&term[3 * i2 + c], (a - d) + (b - d));
+    }
+    atomicAdd(&norm[i0], 2.0f), atomicAdd(&norm[i1], 2.0f), atomicAdd(&norm[i2], 2.0f);
+}
+__global__ void __launch_bounds__(256)
+laplace_vertex_kernel(int V, float* __restrict__ term, const float* __restrict__ norm, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (i < V) {
+        const float inv = 1.0f / fmaxf(norm[i], 1.0f);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float t = term[3 * i + c] * inv;
+            term[3 * i + c] = t;
+            s += t * t;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256)
+laplace_sum_kernel(int nblk, int V, const float* __restrict__ partial, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (3.0f * (float)V);
+}
+// d loss / d v: g[v] = dloss * 2 t[v] / (3 V max(norm[v], 1)) is the gradient w.r.t. term[v]; term is linear in the corners
+__global__ void __launch_bounds__(256)
+laplace_face_bwd_kernel(int F, int V, const int* __restrict__ f, const float* __restrict__ tn, const float* __restrict__ norm,
+                        const float* __restrict__ dloss, float* __restrict__ dv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F) return;
+    const int i0 = f[3 * i], i1 = f[3 * i + 1], i2 = f[3 * i + 2];
+    const float k = dloss[0] * 2.0f / (3.0f * (float)V);
+    const float s0 = k / fmaxf(norm[i0], 1.0f), s1 = k / fmaxf(norm[i1], 1.0f), s2 = k / fmaxf(norm[i2], 1.0f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float g0 = tn[3 * i0 + c] * s0, g1 = tn[3 * i1 + c] * s1, g2 = tn[3 * i2 + c] * s2;
+        atomicAdd(&dv[3 * i0 + c], -2.0f * g0 + g1 + g2);
+        atomicAdd(&dv[3 * i1 + c], g0 - 2.0f * g1 + g2);
+        atomicAdd(&dv[3 * i2 + c], g0 + g1 - 2.0f * g2);
+    }
+}
+
 }  // namespace dgm
 
 using namespace dgm;
@@ -225,6 +294,30 @@ int dgm_dpsr_spectral(int res, float sig, const float* in, float* out, int adjoi
     const size_t K = (size_t)res * res * (res / 2 + 1);
     hipLaunchKernelGGL(dpsr_spectral_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, res, sig,
                        (const float2*)in, (float2*)out, adjoint);
+    return done();
+}
+
+size_t dgm_laplace_scratch_floats(int V) { return V > 0 ? (size_t)4 * V + (size_t)((V + 255) / 256) : 0; }
+
+int dgm_laplace_forward(int V, int F, const float* v_pos, const int* faces, float* scratch, float* loss, void* stream) {
+    if (V <= 0 || F < 0 || !v_pos || !scratch || !loss || (F > 0 && !faces)) return pfail("laplace_forward: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    float *term = scratch, *norm = scratch + (size_t)3 * V, *partial = scratch + (size_t)4 * V;
+    if (hipMemsetAsync(scratch, 0, (size_t)4 * V * sizeof(float), st) != hipSuccess) return pfail("laplace_forward: memset failed");
+    const int nblk = (V + 255) / 256;
+    if (F > 0) hipLaunchKernelGGL(laplace_face_fwd_kernel, dim3((F + 255) / 256), dim3(256), 0, st, F, v_pos, faces, term, norm);
+    hipLaunchKernelGGL(laplace_vertex_kernel, dim3(nblk), dim3(256), 0, st, V, term, norm, partial);
+    hipLaunchKernelGGL(laplace_sum_kernel, dim3(1), dim3(256), 0, st, nblk, V, partial, loss);
+    return done();
+}
+
+int dgm_laplace_backward(int V, int F, const int* faces, const float* scratch, const float* dloss, float* dv, void* stream) {
+    if (V <= 0 || F < 0 || !scratch || !dloss || !dv || (F > 0 && !faces)) return pfail("laplace_backward: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dv, 0, (size_t)3 * V * sizeof(float), st) != hipSuccess) return pfail("laplace_backward: memset failed");
+    if (F > 0)
+        hipLaunchKernelGGL(laplace_face_bwd_kernel, dim3((F + 255) / 256), dim3(256), 0, st, F, V, faces, scratch, scratch + (size_t)3 * V,
+                           dloss, dv);
     return done();
 }
 

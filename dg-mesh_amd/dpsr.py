@@ -137,8 +137,45 @@ class DPSR(nn.Module):
         return torch.stack(outs, 0)
 
 
+class _Laplace(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v_pos, faces):
+        L = _lib.lib()
+        v = v_pos.contiguous()
+        V, F = v.shape[0], faces.shape[0]
+        scratch = torch.empty(int(L.dgm_laplace_scratch_floats(V)), dtype=torch.float32, device=v.device)
+        loss = torch.empty(1, dtype=torch.float32, device=v.device)
+        with _lib.device_guard(v.device):
+            _lib.check(L.dgm_laplace_forward(V, F, _vp(v), _vp(faces), _vp(scratch), _vp(loss), _st()))
+        ctx.save_for_backward(faces, scratch)
+        ctx.V = V
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        faces, scratch = ctx.saved_tensors
+        dl = dloss.reshape(1).contiguous().float()
+        dv = torch.empty((ctx.V, 3), dtype=torch.float32, device=scratch.device)
+        with _lib.device_guard(scratch.device):
+            _lib.check(_lib.lib().dgm_laplace_backward(ctx.V, faces.shape[0], _vp(faces), _vp(scratch), _vp(dl), _vp(dv), _st()))
+        return dv, None
+
+
 def laplace_regularizer_const(v_pos, t_pos_idx):
-    """Umbrella-operator Laplacian regulariser of a triangle mesh (regularizer.py:40-60), torch index ops."""
+    """Umbrella-operator Laplacian regulariser of a triangle mesh (regularizer.py:40-60).  Device tensors run the HIP kernels
+    (csrc/dpsr.hip: dgm_laplace_forward / backward); host tensors -- the CPU tests' path -- the reference's index-op formulation."""
+    if v_pos.is_cuda:
+        if v_pos.dtype != torch.float32 or v_pos.dim() != 2 or v_pos.shape[1] != 3:
+            raise RuntimeError("laplace_regularizer_const: v_pos must be (V, 3) float32")
+        faces = t_pos_idx.to(device=v_pos.device, dtype=torch.int32).contiguous()
+        if faces.dim() != 2 or faces.shape[1] != 3:
+            raise RuntimeError("laplace_regularizer_const: t_pos_idx must be (F, 3)")
+        return _Laplace.apply(v_pos, faces)
+    return _laplace_regularizer_torch(v_pos, t_pos_idx)
+
+
+def _laplace_regularizer_torch(v_pos, t_pos_idx):
+    """The reference's formulation in torch index ops (host tensors; also the GPU test's comparison)."""
     idx = t_pos_idx.long()
     term = torch.zeros_like(v_pos)
     norm = torch.zeros_like(v_pos[..., 0:1])

@@ -361,6 +361,15 @@ int dgm_dpsr_interp_backward(int n, int res, const float* phi, const float* V, c
                              void* stream);
 int dgm_dpsr_spectral(int res, float sig, const float* in, float* out, int adjoint, void* stream);
 
+/* Umbrella-operator Laplacian regulariser of a triangle mesh, laplace_regularizer_const (dgmesh/nvdiffrast_utils/regularizer.py:40-60):
+ * loss[0] = mean over the 3 V components of (term / max(norm, 1))^2, term[v] = sum over the faces at v of (a - v) + (b - v),
+ * norm[v] = 2 x faces at v.  v_pos (V, 3) fp32, faces (F, 3) int32, scratch: dgm_laplace_scratch_floats(V) floats of caller-owned
+ * device memory that the backward reads again (normalised term, norm).  dv (V, 3) = dloss[0] x d loss / d v_pos (overwritten).
+ * Sums use fp32 atomics like the reference's scatter_add_: results agree to rounding, not bit for bit, run to run. */
+size_t dgm_laplace_scratch_floats(int V);
+int dgm_laplace_forward(int V, int F, const float* v_pos, const int* faces, float* scratch, float* loss, void* stream);
+int dgm_laplace_backward(int V, int F, const int* faces, const float* scratch, const float* dloss, float* dv, void* stream);
+
 /* ---- opacity field on a regular grid (csrc/opacity_field.hip) ------------------------------------------------------------
  * Replaces get_opacity_field_from_gaussians (dgmesh/utils/mesh_utils.py:7-76): occ[res^3] = sum over the Gaussians of the
  * cell's block (centre strictly inside the block's box grown by `margin`, opacity > opacity_threshold) of
