@@ -534,7 +534,7 @@ def main():
                              2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r05_pmc_bwd_pair.json"),
             "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r05_pmc_render_bwd4.json"),
             "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "r05_pmc_render_fwd.json"),
-            "tile_sort": ("tile_sort_radix_kernel (+ mid / big worklists)", 0.0, 24.0 * n_inst, "r05_pmc_tile_sort_radix.json"),  # 16-byte records in, point_list + upos out
+            "tile_sort": ("tile_sort_radix_kernel (+ the mid / big worklists' launch)", 0.0, 12.0 * n_inst, "r05_pmc_tile_sort_radix.json"),  # 8-byte records in, point_list out
             # 559 B per Gaussian + the 36-byte rows some pixel blended (live rows; the others are neither written nor read)
             "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 36.0 * (n_live_timed if n_live_timed is not None else n_inst),
                                "r05_pmc_preprocess_bwd.json"),

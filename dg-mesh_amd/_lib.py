@@ -20,9 +20,9 @@ ALLOC_FN = _c.CFUNCTYPE(_c.c_void_p, _c.c_void_p, _c.c_size_t)
 class StateLayout(_c.Structure):
     """Mirror of dgm_state_layout (include/dgmesh_hip.h)."""
     _fields_ = [(n, _c.c_size_t) for n in (
-        "rec", "depth", "radii", "tiles_touched", "offs", "cov3D", "clamped", "block_sums", "block_offs", "hist",
+        "rec", "depth", "radii", "tiles_touched", "offs", "cov3D", "clamped", "block_sums", "hist",
         "tile_count", "tile_offset", "big_list", "counters", "geometry_bytes",
-        "inst", "point_list", "upos", "slab", "live", "ckpt", "ckpt64", "ulist_full", "binning_bytes",
+        "inst", "point_list", "slab", "live", "ckpt", "ckpt64", "ulist_full", "binning_bytes",
         "final_T", "n_contrib", "ranges", "nproc", "cfin", "ulist_last", "image_bytes")] + [
         (n, _c.c_int) for n in ("tiles_x", "tiles_y", "n_chunks", "chunk_size")]
 
@@ -96,7 +96,7 @@ SYMBOLS = {
 }
 
 _LIB = None
-ABI_VERSION = 3  # DGM_ABI_VERSION of include/dgmesh_hip.h
+ABI_VERSION = 4  # DGM_ABI_VERSION of include/dgmesh_hip.h
 
 
 def build(force=False, verbose=False):

@@ -13,12 +13,14 @@
 //                scan over tiles -> tile segment starts, `ranges` (empty tiles stay (0,0) like the
 //                reference's memset) and R;
 //   3. scatter : same chunk workgroups, LDS cursors initialised to (tile start + chunk prefix), each
-//                instance takes a slot with one LDS atomic and writes its 16-byte record
-//                (gaussian, depth bits, position in the per-Gaussian order) straight into its tile segment;
+//                instance takes a slot with one LDS atomic and writes its 8-byte record (gaussian, depth bits) straight
+//                into its tile segment;
 //   4. sort    : one workgroup per tile sorts its segment -- an LSD radix sort on the depth bits with an index tie-break, pairs in
 //                registers / LDS for segments up to 4096 entries, in global memory (L2) beyond that; the result does not
-//                depend on the atomic arrival order -- and emits point_list plus
-//                upos[slot] = offs[g]+k, the instance's position in the per-Gaussian order (backward rows).
+//                depend on the atomic arrival order -- and emits point_list.  (Rounds 2-4 also carried offs[g] + k, the instance's
+//                row in the per-Gaussian order, through the sort into a `upos` array for the backward: 8 more bytes per record
+//                in the scatter, 4 written here and 4 read by render_bwd4 -- which loads rec[g], where the rectangle and offs[g]
+//                sit, anyway, and now forms the row itself: render_common.hpp instance_row.)
 // Wave-cooperative rectangle expansion: a wave loads 64 Gaussians, then iterates over the lanes that own a
 // non-empty rectangle (scalar bit loop on the ballot mask) and lets all 64 lanes cover that rectangle's
 // tiles, so a Gaussian spanning thousands of tiles costs the same lane-cycles as many small ones.
@@ -55,19 +57,27 @@ scan_exclusive_kernel(int n, const unsigned* __restrict__ in, unsigned* __restri
 
 // ---- shared by count and scatter: iterate all (gaussian, tile) instances of a chunk -------------------------
 // F(tile, g, k) is invoked once per instance with all lanes of the wave active on different k.
+// exact k / w for k*w < 2^32 via a 32x32->hi multiply by ceil(2^32 / w)  (w >= 2; 0 stands for w <= 1: y = k).  Every lane divides
+// for its OWN Gaussian, once, before the wave walks the Gaussians one by one: the walk is a serial chain per wave (64 steps,
+// one wave per SIMD), and a scalar 32-bit division inside it was ~25 dependent instructions of every step.
+__device__ __forceinline__ unsigned rect_magic(unsigned rect) {
+    const unsigned w = rect >> 20;
+    return w > 1 ? (0xFFFFFFFFu / w + 1u) : 0u;
+}
+
 template <typename F>
 __device__ __forceinline__ void for_each_instance(int g, unsigned tt, unsigned rect, int gridx, F&& f) {
     unsigned long long m = __ballot(tt != 0u);
+    const unsigned magic_l = rect_magic(rect);
     while (m) {
         const int src = __builtin_ctzll(m);
         m &= m - 1;
         const unsigned tt_i = __builtin_amdgcn_readlane(tt, src);
         const unsigned rect_i = __builtin_amdgcn_readlane(rect, src);
         const int g_i = __builtin_amdgcn_readlane(g, src);
+        const unsigned magic = __builtin_amdgcn_readlane(magic_l, src);
         unsigned xmin, ymin, w;
         unpack_rect(rect_i, xmin, ymin, w);
-        // exact k / w for k*w < 2^32 via a 32x32->hi multiply by ceil(2^32 / w)  (w >= 2)
-        const unsigned magic = w > 1 ? (0xFFFFFFFFu / w + 1u) : 0u;
         for (unsigned k = lane_id(); k < tt_i; k += 64) {
             const unsigned y = w > 1 ? __umulhi(k, magic) : k;
             const unsigned x = k - y * w;
@@ -77,31 +87,54 @@ __device__ __forceinline__ void for_each_instance(int g, unsigned tt, unsigned r
     }
 }
 
-// count: also finishes the exclusive scan over Gaussians (offs) from the per-256 block offsets.
+// count: also makes the exclusive scan over Gaussians (offs) from preprocess_fwd's per-256 block sums -- every workgroup adds up the
+// sums in front of its chunk itself (a few hundred words), which retired the single-workgroup scan launch between the two kernels.
 __global__ void __launch_bounds__(DGM_BIN_THREADS)
 count_tiles_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restrict__ tiles_touched,
-                   float* __restrict__ rec, const unsigned* __restrict__ block_offs, unsigned* __restrict__ offs,
-                   unsigned* __restrict__ hist) {
+                   float* __restrict__ rec, const unsigned* __restrict__ block_sums, unsigned* __restrict__ offs,
+                   unsigned* __restrict__ hist, unsigned* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_hist[];
     __shared__ unsigned wave_tot[DGM_BIN_THREADS / 64];
     for (int t = threadIdx.x; t < tiles; t += DGM_BIN_THREADS) lds_hist[t] = 0u;
-    __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(P, g0 + chunk);
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    for (int base = g0; base < g1; base += DGM_BIN_THREADS) {
-        const int g = base + threadIdx.x;
+    unsigned carry = 0u;  // offs of the pass's first Gaussian
+    if (blockIdx.x == 0) {
+        // the forward call's counter words: everything from tile_scan_kernel on expects them zero, and [1] carries the "culled
+        // although prefiltered" flag that preprocess_fwd leaves in the top bits of its block sums (c_api.hip reads it back with R)
+        unsigned bad = 0u;
+        for (int i = threadIdx.x; i < (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK; i += DGM_BIN_THREADS) bad |= block_sums[i] >> 31;
+        bad = __syncthreads_or((int)bad) ? 1u : 0u;
+        if (threadIdx.x < 8 + DGM_UCTL_WORDS) counters[threadIdx.x] = threadIdx.x == 1 ? bad : 0u;
+    }
+    {
+        unsigned part = 0u;
+        for (int i = threadIdx.x; i < g0 / DGM_PRE_BLOCK; i += DGM_BIN_THREADS) part += block_sums[i] & 0x7fffffffu;  // (chunks: multiples)
+        part = wave_inclusive_scan_u32(part);
+        if (lane == 63) wave_tot[wv] = part;
+        __syncthreads();  // (also: lds_hist is cleared)
+#pragma unroll
+        for (int w = 0; w < DGM_BIN_THREADS / 64; w++) carry += wave_tot[w];
+        __syncthreads();
+    }
+    for (int base = g0; base < g1; base += DGM_BIN_PASS) {
+        const int g = base + wv * 32 + (lane & 31);  // (32 Gaussians per wave, in its lower half)
+        const bool mine = lane < 32 && g < g1;
         unsigned tt = 0u, rect = 0u;
-        if (g < g1) {
+        if (mine) {
             tt = tiles_touched[g];
             rect = __float_as_uint(rec[(size_t)g * DGM_REC_STRIDE + 9]);
         }
-        // exclusive offset = block_offs[g / 256] + prefix inside the 256-group (4 waves)
         const unsigned inc = wave_inclusive_scan_u32(tt);
         if (lane == 63) wave_tot[wv] = inc;
         __syncthreads();
-        if (g < g1) {
-            unsigned pre = block_offs[g / DGM_PRE_BLOCK];
-            for (int w = wv & ~3; w < wv; w++) pre += wave_tot[w];
+        unsigned pre = carry;
+#pragma unroll
+        for (int w = 0; w < DGM_BIN_THREADS / 64; w++) {
+            pre += w < wv ? wave_tot[w] : 0u;
+            carry += wave_tot[w];
+        }
+        if (mine) {
             const unsigned o = pre + inc - tt;
             offs[g] = o;
             rec[(size_t)g * DGM_REC_STRIDE + 10] = __uint_as_float(o);
@@ -125,7 +158,7 @@ count_tiles_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __res
 __global__ void __launch_bounds__(256)
 tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ hist, unsigned* __restrict__ tile_count,
                  unsigned* __restrict__ tile_offset, uint2* __restrict__ ranges, unsigned* __restrict__ big_list,
-                 unsigned* __restrict__ big_count, unsigned* __restrict__ arrive) {
+                 unsigned* __restrict__ big_count, unsigned* __restrict__ arrive, unsigned* __restrict__ total) {
     constexpr int MAXC = DGM_MAX_CHUNKS / 4;  // chunk rows per wave
     __shared__ unsigned wtot[4][64];
     __shared__ unsigned wave_sum[4];
@@ -161,50 +194,78 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
     __syncthreads();
     if (!last) return;
     __threadfence();
-    // exclusive scan of the tile totals, 256 tiles a pass: thread i takes tile base + i, so every access is one 1 KiB segment
-    // per wave whatever the tile count (the first version gave each thread a contiguous run of ceil(tiles / 256) tiles: fine at
-    // 2 500 tiles, a serial walk of 127 strided loads and stores per thread at 4K-class images)
+    // exclusive scan of the tile totals: thread i takes the K = 16 consecutive tiles base + 16 i .. (four 16-byte loads in flight
+    // together, a scan in registers, ONE exchange of the thread totals), 4096 tiles a pass.  (First version: a contiguous run of
+    // ceil(tiles / 256) tiles per thread -- a serial walk of 127 strided loads per thread at 4K-class images; second: 256 tiles a
+    // pass with thread i on tile base + i -- ten dependent load -> scan -> barrier round trips at cfg2's 2 500 tiles, ~10 us of this
+    // kernel's 20 with every other workgroup gone.)  The block of 16 that holds the last tile may reach past `tiles`: tile_count's
+    // allocation is padded to the layout's alignment (>= 64 bytes), the values read there are masked.
+    constexpr int K = 16;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
     unsigned run_total = 0;
-    for (int base = 0; base < tiles; base += 256) {
-        const int t = base + (int)threadIdx.x;
-        const unsigned c = t < tiles ? __builtin_nontemporal_load(tile_count + t) : 0u;
-        const unsigned inc = wave_inclusive_scan_u32(c);
+    for (int base = 0; base < tiles; base += 256 * K) {
+        const int t0 = base + (int)threadIdx.x * K;
+        unsigned c[K];
+#pragma unroll
+        for (int q = 0; q < K / 4; q++) {
+            u4v v = {0u, 0u, 0u, 0u};
+            if (t0 + 4 * q < tiles) v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(tile_count + t0) + q);
+            c[4 * q] = v.x, c[4 * q + 1] = v.y, c[4 * q + 2] = v.z, c[4 * q + 3] = v.w;
+        }
+        unsigned tot = 0u;
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            if (t0 + q >= tiles) c[q] = 0u;
+            tot += c[q];
+        }
+        const unsigned inc = wave_inclusive_scan_u32(tot);
         if (lane == 63) wave_sum[wv] = inc;
         __syncthreads();
-        unsigned start = run_total + inc - c;
+        unsigned start = run_total + inc - tot;
         for (int w = 0; w < wv; w++) start += wave_sum[w];
-        if (t < tiles) {
-            tile_offset[t] = start;
-            ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
-            // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
-            if (c > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
-            else if (c > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            const int t = t0 + q;
+            if (t < tiles) {
+                tile_offset[t] = start;
+                ranges[t] = c[q] ? make_uint2(start, start + c[q]) : make_uint2(0u, 0u);
+                // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
+                if (c[q] > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
+                else if (c[q] > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
+            }
+            start += c[q];
         }
         run_total += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
         __syncthreads();  // (wave_sum is rewritten by the next pass)
     }
-    if (threadIdx.x == 0) tile_offset[tiles] = run_total;
+    if (threadIdx.x == 0) tile_offset[tiles] = run_total, *total = run_total;  // (R: the host reads it back to size the binning buffer)
 }
 
 __global__ void __launch_bounds__(DGM_BIN_THREADS)
-scatter_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restrict__ tiles_touched,
+scatter_kernel(int P, int chunk, int nchunks, int tiles, int gridx, const unsigned* __restrict__ tiles_touched,
                const float* __restrict__ rec, const float* __restrict__ depth, const unsigned* __restrict__ hist,
-               const unsigned* __restrict__ tile_offset, uint4* __restrict__ inst) {
+               const unsigned* __restrict__ tile_offset, uint2* __restrict__ inst) {
     extern __shared__ __attribute__((aligned(16))) unsigned cursor[];
-    const unsigned* row = hist + (size_t)blockIdx.x * tiles;
+    // Workgroup b runs on XCD b % 8, and the chunks' shares of a tile's segment lie one behind the other (67 bytes each on average at
+    // cfg2): XCD x takes the x-th eighth of the chunks, so that the lines of its part of every segment fill up in ONE L2 instead of
+    // being written back in pieces by two or three.
+    const int per_xcd = (nchunks + 7) >> 3;
+    const int chunk_id = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (chunk_id >= nchunks) return;
+    const unsigned* row = hist + (size_t)chunk_id * tiles;
     for (int t = threadIdx.x; t < tiles; t += DGM_BIN_THREADS) cursor[t] = tile_offset[t] + row[t];
     __syncthreads();
-    const int g0 = blockIdx.x * chunk, g1 = min(P, g0 + chunk);
-    for (int base = g0; base < g1; base += DGM_BIN_THREADS) {
-        const int g = base + threadIdx.x;
-        unsigned tt = 0u, rect = 0u, dbits = 0u, og = 0u;
-        if (g < g1) {
+    const int g0 = chunk_id * chunk, g1 = min(P, g0 + chunk);
+    for (int base = g0; base < g1; base += DGM_BIN_PASS) {
+        const int g = base + (int)(threadIdx.x >> 6) * 32 + (int)(threadIdx.x & 31u);  // (as in count_tiles_kernel)
+        unsigned tt = 0u, rect = 0u, dbits = 0u;
+        if ((threadIdx.x & 32u) == 0u && g < g1) {
             tt = tiles_touched[g];
             rect = __float_as_uint(rec[(size_t)g * DGM_REC_STRIDE + 9]);
-            og = __float_as_uint(rec[(size_t)g * DGM_REC_STRIDE + 10]);  // offs[g] (count_tiles_kernel)
             dbits = __float_as_uint(depth[g]);
         }
         unsigned long long m = __ballot(tt != 0u);
+        const unsigned magic_l = rect_magic(rect);
         while (m) {
             const int src = __builtin_ctzll(m);
             m &= m - 1;
@@ -212,18 +273,18 @@ scatter_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restric
             const unsigned rect_i = __builtin_amdgcn_readlane(rect, src);
             const unsigned d_i = __builtin_amdgcn_readlane(dbits, src);
             const unsigned g_i = (unsigned)__builtin_amdgcn_readlane(g, src);
-            const unsigned o_i = __builtin_amdgcn_readlane(og, src);
+            const unsigned magic = __builtin_amdgcn_readlane(magic_l, src);
             unsigned xmin, ymin, w;
             unpack_rect(rect_i, xmin, ymin, w);
-            const unsigned magic = w > 1 ? (0xFFFFFFFFu / w + 1u) : 0u;
             for (unsigned k = lane_id(); k < tt_i; k += 64) {
                 const unsigned y = w > 1 ? __umulhi(k, magic) : k;
                 const unsigned x = k - y * w;
                 const unsigned tile = (ymin + y) * (unsigned)gridx + xmin + x;
                 const unsigned slot = atomicAdd(&cursor[tile], 1u);
-                // one 16-byte store: Gaussian, depth bits (the sort key: depth, then Gaussian) and the position of this
-                // instance in the per-Gaussian order, which the tile sort carries along to `upos`
-                inst[slot] = make_uint4(g_i, d_i, o_i + k, 0u);
+                // one 8-byte store: Gaussian and depth bits (the sort key: depth, then Gaussian).  The kernel is bound by these
+                // scattered writes (rounds 2-4, 16-byte records: 100 MB at the memory for 66 MB of records at cfg2 -- lines leave L2
+                // partly written)
+                inst[slot] = make_uint2(g_i, d_i);
             }
         }
     }
@@ -241,8 +302,8 @@ scatter_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __restric
 //   * equal depths must end in ascending Gaussian index (what the reference's stable sort of the index-ordered emission
 //     gives): after the last pass entries with an equal neighbour are placed inside their run by counting smaller indices;
 //     a segment with a long run of equal depths is sorted again with index passes in front of the depth passes.
-// The Gaussian index and the per-Gaussian position are fetched from the instance records through the payload only once, at
-// the end (one 16-byte gather inside the tile's own segment), and the output is written in order.
+// The Gaussian index is fetched from the instance records through the payload only once, at the end (one gather inside the
+// tile's own segment), and the output is written in order.
 // (WAVES, RS_MAXB pairs per thread) = (4, 8): 256 threads, segments up to 2048 entries, one workgroup per tile at 65 VGPRs
 // (sixteen pairs per thread cost 248); (8, 8): 512 threads, up to 4096 entries, the tiles of the device-built "mid"
 // worklist -- a long segment is spread over more waves instead of more registers.
@@ -262,6 +323,21 @@ __device__ __forceinline__ unsigned radix_varying_bits(const unsigned (&key)[RS_
     const unsigned v = s_red[0] ^ s_red[1];
     __syncthreads();  // (s_red is reused)
     return v;
+}
+
+// Lanes of the wave that hold the same 8-bit digit as this one (among the `valid` lanes), as the two halves of a 64-bit mask: per bit
+// one ballot and m &= (bit set ? ballot : ~ballot) = m & ~(ballot ^ x) with x = 0 / -1 the sign-extended bit -- ONE v_bitop3_b32 per
+// half (truth table 0x90 over (m, ballot, x)), 5 instructions per bit; the select form (`bs ? bb : ~bb`) compiled to 9.
+__device__ __forceinline__ void match_digit(unsigned d, bool valid, unsigned& m_lo, unsigned& m_hi) {
+    const unsigned long long mv = __ballot(valid);
+    m_lo = (unsigned)mv, m_hi = (unsigned)(mv >> 32);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        const int x = __builtin_amdgcn_sbfe((int)d, bit, 1);
+        const unsigned long long bb = __ballot(x != 0);
+        m_lo = __builtin_amdgcn_bitop3_b32(m_lo, (unsigned)bb, (unsigned)x, 0x90);
+        m_hi = __builtin_amdgcn_bitop3_b32(m_hi, (unsigned)(bb >> 32), (unsigned)x, 0x90);
+    }
 }
 
 // stable LSD passes over the bits set in `varying`, 8 bits per pass; on return sk[0 .. n) holds the (key, payload) pairs in
@@ -284,20 +360,15 @@ __device__ __forceinline__ void radix_passes(unsigned (&key)[RS_MAXB], unsigned 
             if (b < nb) {
                 const bool valid = w0 + b * 64 + lane < n;
                 const unsigned d = (key[b] >> shift) & 255u;
-                unsigned long long m = __ballot(valid);
-#pragma unroll
-                for (int bit = 0; bit < 8; bit++) {
-                    const bool bs = (d >> bit) & 1u;
-                    const unsigned long long bb = __ballot(bs);
-                    m &= bs ? bb : ~bb;
-                }
-                const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                unsigned m_lo, m_hi;
+                match_digit(d, valid, m_lo, m_hi);
+                const unsigned rk = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
                 unsigned old = 0u;
                 if (valid && rk == 0u) {  // first lane of its digit group
                     old = cnt[wv][d];
-                    cnt[wv][d] = old + (unsigned)__popcll(m);
+                    cnt[wv][d] = old + (unsigned)(__popc(m_lo) + __popc(m_hi));
                 }
-                const int leader = valid ? __builtin_ctzll(m) : lane;
+                const int leader = valid ? (m_lo ? __builtin_ctz(m_lo) : 32 + __builtin_ctz(m_hi)) : lane;
                 old = (unsigned)__shfl((int)old, leader, 64);
                 rank[b] = old + rk;
             }
@@ -352,14 +423,13 @@ __device__ __forceinline__ void radix_passes(unsigned (&key)[RS_MAXB], unsigned 
 static constexpr int kTieRun = 32;  // runs of equal depth up to this length are ordered in place, longer ones by index passes
 
 template <int WAVES, int RS_MAXB>
-__device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __restrict__ inst, unsigned* __restrict__ point_list,
-                                                unsigned* __restrict__ upos, uint2* sk, unsigned (*cnt)[256],
-                                                unsigned* s_red) {
+__device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint2* __restrict__ inst, unsigned* __restrict__ point_list, uint2* sk,
+                                                unsigned (*cnt)[256], unsigned* s_red) {
     const int n = (int)(r.y - r.x);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nb = (n + WAVES * 64 - 1) / (WAVES * 64);  // batches of 64 per wave
     const int w0 = wv * nb * 64;    // first array index of this wave
-    const uint4* seg = inst + r.x;  // (Gaussian, depth bits, per-Gaussian position, -) in arrival order
+    const uint2* seg = inst + r.x;  // (Gaussian, depth bits) in arrival order
     // Equal depths must come out by ascending Gaussian index.  Short runs (the normal case: none, or a pair) are ordered in
     // place below; if any run is longer than kTieRun -- a scene whose Gaussians share one view depth -- the segment is sorted
     // again from scratch with index passes in front of the depth passes (LSD: the later key is the more significant).
@@ -375,7 +445,7 @@ __device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __re
             if (phase < 2) pay[b] = valid ? (unsigned)i : 0u;
             key[b] = 0xFFFFFFFFu;
             if (valid) {
-                const uint4 e = seg[pay[b]];
+                const uint2 e = seg[pay[b]];
                 key[b] = phase == 1 ? e.x : e.y;
             }
         }
@@ -395,15 +465,14 @@ __device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __re
         }
     }
     // gather the Gaussian index and the per-Gaussian position through the payload; place the members of short runs
-    unsigned gid[RS_MAXB], up[RS_MAXB], dst[RS_MAXB];
+    unsigned gid[RS_MAXB], dst[RS_MAXB];
 #pragma unroll
     for (int b = 0; b < RS_MAXB; b++) {
-        gid[b] = up[b] = dst[b] = 0u;
+        gid[b] = dst[b] = 0u;
         if (b < nb) {
             const int i = w0 + b * 64 + lane;
             if (i < n) {
-                const uint4 e = seg[pay[b]];
-                gid[b] = e.x, up[b] = e.z;
+                gid[b] = seg[pay[b]].x;
                 dst[b] = (unsigned)i;
                 const bool tie = !resort && ((i > 0 && sk[i - 1].x == key[b]) || (i + 1 < n && sk[i + 1].x == key[b]));
                 if (tie) {
@@ -419,37 +488,31 @@ __device__ __forceinline__ void radix_sort_tile(const uint2 r, const uint4* __re
     }
 #pragma unroll
     for (int b = 0; b < RS_MAXB; b++) {
-        if (b < nb && w0 + b * 64 + lane < n) {
-            point_list[r.x + dst[b]] = gid[b];
-            upos[r.x + dst[b]] = up[b];
-        }
+        if (b < nb && w0 + b * 64 + lane < n) point_list[r.x + dst[b]] = gid[b];
     }
 }
 
 __global__ void __launch_bounds__(256)
-tile_sort_radix_kernel(const uint2* __restrict__ ranges, const uint4* __restrict__ inst, unsigned* __restrict__ point_list,
-                       unsigned* __restrict__ upos) {
+tile_sort_radix_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ inst, unsigned* __restrict__ point_list) {
     __shared__ __attribute__((aligned(16))) uint2 sk[kRadixCap];
     __shared__ __attribute__((aligned(16))) unsigned cnt[4][256];
     __shared__ unsigned s_red[2];
     const uint2 r = ranges[blockIdx.x];
     const int n = (int)(r.y - r.x);
     if (n < 1 || n > kRadixCap) return;  // longer segments: the worklists
-    radix_sort_tile<4, kRadixCap / 256>(r, inst, point_list, upos, sk, cnt, s_red);
+    radix_sort_tile<4, kRadixCap / 256>(r, inst, point_list, sk, cnt, s_red);
 }
 
 // segments of kRadixCap + 1 .. 4096 entries: the "mid" worklist (filled from the END of big_list by write_ranges_kernel), fixed grid
 __global__ void __launch_bounds__(512)
 tile_sort_radix_mid_kernel(int tiles, const unsigned* __restrict__ big_list, const unsigned* __restrict__ mid_count,
-                           const uint2* __restrict__ ranges, const uint4* __restrict__ inst,
-                           unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
+                           const uint2* __restrict__ ranges, const uint2* __restrict__ inst, unsigned* __restrict__ point_list) {
     __shared__ __attribute__((aligned(16))) uint2 sk[4096];
     __shared__ __attribute__((aligned(16))) unsigned cnt[8][256];
     __shared__ unsigned s_red[2];
     const unsigned count = *mid_count;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
-        const uint2 r = ranges[big_list[tiles - 1 - (int)w]];
-        radix_sort_tile<8, 8>(r, inst, point_list, upos, sk, cnt, s_red);
+        radix_sort_tile<8, 8>(ranges[big_list[tiles - 1 - (int)w]], inst, point_list, sk, cnt, s_red);
         __syncthreads();
     }
 }
@@ -483,16 +546,11 @@ __device__ __forceinline__ void radix_pass_global(const uint2* __restrict__ src,
         for (int u = 0; u < GB; u++) {
             const bool valid = b0 + u < nbw && w0 + (b0 + u) * 64 + lane < n;
             const unsigned d = (key[u] >> shift) & 255u;
-            unsigned long long m = __ballot(valid);
-            if (m != 0ull) {
-#pragma unroll
-                for (int bit = 0; bit < 8; bit++) {
-                    const bool bs = (d >> bit) & 1u;
-                    const unsigned long long bb = __ballot(bs);
-                    m &= bs ? bb : ~bb;
-                }
-                const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (valid && rk == 0u) cnt[wv][d] += (unsigned)__popcll(m);
+            if (__ballot(valid) != 0ull) {
+                unsigned m_lo, m_hi;
+                match_digit(d, valid, m_lo, m_hi);
+                const unsigned rk = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+                if (valid && rk == 0u) cnt[wv][d] += (unsigned)(__popc(m_lo) + __popc(m_hi));
             }
         }
     }
@@ -531,21 +589,16 @@ __device__ __forceinline__ void radix_pass_global(const uint2* __restrict__ src,
         for (int u = 0; u < GB; u++) {
             const bool valid = b0 + u < nbw && w0 + (b0 + u) * 64 + lane < n;
             const unsigned d = (e[u].x >> shift) & 255u;
-            unsigned long long m = __ballot(valid);
-            if (m != 0ull) {
-#pragma unroll
-                for (int bit = 0; bit < 8; bit++) {
-                    const bool bs = (d >> bit) & 1u;
-                    const unsigned long long bb = __ballot(bs);
-                    m &= bs ? bb : ~bb;
-                }
-                const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (__ballot(valid) != 0ull) {
+                unsigned m_lo, m_hi;
+                match_digit(d, valid, m_lo, m_hi);
+                const unsigned rk = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
                 unsigned old = 0u;
                 if (valid && rk == 0u) {
                     old = cnt[wv][d];
-                    cnt[wv][d] = old + (unsigned)__popcll(m);
+                    cnt[wv][d] = old + (unsigned)(__popc(m_lo) + __popc(m_hi));
                 }
-                const int leader = valid ? __builtin_ctzll(m) : lane;
+                const int leader = valid ? (m_lo ? __builtin_ctz(m_lo) : 32 + __builtin_ctz(m_hi)) : lane;
                 old = (unsigned)__shfl((int)old, leader, 64);
                 if (valid) dst[old + rk] = e[u];
             }
@@ -573,14 +626,13 @@ __device__ __forceinline__ unsigned varying_bits_global(const uint2* __restrict_
 
 // Segments that do not fit the LDS pair buffers: ONE pass through global memory -- a stable partition by the most significant
 // varying byte of the depth -- then consecutive buckets are taken through LDS in groups of up to kBigLds entries (copy in, the
-// remaining passes in LDS, gather + tie placement straight into point_list / upos).  Equal keys share a bucket, so runs never
+// remaining passes in LDS, gather + tie placement straight into point_list).  Equal keys share a bucket, so runs never
 // straddle groups.  Returns false (nothing final written) for what this shape does not cover -- one depth for the whole segment, a
 // bucket larger than the LDS buffers, a run of equal depths longer than kTieRun -- and the caller's all-global passes take over.
 template <int WAVES>
-__device__ __forceinline__ bool msd_first_sort(int n, unsigned rx, const uint4* __restrict__ seg, uint2* __restrict__ gA,
+__device__ __forceinline__ bool msd_first_sort(int n, unsigned rx, const uint2* __restrict__ seg, uint2* __restrict__ gA,
                                                uint2* __restrict__ gB, uint2* lds, unsigned (*cnt)[256], unsigned* s_red,
-                                               unsigned* dstart, unsigned* __restrict__ point_list,
-                                               unsigned* __restrict__ upos) {
+                                               unsigned* dstart, unsigned* __restrict__ point_list) {
     const int tid = threadIdx.x;
 #pragma unroll 4
     for (int i = tid; i < n; i += WAVES * 64) gA[i] = make_uint2(seg[i].y, (unsigned)i);
@@ -623,7 +675,7 @@ __device__ __forceinline__ bool msd_first_sort(int n, unsigned rx, const uint4* 
 #pragma unroll 2
             for (int i = tid; i < m; i += WAVES * 64) {
                 const uint2 me = cur[i];
-                const uint4 e = seg[me.y];
+                const uint2 e = seg[me.y];
                 unsigned at = (unsigned)i;
                 if ((i > 0 && cur[i - 1].x == me.x) || (i + 1 < m && cur[i + 1].x == me.x)) {
                     int a0 = i, a1 = i + 1;
@@ -634,7 +686,6 @@ __device__ __forceinline__ bool msd_first_sort(int n, unsigned rx, const uint4* 
                     at = (unsigned)a0 + below;
                 }
                 point_list[rx + s0 + at] = e.x;
-                upos[rx + s0 + at] = e.z;
             }
             __syncthreads();
         }
@@ -644,23 +695,34 @@ __device__ __forceinline__ bool msd_first_sort(int n, unsigned rx, const uint4* 
 }
 
 __global__ void __launch_bounds__(1024)
-tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
-                           const uint2* __restrict__ ranges, const uint4* __restrict__ inst, uint2* __restrict__ pairs, size_t R,
-                           unsigned* __restrict__ point_list, unsigned* __restrict__ upos) {
+tile_sort_radix_big_kernel(int tiles, const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
+                           const uint2* __restrict__ ranges, const uint2* __restrict__ inst, uint2* __restrict__ pairs, size_t R,
+                           unsigned* __restrict__ point_list) {
     constexpr int WAVES = 16;
     extern __shared__ __attribute__((aligned(16))) uint2 lds_pairs[];  // 2 x kBigLds pairs: segments up to kBigLds entries
     __shared__ __attribute__((aligned(16))) unsigned cnt[WAVES][256];  // ping-pong in LDS, longer ones in global memory
     __shared__ unsigned s_red[2];
     __shared__ __attribute__((aligned(16))) unsigned dstart[260];
+#ifndef DGM_MID_LAUNCH
+    // the "mid" worklist first (kRadixCap + 1 .. kSmallCap entries, from the END of big_list): pairs in registers, four per thread
+    // on sixteen waves, exchanged through the front of the pair buffer
+    {
+        const unsigned mids = big_count[1];
+        for (unsigned w = blockIdx.x; w < mids; w += gridDim.x) {
+            radix_sort_tile<WAVES, 4>(ranges[big_list[tiles - 1 - (int)w]], inst, point_list, lds_pairs, cnt, s_red);
+            __syncthreads();
+        }
+    }
+#endif
     const unsigned count = *big_count;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
         const uint2 r = ranges[big_list[w]];
         const int n = (int)(r.y - r.x);
-        const uint4* seg = inst + r.x;
+        const uint2* seg = inst + r.x;
         uint2* bufA = n <= kBigLds ? lds_pairs : pairs + r.x;  // two pair buffers of this segment
         uint2* bufB = n <= kBigLds ? lds_pairs + kBigLds : pairs + R + r.x;
         if (n > kBigLds &&
-            msd_first_sort<WAVES>(n, r.x, seg, bufA, bufB, lds_pairs, cnt, s_red, dstart, point_list, upos)) {  // (uniform)
+            msd_first_sort<WAVES>(n, r.x, seg, bufA, bufB, lds_pairs, cnt, s_red, dstart, point_list)) {  // (uniform)
             __syncthreads();
             continue;
         }
@@ -675,7 +737,7 @@ tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned
             } else {
 #pragma unroll 4
                 for (int i = threadIdx.x; i < n; i += WAVES * 64) {
-                    const uint4 e = seg[i];
+                    const uint2 e = seg[i];
                     bufA[i] = make_uint2(phase == 1 ? e.x : e.y, (unsigned)i);
                 }
             }
@@ -708,7 +770,7 @@ tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned
 #pragma unroll 2
         for (int i = threadIdx.x; i < n; i += WAVES * 64) {
             const uint2 me = bufA[i];
-            const uint4 e = seg[me.y];
+            const uint2 e = seg[me.y];
             unsigned at = (unsigned)i;
             if (!resort && ((i > 0 && bufA[i - 1].x == me.x) || (i + 1 < n && bufA[i + 1].x == me.x))) {
                 int s0 = i, s1 = i + 1;
@@ -719,7 +781,6 @@ tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned
                 at = (unsigned)s0 + below;
             }
             point_list[r.x + at] = e.x;
-            upos[r.x + at] = e.z;
         }
         __syncthreads();
     }
@@ -735,8 +796,8 @@ void launch_scan_blocks(hipStream_t st, int n, const unsigned* in, unsigned* out
 }
 
 hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
-                        const unsigned* tiles_touched, float* rec, const unsigned* block_offs, unsigned* offs,
-                        unsigned* hist) {
+                        const unsigned* tiles_touched, float* rec, const unsigned* block_sums, unsigned* offs,
+                        unsigned* hist, unsigned* counters) {
     const size_t lds = (size_t)tiles * 4;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)count_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -744,39 +805,44 @@ hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(count_tiles_kernel, dim3(nchunks), dim3(DGM_BIN_THREADS), lds, st, P, chunk, tiles, gridx,
-                       tiles_touched, rec, block_offs, offs, hist);
+                       tiles_touched, rec, block_sums, offs, hist, counters);
     return hipSuccess;
 }
 
 void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
-                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive) {
+                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive,
+                      unsigned* total) {
     hipLaunchKernelGGL(tile_scan_kernel, dim3((tiles + 63) / 64), dim3(256), 0, st, tiles, nchunks, kSmallCap, hist, tile_count,
-                       tile_offset, ranges, big_list, big_count, arrive);
+                       tile_offset, ranges, big_list, big_count, arrive, total);
 }
 
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
-                          const unsigned* tile_offset, uint4* inst) {
+                          const unsigned* tile_offset, uint2* inst) {
     const size_t lds = (size_t)tiles * 4;
     if (lds > 48 * 1024) {
         hipError_t e =
             hipFuncSetAttribute((const void*)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(scatter_kernel, dim3(nchunks), dim3(DGM_BIN_THREADS), lds, st, P, chunk, tiles, gridx,
+    hipLaunchKernelGGL(scatter_kernel, dim3(8 * ((nchunks + 7) / 8)), dim3(DGM_BIN_THREADS), lds, st, P, chunk, nchunks, tiles, gridx,
                        tiles_touched, rec, depth, hist, tile_offset, inst);
     return hipSuccess;
 }
 
-hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint4* inst, uint2* pairs, size_t R,
-                            unsigned* point_list, unsigned* upos, const unsigned* big_list, const unsigned* big_count) {
-    static_assert(kSmallCap == 8 * 64 * 8, "tile_sort_radix_mid_kernel covers segments up to kSmallCap");
+hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, const uint2* inst, uint2* pairs, size_t R,
+                            unsigned* point_list, const unsigned* big_list, const unsigned* big_count) {
+    static_assert(kSmallCap == 8 * 64 * 8 && kSmallCap == 16 * 64 * 4, "the mid worklist's sorts cover segments up to kSmallCap");
     // (tried: the mid worklist and the one-tile-per-workgroup class in ONE launch of 512-thread workgroups, short segments on eight
     // waves with four pairs a thread, so that the mid class's 32 us would run beside the short class: 84 -> 97-100 us at cfg2 --
     // eight waves pay twice the counter scan and barrier population for a 2048-entry segment)
-    hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(768), dim3(512), 0, st, tiles, big_list, big_count + 1, ranges, inst,
-                       point_list, upos);
-    hipLaunchKernelGGL(tile_sort_radix_kernel, dim3(tiles), dim3(256), 0, st, ranges, inst, point_list, upos);
+    // (tried in round 5: hipExtAnyOrderLaunch on the second and third launch -- packets without the barrier bit, so that the three
+    // classes, which sort disjoint tiles, run side by side.  The runtime ignores the flag on gfx9: the gap between the scatter's end and
+    // render_fwd's start stayed at 77-78 us = the sum of the three kernels, `tools/chain_wall.py`.)
+#ifdef DGM_MID_LAUNCH  // (rounds 2-4: the mid worklist as a launch of its own, 768 x 512 threads, eight pairs per thread)
+    hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(768), dim3(512), 0, st, tiles, big_list, big_count + 1, ranges, inst, point_list);
+#endif
+    hipLaunchKernelGGL(tile_sort_radix_kernel, dim3(tiles), dim3(256), 0, st, ranges, inst, point_list);
     static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
     bool& attr_set = attr_set_dev[current_device_slot()];
     if (!attr_set) {
@@ -785,8 +851,8 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(tile_sort_radix_big_kernel, dim3(256), dim3(1024), 2 * kBigLds * 8, st, big_list, big_count, ranges, inst,
-                       pairs, R, point_list, upos);
+    hipLaunchKernelGGL(tile_sort_radix_big_kernel, dim3(256), dim3(1024), 2 * kBigLds * 8, st, tiles, big_list, big_count, ranges, inst, pairs,
+                       R, point_list);
     return hipSuccess;
 }
 

@@ -22,21 +22,22 @@ void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* mea
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                            int gridx, int gridy, int prefiltered, int* radii_out, float* rec, float* depth,
                            int* radii_int, unsigned* tiles_touched, float* cov3Ds, uint8_t* clamped,
-                           unsigned* block_sums, unsigned* counters);
+                           unsigned* block_sums);
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
 // binning.hip
 int binning_lds_limit_tiles();
 void launch_scan_blocks(hipStream_t st, int n, const unsigned* in, unsigned* out, unsigned* total);
 hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
-                        const unsigned* tiles_touched, float* rec, const unsigned* block_offs, unsigned* offs,
-                        unsigned* hist);
+                        const unsigned* tiles_touched, float* rec, const unsigned* block_sums, unsigned* offs,
+                        unsigned* hist, unsigned* counters);
 void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
-                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive);
+                      unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive,
+                      unsigned* total);
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
-                          const unsigned* tile_offset, uint4* inst);
-hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, uint4* inst, uint2* pairs, size_t R,
-                            unsigned* point_list, unsigned* upos, const unsigned* big_list, const unsigned* big_count);
+                          const unsigned* tile_offset, uint2* inst);
+hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, const uint2* inst, uint2* pairs, size_t R,
+                            unsigned* point_list, const unsigned* big_list, const unsigned* big_count);
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
@@ -44,7 +45,7 @@ void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const uns
                        uint4* ulist_full, uint4* ulist_last, uint8_t* live);
 void launch_render_bwd4(hipStream_t st, int tiles, size_t R, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
-                        const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* upos, float* slab,
+                        const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, float* slab,
                         uint8_t* live, const unsigned* uctl, const uint4* ulist_full, const uint4* ulist_last);
 // preprocess_bwd.hip
 void launch_preprocess_bwd(hipStream_t st, int P, int D, int M, int gridx, const float* means3D, const int* radii,
@@ -343,7 +344,6 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     float* cov3D = (float*)(geom + L.cov3D);
     uint8_t* clamped = (uint8_t*)(geom + L.clamped);
     unsigned* block_sums = (unsigned*)(geom + L.block_sums);
-    unsigned* block_offs = (unsigned*)(geom + L.block_offs);
     unsigned* hist = (unsigned*)(geom + L.hist);
     unsigned* tile_count = (unsigned*)(geom + L.tile_count);
     unsigned* tile_offset = (unsigned*)(geom + L.tile_offset);
@@ -351,18 +351,27 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     unsigned* counters = (unsigned*)(geom + L.counters);
 
     StageTimer tm(st);
-    DGM_HIP(hipMemsetAsync(counters, 0, (8 + DGM_UCTL_WORDS) * sizeof(unsigned), st));  // (+ the replay units' control block)
+    // (no memset of the counter words -- 8 + the replay units' control block: count_tiles_kernel's first workgroup clears them, and
+    // nothing before it touches them)
 
     tm.begin(DGM_STAGE_PREPROCESS);
     launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
                           colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, gridx,
-                          gridy, prefiltered, radii, rec, depth, radii_int, tiles_touched, cov3D, clamped, block_sums,
-                          counters);
+                          gridy, prefiltered, radii, rec, depth, radii_int, tiles_touched, cov3D, clamped, block_sums);
     DGM_CHECK("preprocess_fwd");
-    const int nblk = (P + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
-    launch_scan_blocks(st, nblk, block_sums, block_offs, counters);
-    DGM_CHECK("scan_blocks");
     tm.end(DGM_STAGE_PREPROCESS);
+
+    // per-chunk tile histograms, then tile totals / starts / ranges / worklists and R = counters[0]: neither needs the binning
+    // buffer, so both run before the host learns R
+    tm.begin(DGM_STAGE_BIN_COUNT);
+    DGM_HIP(launch_count(st, P, L.chunk_size, L.n_chunks, tiles, gridx, tiles_touched, rec, block_sums, offs, hist, counters));
+    DGM_CHECK("count_tiles");
+    tm.end(DGM_STAGE_BIN_COUNT);
+
+    tm.begin(DGM_STAGE_BIN_SCAN);
+    launch_tile_scan(st, tiles, L.n_chunks, hist, tile_count, tile_offset, ranges, big_list, counters + 2, counters + 4, counters);
+    DGM_CHECK("tile_scan");
+    tm.end(DGM_STAGE_BIN_SCAN);
 
     // R is needed on the host to size the binning buffer (rasterizer_impl.cu:281 does the same read-back); the
     // "prefiltered but culled" flag of auxiliary.h:156-160 rides in the same 8-byte copy, so it is ALWAYS checked
@@ -386,21 +395,10 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     char* bin = binning_alloc(binning_ctx, L.binning_bytes);
     if (!bin) return fail("rasterize_forward: binning allocator returned NULL");
     bin = align_ptr(bin);
-    uint4* inst = (uint4*)(bin + L.inst);
+    uint2* inst = (uint2*)(bin + L.inst);
     unsigned* point_list = (unsigned*)(bin + L.point_list);
-    unsigned* upos = (unsigned*)(bin + L.upos);
     float4* ckpt = (float4*)(bin + L.ckpt);
     float4* ckpt64 = (float4*)(bin + L.ckpt64);
-
-    tm.begin(DGM_STAGE_BIN_COUNT);
-    DGM_HIP(launch_count(st, P, L.chunk_size, L.n_chunks, tiles, gridx, tiles_touched, rec, block_offs, offs, hist));
-    DGM_CHECK("count_tiles");
-    tm.end(DGM_STAGE_BIN_COUNT);
-
-    tm.begin(DGM_STAGE_BIN_SCAN);
-    launch_tile_scan(st, tiles, L.n_chunks, hist, tile_count, tile_offset, ranges, big_list, counters + 2, counters + 4);
-    DGM_CHECK("tile_scan");
-    tm.end(DGM_STAGE_BIN_SCAN);
 
     if (R > 0) {
         tm.begin(DGM_STAGE_BIN_SCATTER);
@@ -412,8 +410,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
         tm.begin(DGM_STAGE_TILE_SORT);
         // (segments beyond 4096 entries sort in global memory: their pair buffers are carved from the backward's row slab,
         // 36 bytes per entry -- they need 16 -- and idle during the forward pass)
-        DGM_HIP(launch_tile_sort(st, tiles, ranges, inst, (uint2*)(bin + L.slab), (size_t)R, point_list, upos, big_list,
-                                 counters + 2));
+        DGM_HIP(launch_tile_sort(st, tiles, ranges, inst, (uint2*)(bin + L.slab), (size_t)R, point_list, big_list, counters + 2));
         DGM_CHECK("tile_sort");
         tm.end(DGM_STAGE_TILE_SORT);
     }
@@ -476,7 +473,6 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
     const float* cov3D = (const float*)(geom + L.cov3D);
     const uint8_t* clamped = (const uint8_t*)(geom + L.clamped);
     const unsigned* point_list = (const unsigned*)(bin + L.point_list);
-    const unsigned* upos = (const unsigned*)(bin + L.upos);
     float* slab = (float*)(bin + L.slab);
     uint8_t* live = (uint8_t*)(bin + L.live);
     const unsigned* n_contrib = (const unsigned*)(img + L.n_contrib);
@@ -492,7 +488,7 @@ int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* bac
     StageTimer tm(st);
     tm.begin(DGM_STAGE_RENDER_BWD);
     launch_render_bwd4(st, tiles, (size_t)R, ranges, point_list, width, height, gridx, background, rec, cfin, ckpt, ckpt64,
-                       n_contrib, dL_dpix, upos, slab, live, (const unsigned*)(geom + L.counters) + 8, (const uint4*)(bin + L.ulist_full),
+                       n_contrib, dL_dpix, slab, live, (const unsigned*)(geom + L.counters) + 8, (const uint4*)(bin + L.ulist_full),
                        (const uint4*)(img + L.ulist_last));
     DGM_CHECK("render_bwd");
     tm.end(DGM_STAGE_RENDER_BWD);

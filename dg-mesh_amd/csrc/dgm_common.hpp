@@ -21,7 +21,9 @@
 #define DGM_UCTL_WORDS 64
 #define DGM_UCTL_LINE 32
 #define DGM_PRE_BLOCK 256    // Gaussians per preprocess workgroup (also the granularity of block_sums)
-#define DGM_BIN_THREADS 512  // threads of a binning chunk workgroup
+#define DGM_BIN_PASS 512      // Gaussians a binning chunk workgroup takes per pass (chunks are multiples of it)
+#define DGM_BIN_THREADS 1024  // its threads: a wave holds 32 Gaussians of the pass in its lower half (binning.hip: the wave walks its
+                              // Gaussians one by one, a serial chain -- 32 steps on sixteen waves instead of 64 on eight)
 #define DGM_MAX_CHUNKS 256   // chunk workgroups = rows of the per-chunk tile histogram
 #define DGM_MAX_GRID_DIM 1023  // tiles per axis that fit the 10-bit rect packing
 
@@ -39,9 +41,9 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     const size_t tiles = (size_t)tx * ty;
     const size_t Pz = (size_t)(P > 0 ? P : 0), Rz = (size_t)(R > 0 ? R : 0);
     const size_t nblk = (Pz + DGM_PRE_BLOCK - 1) / DGM_PRE_BLOCK;
-    // chunk = contiguous run of Gaussians owned by one binning workgroup; multiple of DGM_BIN_THREADS
+    // chunk = contiguous run of Gaussians owned by one binning workgroup; multiple of DGM_BIN_PASS
     size_t chunk = (Pz + DGM_MAX_CHUNKS - 1) / DGM_MAX_CHUNKS;
-    chunk = align_up(chunk ? chunk : 1, DGM_BIN_THREADS);
+    chunk = align_up(chunk ? chunk : 1, DGM_BIN_PASS);
     size_t nchunks = (Pz + chunk - 1) / chunk;
     if (nchunks == 0) nchunks = 1;
     L->tiles_x = tx;
@@ -62,7 +64,6 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->cov3D = take(Pz * 24);
     L->clamped = take(Pz);
     L->block_sums = take(nblk * 4);
-    L->block_offs = take(nblk * 4);
     L->hist = take(nchunks * tiles * 4);
     L->tile_count = take(tiles * 4);
     L->tile_offset = take((tiles + 1) * 4);
@@ -70,9 +71,8 @@ static inline void compute_layout(int P, int W, int H, int R, dgm_state_layout* 
     L->counters = take((8 + DGM_UCTL_WORDS) * 4);  // (the replay-unit control block rides behind them: one memset clears both)
     L->geometry_bytes = o + A;
     o = 0;
-    L->inst = take(Rz * 16);
+    L->inst = take(Rz * 8);
     L->point_list = take(Rz * 4);
-    L->upos = take(Rz * 4);
     L->slab = take(Rz * (DGM_SLAB_STRIDE * 4 > 16 ? DGM_SLAB_STRIDE * 4 : 16));  // (>= 16 B per entry: the tile sort's scratch)
     L->live = take(Rz + 8);  // (+8: flags are read eight at a time)
     L->ckpt = take((Rz / 256 + 1) * 256 * 16);  // per (tile, 256-entry round boundary): (T, C) of the tile's 256 pixels

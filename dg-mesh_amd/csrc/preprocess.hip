@@ -119,7 +119,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float tan_fovx, float tan_fovy, float focal_x, float focal_y, int gridx, int gridy,
                       int prefiltered, int* __restrict__ radii_out, float* __restrict__ rec, float* __restrict__ depth,
                       int* __restrict__ radii_int, unsigned* __restrict__ tiles_touched, float* __restrict__ cov3Ds,
-                      uint8_t* __restrict__ clamped, unsigned* __restrict__ block_sums, unsigned* __restrict__ counters) {
+                      uint8_t* __restrict__ clamped, unsigned* __restrict__ block_sums) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ unsigned wave_tot[DGM_PRE_BLOCK / 64];
     const int base = blockIdx.x * DGM_PRE_BLOCK;
@@ -132,6 +132,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     __syncthreads();
 
     unsigned my_tiles = 0;
+    bool culled_prefiltered = false;
     if (idx < P) {
         int my_radius_i = 0;
         unsigned rect = 0;
@@ -146,7 +147,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float vy = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
         const float vz = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
         bool alive = !(vz <= 0.2f);  // auxiliary.h:154
-        if (!alive && prefiltered) atomicOr(&counters[1], 1u);  // reference: printf + __trap (auxiliary.h:156-160)
+        culled_prefiltered = !alive && prefiltered;  // reference: printf + __trap (auxiliary.h:156-160); reported through block_sums' top bit
         if (alive) {
             const float hx = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
             const float hy = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
@@ -291,14 +292,17 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         clamped[idx] = clamp_bits;
     }
     // per-block sum of tiles_touched (first level of the exclusive scan over Gaussians)
+    // (bit 31: some Gaussian of the block was culled although the caller said prefiltered -- the count kernel gathers these into
+    // counters[1], so that no counter word has to be zero before this kernel runs; a block's sum stays below 2^31: 256 x 36 k tiles)
     unsigned s = wave_sum_u32(my_tiles);
+    if (__any(culled_prefiltered)) s |= 0x80000000u;
     if (lane_id() == 0) wave_tot[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned t = 0;
+        unsigned t = 0, bad = 0;
 #pragma unroll
-        for (int w = 0; w < DGM_PRE_BLOCK / 64; w++) t += wave_tot[w];
-        block_sums[blockIdx.x] = t;
+        for (int w = 0; w < DGM_PRE_BLOCK / 64; w++) t += wave_tot[w] & 0x7fffffffu, bad |= wave_tot[w] & 0x80000000u;
+        block_sums[blockIdx.x] = t | bad;
     }
 }
 
@@ -318,7 +322,7 @@ void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* mea
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                            int gridx, int gridy, int prefiltered, int* radii_out, float* rec, float* depth,
                            int* radii_int, unsigned* tiles_touched, float* cov3Ds, uint8_t* clamped,
-                           unsigned* block_sums, unsigned* counters) {
+                           unsigned* block_sums) {
     const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:222-223
     const float focal_x = W / (2.0f * tan_fovx);
     const int n_sh = (D + 1) * (D + 1);
@@ -329,7 +333,7 @@ void launch_preprocess_fwd(hipStream_t st, int P, int D, int M, const float* mea
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(DGM_PRE_BLOCK), lds_bytes, st, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp, colors_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gridx, gridy, prefiltered, radii_out, rec,
-                       depth, radii_int, tiles_touched, cov3Ds, clamped, block_sums, counters);
+                       depth, radii_int, tiles_touched, cov3Ds, clamped, block_sums);
 }
 
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* viewmatrix, uint8_t* present) {

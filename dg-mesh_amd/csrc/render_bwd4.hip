@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RB4_WAV
 render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
                    const float* __restrict__ bg, const float* __restrict__ rec, const float4* __restrict__ cfin,
                    const float4* __restrict__ ckpt, const float4* __restrict__ ckpt64, const unsigned* __restrict__ n_contrib,
-                   const float* __restrict__ dL_dpixels, const unsigned* __restrict__ upos, float* __restrict__ slab,
+                   const float* __restrict__ dL_dpixels, float* __restrict__ slab,
                    uint8_t* __restrict__ live, const int ntiles, const int ulog, const unsigned* __restrict__ uctl,
                    const uint4* __restrict__ ulist_full, const uint4* __restrict__ ulist_last) {
     // staged splats, 48 bytes each: x, y, conic a * -log2(e)/2, conic b * -log2(e) | conic c * -log2(e)/2, opacity, r, g | b
@@ -161,6 +161,7 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
     f2 bgd[2];         // bg . dL/dC (the last unit starts from T_final, S' = T_final (bg . dL/dC))
     unsigned lc_top = 0u, lc_bot = 0u;
     float pxf = 0.f, tx0 = 0.f, ty0 = 0.f;
+    unsigned tile_xu = 0u, tile_yu = 0u;
 
     // ---- this workgroup's unit (see above): x = id % 8, t = id / 8
     uint4 d;
@@ -189,8 +190,8 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
         const int seg_end = min(nproc, seg_begin + ulen);
         // hop 1 of the unit (with the pixel state below): the first batch's slice of the list
         const int pos0 = seg_end - 1 - lane;
-        unsigned g0 = 0u, row0 = 0u;
-        if (pos0 >= seg_begin) g0 = point_list[first + pos0], row0 = upos[first + pos0];
+        unsigned g0 = 0u;
+        if (pos0 >= seg_begin) g0 = point_list[first + pos0];
         // ... and the blend state at the unit's back end (the last unit starts from the final state, which is part of the pixel state)
         const bool from_ckpt = k != nunits - 1;
         float4 ck[4];
@@ -203,6 +204,7 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
         f2 Tf[2];
         {
             const int tile_x = tile % gridx, tile_y = tile / gridx;
+            tile_xu = (unsigned)tile_x, tile_yu = (unsigned)tile_y;
             const int px = tile_x * DGM_TILE + (lane & 15);
             const int pyb = tile_y * DGM_TILE + (lane >> 4);  // rows pyb + {0, 4, 8, 12}
             pxf = (float)px;
@@ -240,11 +242,10 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
             lc_bot = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(max(P[1].lc0, P[1].lc1)));
         }
         // hop 2: the first batch's splat records, together with the checkpoint
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-        float q2 = 0.f;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2v = q0;  // (q2v: colour b | rectangle | offs[g] | -)
         if (pos0 >= seg_begin) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g0 * DGM_REC_STRIDE);
-            q0 = r4[0], q1 = r4[1], q2 = r4[2].x;
+            q0 = r4[0], q1 = r4[1], q2v = r4[2];
         }
         // replay state at the back end of the unit
 #pragma unroll
@@ -260,6 +261,9 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                 P[h].S = Tf[h] * bgd[h];
             }
         }
+        // the first batch's gradient rows (the record is in by now: its loads were issued behind the checkpoint's)
+        const float q2 = q2v.x;
+        const unsigned row0 = instance_row(__float_as_uint(q2v.y), __float_as_uint(q2v.z), tile_xu, tile_yu);
         const int nb = (seg_end - seg_begin + 63) >> 6;
         for (int t = 0; t < nb; t++) {
             const int base_pos = seg_end - 1 - t * 64;  // list position staged by lane 0; lane l stages base_pos - l
@@ -271,9 +275,10 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
                 row = row0;
                 if (t != 0) {  // (256-entry units of the long lists: later batches are fetched as they come)
                     const unsigned g = point_list[first + pos];
-                    row = upos[first + pos];  // fetched with the splat: the dependent stores below do not wait for it
                     const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * DGM_REC_STRIDE);
-                    r0 = r4[0], r1 = r4[1], r2x = r4[2].x;
+                    const float4 r2 = r4[2];
+                    r0 = r4[0], r1 = r4[1], r2x = r2.x;
+                    row = instance_row(__float_as_uint(r2.y), __float_as_uint(r2.z), tile_xu, tile_yu);  // the instance's gradient row
                 }
                 const float l2e = 1.4426950408889634f;
                 sR[3 * lane] = make_float4(r0.x, r0.y, -0.5f * l2e * r0.z, -l2e * r0.w);
@@ -389,14 +394,14 @@ extern "C" int dgm_debug_rb4_trace(void* dst, size_t bytes, int reset) {
 
 void launch_render_bwd4(hipStream_t st, int tiles, size_t R, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
-                        const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, const unsigned* upos, float* slab,
+                        const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, float* slab,
                         uint8_t* live, const unsigned* uctl, const uint4* ulist_full, const uint4* ulist_last) {
     const int ulog = replay_unit_log2(R);
     // one workgroup per possible unit: at most R / u full units and one last unit per tile; XCD x's share of either list is at most
     // ceil(count / 8) long, so 8 (ceil(R / u / 8) + ceil(tiles / 8)) ids cover every (x, t)
     const size_t grid = 8 * ((((R >> ulog) + 7) >> 3) + (((size_t)tiles + 7) >> 3));
     hipLaunchKernelGGL(render_bwd4_kernel, dim3((unsigned)grid), dim3(64), 0, st, ranges, point_list, W, H, gridx, bg, rec, cfin, ckpt,
-                       ckpt64, n_contrib, dL_dpix, upos, slab, live, tiles, ulog, uctl, ulist_full, ulist_last);
+                       ckpt64, n_contrib, dL_dpix, slab, live, tiles, ulog, uctl, ulist_full, ulist_last);
 }
 
 }  // namespace dgm

@@ -61,6 +61,15 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float a, flo
     return m;
 }
 
+// offs[g] + k: the row of Gaussian g's instance on tile (tile_x, tile_y) in the per-Gaussian order -- k counts the tiles of its rectangle
+// row by row, as binning.hip's count / scatter walk them.  rect = rec[g][9] (pack_rect), offs = rec[g][10]: the backward gets both with
+// the third 16-byte load of the splat's record, so the (R x 4)-byte array rounds 2-4 carried through the tile sort is gone.
+__device__ __forceinline__ unsigned instance_row(unsigned rect, unsigned offs, unsigned tile_x, unsigned tile_y) {
+    unsigned xmin, ymin, w;
+    unpack_rect(rect, xmin, ymin, w);
+    return offs + (tile_y - ymin) * w + (tile_x - xmin);
+}
+
 // The same test for the two 16 x 8 half tiles (bit 0: rows 0..7, bit 1: rows 8..15): the backward's culling unit.
 __device__ __forceinline__ unsigned half_mask(float x, float y, float a, float b, float c, float o, float tx0, float ty0) {
     const float o255 = o * 255.0f;

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define DGM_ABI_VERSION 3
+#define DGM_ABI_VERSION 4
 
 /* Allocator callback: must return a device pointer to at least `bytes` bytes (128-byte aligned),
  * valid until the matching backward has run.  Mirrors resizeFunctional, rasterize_points.cu:27-33. */
@@ -122,8 +122,7 @@ typedef struct {
     size_t offs;          /* u32[P]     EXCLUSIVE scan of tiles_touched (reference stores the inclusive scan) */
     size_t cov3D;         /* float[P][6] */
     size_t clamped;       /* u8[P]      bit ch set = colour channel ch clamped at 0 */
-    size_t block_sums;    /* u32[ceil(P/256)] */
-    size_t block_offs;    /* u32[ceil(P/256)] */
+    size_t block_sums;    /* u32[ceil(P/256)] tiles touched per 256 Gaussians (preprocess -> the count kernel's offs) */
     size_t hist;          /* u32[n_chunks][tiles] */
     size_t tile_count;    /* u32[tiles] */
     size_t tile_offset;   /* u32[tiles+1] */
@@ -134,12 +133,14 @@ typedef struct {
                              listed (the backward's work list, written by the forward; one 128-byte line each) */
     size_t geometry_bytes;
     /* binning buffer */
-    size_t inst;       /* uint4[R] instance records (gaussian, depth bits, offs[g] + k, 0), grouped by tile, in arrival
-                          order within a tile (the tile sort's input) */
+    size_t inst;       /* uint2[R] instance records (gaussian, depth bits), grouped by tile, in arrival order within a tile
+                          (the tile sort's input) */
     size_t point_list; /* u32[R]  gaussian ids, by tile then depth then id: identical to the reference's */
-    size_t upos;       /* u32[R]  upos[slot] = offs[g] + k for the point_list entry at `slot`: g's k-th tile instance */
-    size_t slab;       /* float[R][9] per-instance gradient rows written by backward AT ROW upos[slot] (grouped by
-                          Gaussian, so the per-Gaussian sum reads them contiguously): colour r,g,b | moments of
+    size_t slab;       /* float[R][9] per-instance gradient rows written by backward AT ROW offs[g] + k for Gaussian g's k-th tile
+                          instance (k counts the tiles of g's rectangle row by row; rec[g][9] = packed rectangle, rec[g][10] =
+                          offs[g]: the backward forms the row from the record it loads anyway -- ABI <= 3 carried it in a
+                          u32[R] array `upos`).  Rows are therefore grouped by Gaussian and the per-Gaussian sum reads them
+                          contiguously: colour r,g,b | moments of
                           g = G dL/dalpha about the splat centre: dx, dy, dx^2, dx dy, dy^2, 1.  Only rows with live[row] != 0
                           are written */
     size_t live;       /* u8[R] live[row] = 1 iff some pixel blended the instance, i.e. slab[row] was written by this backward */

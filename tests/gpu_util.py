@@ -57,7 +57,16 @@ def hip_forward(a, debug=False):
     if n > 0:
         ulog = 5 if n < (1 << 20) else 6
         cap = (n >> ulog) + 1
-        out.update(point_list=view(binning, lay.point_list, np.uint32, n), upos=view(binning, lay.upos, np.uint32, n),
+        point_list = view(binning, lay.point_list, np.uint32, n)
+        # the gradient row of every list entry as render_bwd4 forms it (render_common.hpp instance_row): offs[g] + the position of the
+        # entry's tile in g's rectangle, row by row
+        tile_of = np.zeros(n, np.int64)
+        for tl, (a0, a1) in enumerate(out["ranges"]):
+            tile_of[a0:a1] = tl
+        rect = out["rect"][point_list].astype(np.int64)
+        xmin, ymin, w = rect & 1023, (rect >> 10) & 1023, rect >> 20
+        upos = out["rec_offs"][point_list].astype(np.int64) + (tile_of // lay.tiles_x - ymin) * w + (tile_of % lay.tiles_x - xmin)
+        out.update(point_list=point_list, upos=upos.astype(np.uint32),
                    ulist_full=view(binning, lay.ulist_full, np.uint32, cap * 4).reshape(cap, 4), unit_log2=ulog)
     else:
         out.update(point_list=np.zeros(0, np.uint32), upos=np.zeros(0, np.uint32))

@@ -402,6 +402,38 @@ def test_optional_inputs(orc, syn, variant):
     check_backward(orc, a, f_or, f_hip)
 
 
+def test_prefiltered_but_culled_is_reported(syn):
+    """auxiliary.h:154-160: with prefiltered set, a Gaussian behind the near plane makes the reference print and trap; here the forward
+    call fails with that message (the flag travels preprocess_fwd -> block sums' top bit -> count_tiles_kernel -> the R read-back),
+    and the same scene with prefiltered off renders."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H, P = 160, 112, 3000
+    a = raster_args(syn, P, W, H, seed=5, kind="aniso")
+    dev = "cuda"
+    means = np.array(a["means3D"], copy=True)
+    vm = np.asarray(a["viewmatrix"], np.float64).reshape(4, 4)  # row-vector convention: view z = m . vm[:3, 2] + vm[3, 2]
+    depth = means.astype(np.float64) @ vm[:3, 2] + vm[3, 2]
+    assert (depth > 0.2).all()
+    axis = vm[:3, 2] / np.dot(vm[:3, 2], vm[:3, 2])
+    means[P - 7] = (means[P - 7].astype(np.float64) - (depth[P - 7] + 1.0) * axis).astype(np.float32)  # one Gaussian to view z = -1
+
+    def run(prefiltered):
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=a["tanfovx"], tanfovy=a["tanfovy"], bg=torch.tensor(a["bg"], device=dev),
+            scale_modifier=1.0, viewmatrix=torch.tensor(a["viewmatrix"], device=dev),
+            projmatrix=torch.tensor(a["projmatrix"], device=dev), sh_degree=3, campos=torch.tensor(a["campos"], device=dev),
+            prefiltered=prefiltered, debug=False)
+        t = lambda k: torch.tensor(a[k], device=dev)
+        return GaussianRasterizer(raster_settings=rs)(
+            means3D=torch.tensor(means, device=dev), means2D=torch.zeros(P, 3, device=dev), shs=t("sh"), colors_precomp=None,
+            opacities=t("opacities"), scales=t("scales"), rotations=t("rotations"), cov3D_precomp=None)
+
+    img, radii = run(False)
+    assert int(radii[P - 7]) == 0 and bool(torch.isfinite(img).all())
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        run(True)
+
+
 def test_module_api_autograd(orc, syn):
     """The nn.Module / autograd.Function surface: same call as R/gaussian_renderer/__init__.py:66-114."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer

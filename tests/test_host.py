@@ -25,7 +25,7 @@ def test_build_and_exports():
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dgm_abi_version() == 3
+    assert lib.dgm_abi_version() == 4
     names = [lib.dgm_stage_name(i).decode() for i in range(L.STAGE_COUNT)]
     assert names[0] == "preprocess_fwd" and names[7] == "preprocess_bwd" and names[-2] == "mlp_layer_dw" and names[-1] == "mlp_bwd_pair"
 
@@ -40,12 +40,12 @@ def test_state_layout_is_pure_and_aligned():
         assert getattr(a, f) == getattr(b, f)
     assert (a.tiles_x, a.tiles_y) == (50, 50)
     assert a.n_chunks * a.chunk_size >= 100000 and a.chunk_size % 512 == 0 and a.n_chunks <= 256
-    offs = [a.rec, a.depth, a.radii, a.tiles_touched, a.offs, a.cov3D, a.clamped, a.block_sums, a.block_offs, a.hist,
+    offs = [a.rec, a.depth, a.radii, a.tiles_touched, a.offs, a.cov3D, a.clamped, a.block_sums, a.hist,
             a.tile_count, a.tile_offset, a.big_list, a.counters]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert a.depth - a.rec >= 100000 * 48
     assert a.geometry_bytes == lib.dgm_geometry_bytes(100000, 800, 800)
-    assert a.binning_bytes == lib.dgm_binning_bytes(2780000) and a.binning_bytes >= 2780000 * (8 + 4 + 4 + 48)
+    assert a.binning_bytes == lib.dgm_binning_bytes(2780000) and a.binning_bytes >= 2780000 * (8 + 4 + 36 + 1)
     assert a.image_bytes == lib.dgm_image_bytes(800, 800)
     # geometry / image sizes must not depend on R (backward re-derives them)
     assert lib.dgm_describe_state(100000, 800, 800, 5, ctypes.byref(b)) == 0
