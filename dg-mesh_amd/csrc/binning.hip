@@ -327,14 +327,15 @@ __device__ __forceinline__ unsigned radix_varying_bits(const unsigned (&key)[RS_
 
 // Lanes of the wave that hold the same 8-bit digit as this one (among the `valid` lanes), as the two halves of a 64-bit mask: per bit
 // one ballot and m &= (bit set ? ballot : ~ballot) = m & ~(ballot ^ x) with x = 0 / -1 the sign-extended bit -- ONE v_bitop3_b32 per
-// half (truth table 0x90 over (m, ballot, x)), 5 instructions per bit; the select form (`bs ? bb : ~bb`) compiled to 9.
+// half (truth table 0x90 over (m, ballot, x)), 4 instructions per bit; the select form (`bs ? bb : ~bb`) compiled to 9.
 __device__ __forceinline__ void match_digit(unsigned d, bool valid, unsigned& m_lo, unsigned& m_hi) {
     const unsigned long long mv = __ballot(valid);
     m_lo = (unsigned)mv, m_hi = (unsigned)(mv >> 32);
 #pragma unroll
     for (int bit = 0; bit < 8; bit++) {
         const int x = __builtin_amdgcn_sbfe((int)d, bit, 1);
-        const unsigned long long bb = __ballot(x != 0);
+        unsigned long long bb;  // = __ballot(x != 0), as the compare of x itself (the compiler shifts d again for its own: +1 per bit)
+        asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(bb) : "v"(x));
         m_lo = __builtin_amdgcn_bitop3_b32(m_lo, (unsigned)bb, (unsigned)x, 0x90);
         m_hi = __builtin_amdgcn_bitop3_b32(m_hi, (unsigned)(bb >> 32), (unsigned)x, 0x90);
     }
@@ -363,6 +364,12 @@ __device__ __forceinline__ void radix_passes(unsigned (&key)[RS_MAXB], unsigned 
                 unsigned m_lo, m_hi;
                 match_digit(d, valid, m_lo, m_hi);
                 const unsigned rk = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+                // every lane of a digit group reads the wave's counter (one address: a broadcast), THEN the group's first lane
+                // advances it -- a wave's LDS operations execute in order, so no lane sees the update (first version: only the
+                // first lane read, and ds_bpermute handed its value round: a find-first-set pair and one more LDS operation a batch)
+                // (tried: every lane of the group reads the counter -- one address, a broadcast -- and the first lane then advances it,
+                // which needs neither the find-first-set pair nor the ds_bpermute: 47.5 -> 54.4 us at cfg2.  Sixty-four lanes on the
+                // counters' banks cost more than the ~40 group leaders plus the permute.)
                 unsigned old = 0u;
                 if (valid && rk == 0u) {  // first lane of its digit group
                     old = cnt[wv][d];
@@ -695,7 +702,7 @@ __device__ __forceinline__ bool msd_first_sort(int n, unsigned rx, const uint2* 
 }
 
 __global__ void __launch_bounds__(1024)
-tile_sort_radix_big_kernel(int tiles, const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
+tile_sort_radix_big_kernel(const unsigned* __restrict__ big_list, const unsigned* __restrict__ big_count,
                            const uint2* __restrict__ ranges, const uint2* __restrict__ inst, uint2* __restrict__ pairs, size_t R,
                            unsigned* __restrict__ point_list) {
     constexpr int WAVES = 16;
@@ -703,17 +710,6 @@ tile_sort_radix_big_kernel(int tiles, const unsigned* __restrict__ big_list, con
     __shared__ __attribute__((aligned(16))) unsigned cnt[WAVES][256];  // ping-pong in LDS, longer ones in global memory
     __shared__ unsigned s_red[2];
     __shared__ __attribute__((aligned(16))) unsigned dstart[260];
-#ifndef DGM_MID_LAUNCH
-    // the "mid" worklist first (kRadixCap + 1 .. kSmallCap entries, from the END of big_list): pairs in registers, four per thread
-    // on sixteen waves, exchanged through the front of the pair buffer
-    {
-        const unsigned mids = big_count[1];
-        for (unsigned w = blockIdx.x; w < mids; w += gridDim.x) {
-            radix_sort_tile<WAVES, 4>(ranges[big_list[tiles - 1 - (int)w]], inst, point_list, lds_pairs, cnt, s_red);
-            __syncthreads();
-        }
-    }
-#endif
     const unsigned count = *big_count;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
         const uint2 r = ranges[big_list[w]];
@@ -831,28 +827,34 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
 }
 
 hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, const uint2* inst, uint2* pairs, size_t R,
-                            unsigned* point_list, const unsigned* big_list, const unsigned* big_count) {
-    static_assert(kSmallCap == 8 * 64 * 8 && kSmallCap == 16 * 64 * 4, "the mid worklist's sorts cover segments up to kSmallCap");
+                            unsigned* point_list, const unsigned* big_list, const unsigned* big_count, unsigned n_big, unsigned n_mid) {
+    static_assert(kSmallCap == 8 * 64 * 8, "tile_sort_radix_mid_kernel covers segments up to kSmallCap");
+    // n_big / n_mid: the lengths of the two worklists, which the host reads back together with R (tile_scan_kernel has built them
+    // by then).  Rounds 2-4 launched all three classes on every frame with fixed grids -- an empty worklist cost a 5 us launch, and
+    // both are empty on most frames of a trained scene.
     // (tried: the mid worklist and the one-tile-per-workgroup class in ONE launch of 512-thread workgroups, short segments on eight
     // waves with four pairs a thread, so that the mid class's 32 us would run beside the short class: 84 -> 97-100 us at cfg2 --
-    // eight waves pay twice the counter scan and barrier population for a 2048-entry segment)
-    // (tried in round 5: hipExtAnyOrderLaunch on the second and third launch -- packets without the barrier bit, so that the three
-    // classes, which sort disjoint tiles, run side by side.  The runtime ignores the flag on gfx9: the gap between the scatter's end and
-    // render_fwd's start stayed at 77-78 us = the sum of the three kernels, `tools/chain_wall.py`.)
-#ifdef DGM_MID_LAUNCH  // (rounds 2-4: the mid worklist as a launch of its own, 768 x 512 threads, eight pairs per thread)
-    hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(768), dim3(512), 0, st, tiles, big_list, big_count + 1, ranges, inst, point_list);
-#endif
+    // eight waves pay twice the counter scan and barrier population for a 2048-entry segment.  Round 5: the mid worklist inside the
+    // big launch, sixteen waves x four pairs per tile -- 3.6 us less with a few dozen mid tiles, 3.4 us more with a few hundred, which
+    // 256 workgroups of 145 KB LDS take in turns.  Also round 5: hipExtAnyOrderLaunch on the second and third launch -- packets without
+    // the barrier bit, so that the classes, which sort disjoint tiles, run side by side.  The runtime ignores the flag on gfx9: the gap
+    // between the scatter's end and render_fwd's start stayed at the sum of the three kernels, `tools/chain_wall.py`.)
+    if (n_mid > 0u)
+        hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(n_mid < 768u ? n_mid : 768u), dim3(512), 0, st, tiles, big_list, big_count + 1,
+                           ranges, inst, point_list);
     hipLaunchKernelGGL(tile_sort_radix_kernel, dim3(tiles), dim3(256), 0, st, ranges, inst, point_list);
-    static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
-    bool& attr_set = attr_set_dev[current_device_slot()];
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tile_sort_radix_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * kBigLds * 8);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    if (n_big > 0u) {
+        static bool attr_set_dev[DGM_MAX_DEVICES] = {false};  // function attributes are per device
+        bool& attr_set = attr_set_dev[current_device_slot()];
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)tile_sort_radix_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               2 * kBigLds * 8);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tile_sort_radix_big_kernel, dim3(n_big < 256u ? n_big : 256u), dim3(1024), 2 * kBigLds * 8, st, big_list, big_count,
+                           ranges, inst, pairs, R, point_list);
     }
-    hipLaunchKernelGGL(tile_sort_radix_big_kernel, dim3(256), dim3(1024), 2 * kBigLds * 8, st, tiles, big_list, big_count, ranges, inst, pairs,
-                       R, point_list);
     return hipSuccess;
 }
 

@@ -37,7 +37,7 @@ hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int til
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, uint2* inst);
 hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, const uint2* inst, uint2* pairs, size_t R,
-                            unsigned* point_list, const unsigned* big_list, const unsigned* big_count);
+                            unsigned* point_list, const unsigned* big_list, const unsigned* big_count, unsigned n_big, unsigned n_mid);
 // render.hip
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
@@ -374,16 +374,17 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     tm.end(DGM_STAGE_BIN_SCAN);
 
     // R is needed on the host to size the binning buffer (rasterizer_impl.cu:281 does the same read-back); the
-    // "prefiltered but culled" flag of auxiliary.h:156-160 rides in the same 8-byte copy, so it is ALWAYS checked
+    // "prefiltered but culled" flag of auxiliary.h:156-160 rides in the same 16-byte copy, so it is ALWAYS checked
     // (the reference traps the kernel unconditionally), not only with debug on.
     // (into PINNED host memory, one small buffer per calling thread: a copy to pageable memory is staged through the runtime's
     // own bounce buffer and costs the GPU a longer idle gap per frame.  Tried on top and not kept: the scan kernel mailing
     // {R, flags, sequence number} into host-mapped memory with the host polling it -- +0.6 % at cfg2, -3 % at the host-bound cfg1)
     static thread_local unsigned* pinned_words = nullptr;
     if (!pinned_words && hipHostMalloc((void**)&pinned_words, 64, hipHostMallocDefault) != hipSuccess) pinned_words = nullptr;
-    unsigned stack_words[2] = {0, 0};
+    unsigned stack_words[4] = {0, 0, 0, 0};
     unsigned* host_words = pinned_words ? pinned_words : stack_words;
-    DGM_HIP(hipMemcpyAsync(host_words, counters, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    // (R, flags, and the lengths of the tile sort's "big" and "mid" worklists: empty ones are not launched)
+    DGM_HIP(hipMemcpyAsync(host_words, counters, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     DGM_HIP(hipStreamSynchronize(st));
     const unsigned R_host = host_words[0];
     if (R_host > 0x7fffffffu) return fail("rasterize_forward: %u tile instances overflow int", R_host);
@@ -410,7 +411,8 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
         tm.begin(DGM_STAGE_TILE_SORT);
         // (segments beyond 4096 entries sort in global memory: their pair buffers are carved from the backward's row slab,
         // 36 bytes per entry -- they need 16 -- and idle during the forward pass)
-        DGM_HIP(launch_tile_sort(st, tiles, ranges, inst, (uint2*)(bin + L.slab), (size_t)R, point_list, big_list, counters + 2));
+        DGM_HIP(launch_tile_sort(st, tiles, ranges, inst, (uint2*)(bin + L.slab), (size_t)R, point_list, big_list, counters + 2,
+                                 host_words[2], host_words[3]));
         DGM_CHECK("tile_sort");
         tm.end(DGM_STAGE_TILE_SORT);
     }

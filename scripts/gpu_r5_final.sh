@@ -19,7 +19,7 @@ print('pre_bwd', d['kernels'].get('preprocess_bwd'))
 PY
 ( cd /tmp && DGM_BENCH_STEADY_STEPS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof" -o b -- python "$GRAFT_REPO_ROOT/bench.py" --steps 200 --warmup 20 --no-extras --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.log" 2>&1 )
 f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1); python tools/prof_summary.py $f 1 50 > gpurun_out/${TAG}_bench_kernel_stats.txt; head -30 gpurun_out/${TAG}_bench_kernel_stats.txt | cut -c1-120; find gpurun_out/${TAG}_prof -name "*kernel_trace.csv" -delete
-for w in cfg1 cfg5; do
+for w in cfg1 cfg4 cfg5; do
   timeout 600 python bench.py --workload $w --steps 40 --warmup 10 --no-extras --no-cpu-baseline > gpurun_out/${TAG}_bench_$w.json 2>/dev/null
   python -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_$w.json')); print('$w', round(d['value'],1), 'it/s', round(d['ms_per_step'],3), 'ms', d['host_ms_per_step'])"
 done
