@@ -388,7 +388,11 @@ def main():
 
     if world > 1:
         tr.exchange_events = []
+    dev_allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     elapsed, stages, blocked_s, pkg = timed(args.steps, it0 + args.warmup)
+    # hipMalloc calls of torch's caching allocator inside the timed region: 0 at steady state; a scene whose R keeps setting new
+    # maxima (cfg4 under the random targets) pays one multi-GB allocation per new size of the binning buffer
+    dev_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - dev_allocs0
     dp = None
     if world > 1:
         # Self-verification of the data-parallel run: every rank must hold bit-identical parameters and Adam moments after the
@@ -604,7 +608,8 @@ def main():
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
             # host side: time blocked in the rasterizer forward (its R read-back is the step's only sync) vs busy
             "host_ms_per_step": {"blocked_on_gpu": round(1e3 * blocked_s / args.steps, 3),
-                                 "busy": round(1e3 * (elapsed - blocked_s) / args.steps, 3)},
+                                 "busy": round(1e3 * (elapsed - blocked_s) / args.steps, 3),
+                                 "device_allocations_in_timed_region": int(dev_allocs)},
         }
         out["rccl_world_size"] = dist.get_world_size() if world > 1 else 1
         if dp is not None:
