@@ -241,50 +241,60 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
     if (threadIdx.x == 0) tile_offset[tiles] = run_total, *total = run_total;  // (R: the host reads it back to size the binning buffer)
 }
 
+// Workgroup b = 8 * chunk + x runs on XCD x = b % 8 and emits the instances of its chunk that fall on the x-th BAND of tile rows.
+// Why bands: a record is 8 bytes and successive records of one 128-byte line arrive a good fraction of the kernel apart; with a
+// workgroup per chunk writing to all tiles (rounds 1-5a) an XCD's L2 had ~60 k lines open at a time, 7.7 MB against its 4 MB, and
+// every record left for memory as a partial sector of its own -- `profiles/r05_pmc_scatter.json`: 113 MB written for 24 MB of records.
+// A band keeps the open lines of an L2 to (chunks) x (tiles of the band) and every line is completed in the one L2 that
+// holds it.  Price: each chunk is walked by eight workgroups, each skipping the Gaussians whose rectangle misses its band (the
+// skip is decided per lane before the walk and costs the walk nothing).
 __global__ void __launch_bounds__(DGM_BIN_THREADS)
-scatter_kernel(int P, int chunk, int nchunks, int tiles, int gridx, const unsigned* __restrict__ tiles_touched,
+scatter_kernel(int P, int chunk, int tiles, int gridx, int gridy, const unsigned* __restrict__ tiles_touched,
                const float* __restrict__ rec, const float* __restrict__ depth, const unsigned* __restrict__ hist,
                const unsigned* __restrict__ tile_offset, uint2* __restrict__ inst) {
-    extern __shared__ __attribute__((aligned(16))) unsigned cursor[];
-    // Workgroup b runs on XCD b % 8, and the chunks' shares of a tile's segment lie one behind the other (67 bytes each on average at
-    // cfg2): XCD x takes the x-th eighth of the chunks, so that the lines of its part of every segment fill up in ONE L2 instead of
-    // being written back in pieces by two or three.
-    const int per_xcd = (nchunks + 7) >> 3;
-    const int chunk_id = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    if (chunk_id >= nchunks) return;
-    const unsigned* row = hist + (size_t)chunk_id * tiles;
-    for (int t = threadIdx.x; t < tiles; t += DGM_BIN_THREADS) cursor[t] = tile_offset[t] + row[t];
+    extern __shared__ __attribute__((aligned(16))) unsigned cursor[];  // the band's tiles only
+    const int chunk_id = (int)(blockIdx.x >> 3);
+    const int rows_per = (gridy + 7) >> 3;
+    const int ty0 = (int)(blockIdx.x & 7u) * rows_per, ty1 = min(gridy, ty0 + rows_per);
+    if (ty0 >= ty1) return;
+    const int t0 = ty0 * gridx, nt = (ty1 - ty0) * gridx;
+    const unsigned* row = hist + (size_t)chunk_id * tiles + t0;
+    for (int t = threadIdx.x; t < nt; t += DGM_BIN_THREADS) cursor[t] = tile_offset[t0 + t] + row[t];
     __syncthreads();
     const int g0 = chunk_id * chunk, g1 = min(P, g0 + chunk);
+    const int lane = lane_id();
     for (int base = g0; base < g1; base += DGM_BIN_PASS) {
-        const int g = base + (int)(threadIdx.x >> 6) * 32 + (int)(threadIdx.x & 31u);  // (as in count_tiles_kernel)
+        const int gw = base + (int)(threadIdx.x >> 6) * 32;  // this wave's 32 Gaussians, in its lower half (as in count_tiles_kernel)
+        const int g = gw + (lane & 31);
         unsigned tt = 0u, rect = 0u, dbits = 0u;
-        if ((threadIdx.x & 32u) == 0u && g < g1) {
+        if (lane < 32 && g < g1) {
             tt = tiles_touched[g];
             rect = __float_as_uint(rec[(size_t)g * DGM_REC_STRIDE + 9]);
             dbits = __float_as_uint(depth[g]);
         }
-        unsigned long long m = __ballot(tt != 0u);
+        // the part of the rectangle inside the band: rows [ya, yb), n_l tiles; geo_l = width | xmin << 12 | (ya - ty0) << 22
+        unsigned xmin, ymin, w;
+        unpack_rect(rect, xmin, ymin, w);
         const unsigned magic_l = rect_magic(rect);
+        const unsigned h = w > 1 ? __umulhi(tt, magic_l) : tt;  // tt = w * h
+        const int ya = max((int)ymin, ty0), yb = min((int)(ymin + h), ty1);
+        const unsigned n_l = (tt != 0u && yb > ya) ? (unsigned)(yb - ya) * w : 0u;
+        const unsigned geo_l = w | (xmin << 12) | ((unsigned)(ya - ty0) << 22);
+        unsigned long long m = __ballot(n_l != 0u);
         while (m) {
             const int src = __builtin_ctzll(m);
             m &= m - 1;
-            const unsigned tt_i = __builtin_amdgcn_readlane(tt, src);
-            const unsigned rect_i = __builtin_amdgcn_readlane(rect, src);
+            const unsigned n_i = __builtin_amdgcn_readlane(n_l, src);
+            const unsigned geo = __builtin_amdgcn_readlane(geo_l, src);
             const unsigned d_i = __builtin_amdgcn_readlane(dbits, src);
-            const unsigned g_i = (unsigned)__builtin_amdgcn_readlane(g, src);
             const unsigned magic = __builtin_amdgcn_readlane(magic_l, src);
-            unsigned xmin, ymin, w;
-            unpack_rect(rect_i, xmin, ymin, w);
-            for (unsigned k = lane_id(); k < tt_i; k += 64) {
-                const unsigned y = w > 1 ? __umulhi(k, magic) : k;
-                const unsigned x = k - y * w;
-                const unsigned tile = (ymin + y) * (unsigned)gridx + xmin + x;
-                const unsigned slot = atomicAdd(&cursor[tile], 1u);
-                // one 8-byte store: Gaussian and depth bits (the sort key: depth, then Gaussian).  The kernel is bound by these
-                // scattered writes (rounds 2-4, 16-byte records: 100 MB at the memory for 66 MB of records at cfg2 -- lines leave L2
-                // partly written)
-                inst[slot] = make_uint2(g_i, d_i);
+            const unsigned g_i = (unsigned)(gw + src);
+            const unsigned w_i = geo & 4095u, x_i = (geo >> 12) & 1023u, y_i = geo >> 22;
+            for (unsigned k = lane; k < n_i; k += 64) {
+                const unsigned y = w_i > 1 ? __umulhi(k, magic) : k;
+                const unsigned x = k - y * w_i;
+                const unsigned slot = atomicAdd(&cursor[(y_i + y) * (unsigned)gridx + x_i + x], 1u);
+                inst[slot] = make_uint2(g_i, d_i);  // one 8-byte store: Gaussian and depth bits (the sort key: depth, then Gaussian)
             }
         }
     }
@@ -812,17 +822,12 @@ void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, un
                        tile_offset, ranges, big_list, big_count, arrive, total);
 }
 
-hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx,
+hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx, int gridy,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, uint2* inst) {
-    const size_t lds = (size_t)tiles * 4;
-    if (lds > 48 * 1024) {
-        hipError_t e =
-            hipFuncSetAttribute((const void*)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(scatter_kernel, dim3(8 * ((nchunks + 7) / 8)), dim3(DGM_BIN_THREADS), lds, st, P, chunk, nchunks, tiles, gridx,
-                       tiles_touched, rec, depth, hist, tile_offset, inst);
+    const size_t lds = (size_t)((gridy + 7) / 8) * gridx * 4;  // cursors of one band of tile rows (<= 18 KB at the 36 k-tile limit)
+    hipLaunchKernelGGL(scatter_kernel, dim3(8 * nchunks), dim3(DGM_BIN_THREADS), lds, st, P, chunk, tiles, gridx, gridy, tiles_touched,
+                       rec, depth, hist, tile_offset, inst);
     return hipSuccess;
 }
 
