@@ -241,7 +241,8 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
     if (threadIdx.x == 0) tile_offset[tiles] = run_total, *total = run_total;  // (R: the host reads it back to size the binning buffer)
 }
 
-// Workgroup b = 8 * chunk + x runs on XCD x = b % 8 and emits the instances of its chunk that fall on the x-th BAND of tile rows.
+// Workgroup b = 8 * chunk + x runs on XCD x = b % 8 and emits the instances of its chunk that fall on the x-th BAND of tile rows
+// (dense frames; nbands = 8).
 // Why bands: a record is 8 bytes and successive records of one 128-byte line arrive a good fraction of the kernel apart; with a
 // workgroup per chunk writing to all tiles (rounds 1-5a) an XCD's L2 had ~60 k lines open at a time, 7.7 MB against its 4 MB, and
 // every record left for memory as a partial sector of its own -- `profiles/r05_pmc_scatter.json`: 113 MB written for 24 MB of records.
@@ -249,13 +250,15 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
 // holds it.  Price: each chunk is walked by eight workgroups, each skipping the Gaussians whose rectangle misses its band (the
 // skip is decided per lane before the walk and costs the walk nothing).
 __global__ void __launch_bounds__(DGM_BIN_THREADS)
-scatter_kernel(int P, int chunk, int tiles, int gridx, int gridy, const unsigned* __restrict__ tiles_touched,
+scatter_kernel(int P, int chunk, int nbands, int tiles, int gridx, int gridy, const unsigned* __restrict__ tiles_touched,
                const float* __restrict__ rec, const float* __restrict__ depth, const unsigned* __restrict__ hist,
                const unsigned* __restrict__ tile_offset, uint2* __restrict__ inst) {
     extern __shared__ __attribute__((aligned(16))) unsigned cursor[];  // the band's tiles only
-    const int chunk_id = (int)(blockIdx.x >> 3);
-    const int rows_per = (gridy + 7) >> 3;
-    const int ty0 = (int)(blockIdx.x & 7u) * rows_per, ty1 = min(gridy, ty0 + rows_per);
+    // (nbands = 8, or 1 on sparse frames -- R < 2^20 -- where the lines are few enough to stay in L2 anyway and eight walks per chunk
+    // cost more than they save: 18.9 vs 23.0 us on the trained-like scene)
+    const int chunk_id = (int)blockIdx.x / nbands, band = (int)blockIdx.x - chunk_id * nbands;
+    const int rows_per = (gridy + nbands - 1) / nbands;
+    const int ty0 = band * rows_per, ty1 = min(gridy, ty0 + rows_per);
     if (ty0 >= ty1) return;
     const int t0 = ty0 * gridx, nt = (ty1 - ty0) * gridx;
     const unsigned* row = hist + (size_t)chunk_id * tiles + t0;
@@ -317,6 +320,18 @@ scatter_kernel(int P, int chunk, int tiles, int gridx, int gridy, const unsigned
 // (WAVES, RS_MAXB pairs per thread) = (4, 8): 256 threads, segments up to 2048 entries, one workgroup per tile at 65 VGPRs
 // (sixteen pairs per thread cost 248); (8, 8): 512 threads, up to 4096 entries, the tiles of the device-built "mid"
 // worklist -- a long segment is spread over more waves instead of more registers.
+// OR / AND over the wave (DPP, dgm_common.hpp), then lane 63 merges the pair into the two LDS words
+__device__ __forceinline__ unsigned dgm_op_or(unsigned a, unsigned b) { return a | b; }
+__device__ __forceinline__ unsigned dgm_op_and(unsigned a, unsigned b) { return a & b; }
+__device__ __forceinline__ void wave_or_and_to(unsigned vo, unsigned va, unsigned* s_red) {
+    DGM_DPP_SCAN(dgm_op_or, vo, 0u)
+    DGM_DPP_SCAN(dgm_op_and, va, 0xFFFFFFFFu)
+    if ((threadIdx.x & 63) == 63) {
+        atomicOr(&s_red[0], vo);
+        atomicAnd(&s_red[1], va);
+    }
+}
+
 // bits in which the keys of the segment differ (workgroup-wide OR / AND through two LDS words)
 template <int RS_MAXB>
 __device__ __forceinline__ unsigned radix_varying_bits(const unsigned (&key)[RS_MAXB], int n, int nb, int w0, unsigned* s_red) {
@@ -327,8 +342,7 @@ __device__ __forceinline__ unsigned radix_varying_bits(const unsigned (&key)[RS_
 #pragma unroll
     for (int b = 0; b < RS_MAXB; b++)
         if (b < nb && w0 + b * 64 + lane < n) vo |= key[b], va &= key[b];
-    atomicOr(&s_red[0], vo);
-    atomicAnd(&s_red[1], va);
+    wave_or_and_to(vo, va, s_red);  // (one LDS atomic pair per wave: 256 threads on two words serialise)
     __syncthreads();
     const unsigned v = s_red[0] ^ s_red[1];
     __syncthreads();  // (s_red is reused)
@@ -633,8 +647,7 @@ __device__ __forceinline__ unsigned varying_bits_global(const uint2* __restrict_
     unsigned vo = 0u, va = 0xFFFFFFFFu;
 #pragma unroll 4
     for (int i = threadIdx.x; i < n; i += WAVES * 64) vo |= src[i].x, va &= src[i].x;
-    atomicOr(&s_red[0], vo);
-    atomicAnd(&s_red[1], va);
+    wave_or_and_to(vo, va, s_red);
     __syncthreads();
     const unsigned v = s_red[0] ^ s_red[1];
     __syncthreads();
@@ -822,12 +835,17 @@ void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, un
                        tile_offset, ranges, big_list, big_count, arrive, total);
 }
 
-hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx, int gridy,
+hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx, int gridy, size_t R,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, uint2* inst) {
-    const size_t lds = (size_t)((gridy + 7) / 8) * gridx * 4;  // cursors of one band of tile rows (<= 18 KB at the 36 k-tile limit)
-    hipLaunchKernelGGL(scatter_kernel, dim3(8 * nchunks), dim3(DGM_BIN_THREADS), lds, st, P, chunk, tiles, gridx, gridy, tiles_touched,
-                       rec, depth, hist, tile_offset, inst);
+    const int nbands = R < DGM_FINE_UNITS_BELOW ? 1 : 8;
+    const size_t lds = (size_t)((gridy + nbands - 1) / nbands) * gridx * 4;  // cursors of one band of tile rows
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(scatter_kernel, dim3(nbands * nchunks), dim3(DGM_BIN_THREADS), lds, st, P, chunk, nbands, tiles, gridx, gridy,
+                       tiles_touched, rec, depth, hist, tile_offset, inst);
     return hipSuccess;
 }
 

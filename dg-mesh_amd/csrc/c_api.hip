@@ -33,7 +33,7 @@ hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles
 void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
                       unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive,
                       unsigned* total);
-hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx, int gridy,
+hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx, int gridy, size_t R,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, uint2* inst);
 hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, const uint2* inst, uint2* pairs, size_t R,
@@ -403,7 +403,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
 
     if (R > 0) {
         tm.begin(DGM_STAGE_BIN_SCATTER);
-        DGM_HIP(launch_scatter(st, P, L.chunk_size, L.n_chunks, tiles, gridx, gridy, tiles_touched, rec, depth, hist,
+        DGM_HIP(launch_scatter(st, P, L.chunk_size, L.n_chunks, tiles, gridx, gridy, (size_t)R, tiles_touched, rec, depth, hist,
                                tile_offset, inst));
         DGM_CHECK("scatter");
         tm.end(DGM_STAGE_BIN_SCATTER);

@@ -144,27 +144,32 @@ typedef unsigned long long dgm_u64u __attribute__((aligned(1)));
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // wave-wide inclusive scan / sum through ds_bpermute-free shuffles (light kernels only)
+// Wave-wide scans / reductions on the DPP data path (VALU rate): a Hillis-Steele scan inside each row of 16 lanes (row_shr 1, 2, 4,
+// 8; lanes without a source add the identity), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast15), then lane 31 into the
+// upper half (row_bcast31) -- six instructions.  (Rounds 1-5a: six dependent __shfl_up / __shfl_xor steps, each a ds_bpermute
+// through the LDS crossbar -- ~700 cycles per scan, on the critical path of the tile sort's counter scan in every pass, the binning
+// kernels' offsets and the backward's unit prologue.)  All 64 lanes must be active.
+#define DGM_DPP_STEP(OP, v, ident, ctrl, rmask) OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)(ident), (int)(v), ctrl, rmask, 0xf, false))
+#define DGM_DPP_SCAN(OP, v, ident)                 \
+    v = DGM_DPP_STEP(OP, v, ident, 0x111, 0xf); /* row_shr:1 */  \
+    v = DGM_DPP_STEP(OP, v, ident, 0x112, 0xf); /* row_shr:2 */  \
+    v = DGM_DPP_STEP(OP, v, ident, 0x114, 0xf); /* row_shr:4 */  \
+    v = DGM_DPP_STEP(OP, v, ident, 0x118, 0xf); /* row_shr:8 */  \
+    v = DGM_DPP_STEP(OP, v, ident, 0x142, 0xa); /* row_bcast:15 -> rows 1, 3 */ \
+    v = DGM_DPP_STEP(OP, v, ident, 0x143, 0xc); /* row_bcast:31 -> rows 2, 3 */
+__device__ __forceinline__ unsigned dgm_op_add(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned dgm_op_max(unsigned a, unsigned b) { return a > b ? a : b; }
 __device__ __forceinline__ unsigned wave_inclusive_scan_u32(unsigned v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
-    }
+    DGM_DPP_SCAN(dgm_op_add, v, 0u)
     return v;
 }
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {  // (in every lane)
+    DGM_DPP_SCAN(dgm_op_add, v, 0u)
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        unsigned o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {  // (in every lane)
+    DGM_DPP_SCAN(dgm_op_max, v, 0u)
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 #endif  // __HIPCC__
