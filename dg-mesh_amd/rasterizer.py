@@ -59,15 +59,16 @@ def _stream():
 
 
 def _bucket(nbytes):
-    """Sizes above 1 MiB rounded up to m * 2^k with m in 8..15 (at most 12.5 % more), above 256 MiB to the next power of two.  The
+    """Sizes above 1 MiB rounded up to m * 2^k with m in 8..15 (at most 12.5 % more), above 2 GiB to the next power of two.  The
     binning buffer follows R, which differs from frame to frame and creeps upwards while the scene densifies or its splats grow:
     with exact sizes nearly every new maximum misses torch's caching allocator (a cached block serves smaller requests only) and
-    costs a hipMalloc -- of several GB at cfg4 on a scene inflating under the bench's random targets, where the old blocks also
-    pile up in the cache.  With a few sizes per octave (one, where a block is large) the same blocks come round again."""
+    costs a hipMalloc, which takes ~25 ms per GiB here.  With a few sizes per octave the same blocks come round again; where a
+    block is several GiB (cfg4 on a scene inflating under the bench's random targets: 13 GB) one size per octave keeps the bytes
+    allocated over a period of growth at twice the final size instead of nine times."""
     n = int(nbytes)
     if n <= (1 << 20):
         return n
-    if n > (1 << 28):
+    if n > (1 << 31):
         return 1 << (n - 1).bit_length()
     k = n.bit_length() - 4
     return ((n + (1 << k) - 1) >> k) << k
