@@ -216,3 +216,20 @@ def test_pack_heads_keeps_the_module_and_makes_the_heads_adjacent():
     with torch.no_grad():
         heads[2].weight.add_(1.0)
     assert torch.equal(M._stacked([m.weight for m in heads], (n_out, 256)), torch.cat([m.weight for m in heads], 0))
+
+
+def test_binning_buffer_sizes_are_bucketed():
+    """rasterizer._bucket: exact up to 1 MiB, then m * 2^k with m in 8..15 (<= 12.5 % more), one size per octave above 2 GiB; monotone,
+    never below the request -- the binning buffer's size follows R and must not miss the caching allocator at every new maximum."""
+    R = pkg("rasterizer")
+    assert [R._bucket(n) for n in (0, 1, 4096, 1 << 20)] == [0, 1, 4096, 1 << 20]
+    last = 0
+    for n in list(range((1 << 20) + 1, 1 << 22, 65537)) + [10 ** 8, 5 * 10 ** 8, (1 << 31), (1 << 31) + 1, 13 * 10 ** 9]:
+        b = R._bucket(n)
+        assert b >= n and b >= last
+        last = b
+        if n <= (1 << 31):
+            assert b <= n * 1.125 + 1 and (b >> (b.bit_length() - 4)) << (b.bit_length() - 4) == b
+        else:
+            assert b & (b - 1) == 0 and b < 2 * n
+    assert len({R._bucket(n) for n in range(400 * 10 ** 6, 500 * 10 ** 6, 10 ** 6)}) <= 4
