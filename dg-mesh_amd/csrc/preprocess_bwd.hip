@@ -46,52 +46,32 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
     const int L = 3 * M;            // full row: gradients of unused coefficients are written as zeros
     const int stride = L | 1;
 
-    // ---- gather: this Gaussian's gradient rows, summed ---------------------------------------------------------------------
-    // Gaussian g owns slab rows offs[g] .. offs[g] + tiles_touched[g] - 1 and their liveness bytes: one thread walks them eight at
-    // a time -- ONE 8-byte load for the flags, then 16-byte loads for the rows render_bwd wrote (a row whose flag is 0 holds stale
-    // bytes and is never read), summed in ascending order (fixed order => reproducible).
-    // Measured at cfg2 (3.0 M rows, about half of them dead), same kernel otherwise: this form 0.084 ms; flags read as eight
-    // byte loads 0.106; every row read and dead ones dropped by a select 0.118; 48-byte aligned rows with the dead ones written
-    // as zeros (round 3's form, no flags) 0.069 in round 3's library and 0.110 here with the flag loads added; the workgroup's
-    // row span streamed through LDS in 1024-row chunks (coalesced, nine loads in flight) 0.126 -- only ~34 of the 256 threads
-    // own rows of a given chunk.  The kernel is bound by the number of load instructions whose lanes touch 64 different
-    // cache lines, so the byte loads of the flags cost as much as the rows' 16-byte loads.
-    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (idx < P && radii[idx] > 0) {
-        const unsigned n = tiles_touched[idx];
-        const size_t first = offs[idx];
-        const uint8_t* fl = live + first;
-        const float* row = slab + first * DGM_SLAB_STRIDE;
-        // eight flags in ONE load (byte-aligned 8-byte access; up to 7 bytes past the Gaussian's own flags, inside the array's padding);
-        // the next eight are asked for before this batch's rows, so that a batch costs one dependent round trip, not two
-        unsigned long long f8_next = n ? *reinterpret_cast<const dgm_u64u*>(fl) : 0ull;
-        for (unsigned k0 = 0; k0 < n; k0 += 8) {
-            const unsigned long long f8 = f8_next;
-            if (k0 + 8 < n) f8_next = *reinterpret_cast<const dgm_u64u*>(fl + k0 + 8);
-            bool on[8];
+    // ---- everything that does not depend on the gather is asked for FIRST: the Gaussian's own inputs (used after the barrier) and
+    // the SH block's staging loads.  Round 1-5a order -- gather, then staging, barrier, then the inputs -- made five dependent
+    // memory round trips out of what is three (sizes and offsets -> flags -> rows): the kernel is one round of workgroups, 1.5 waves
+    // per SIMD, so its time is the length of that chain.
+    float4 in_r0 = make_float4(0.f, 0.f, 0.f, 0.f), in_r1 = in_r0, in_rot = in_r0;
+    float in_m[3] = {0.f, 0.f, 0.f}, in_c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, in_s[3] = {0.f, 0.f, 0.f};
+    int in_radius = 0;
+    unsigned in_n = 0u, in_first = 0u;
+    uint8_t in_cl = 0;
+    if (idx < P) {
+        in_radius = radii[idx];
+        in_n = tiles_touched[idx];
+        in_first = offs[idx];
+        in_r0 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[0];
+        in_r1 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[1];
 #pragma unroll
-            for (int j = 0; j < 8; j++) on[j] = k0 + j < n && ((f8 >> (8 * j)) & 0xffull) != 0;
-            float r[8][9];
+        for (int i = 0; i < 3; i++) in_m[i] = means3D[3 * idx + i];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+        for (int i = 0; i < 6; i++) in_c3[i] = cov3Ds[6 * idx + i];
+        in_cl = clamped[idx];
+        if (scales != nullptr) {
 #pragma unroll
-                for (int i = 0; i < 9; i++) r[j][i] = 0.f;
-                if (on[j]) {
-                    const float* rp = row + (size_t)(k0 + j) * DGM_SLAB_STRIDE;
-                    const dgm_f4u a0 = *reinterpret_cast<const dgm_f4u*>(rp), a1 = *reinterpret_cast<const dgm_f4u*>(rp + 4);
-                    r[j][0] = a0.x, r[j][1] = a0.y, r[j][2] = a0.z, r[j][3] = a0.w;
-                    r[j][4] = a1.x, r[j][5] = a1.y, r[j][6] = a1.z, r[j][7] = a1.w;
-                    r[j][8] = rp[8];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) acc[i] += r[j][i];
-            }
+            for (int i = 0; i < 3; i++) in_s[i] = scales[3 * idx + i];
+            in_rot = make_float4(rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2], rotations[4 * idx + 3]);
         }
     }
-
     if (use_sh) {
         // stage the whole (cnt, M, 3) block, coalesced
         const int total = cnt * L;
@@ -140,18 +120,63 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
             }
         }
     }
+    // ---- gather: this Gaussian's gradient rows, summed ---------------------------------------------------------------------
+    // Gaussian g owns slab rows offs[g] .. offs[g] + tiles_touched[g] - 1 and their liveness bytes: one thread walks them eight at
+    // a time -- ONE 8-byte load for the flags, then 16-byte loads for the rows render_bwd wrote (a row whose flag is 0 holds stale
+    // bytes and is never read), summed in ascending order (fixed order => reproducible).
+    // Measured at cfg2 (3.0 M rows, about half of them dead), same kernel otherwise: this form 0.084 ms; flags read as eight
+    // byte loads 0.106; every row read and dead ones dropped by a select 0.118; 48-byte aligned rows with the dead ones written
+    // as zeros (round 3's form, no flags) 0.069 in round 3's library and 0.110 here with the flag loads added; the workgroup's
+    // row span streamed through LDS in 1024-row chunks (coalesced, nine loads in flight) 0.126 -- only ~34 of the 256 threads
+    // own rows of a given chunk.  The kernel is bound by the number of load instructions whose lanes touch 64 different
+    // cache lines, so the byte loads of the flags cost as much as the rows' 16-byte loads.
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (idx < P && in_radius > 0) {
+        const unsigned n = in_n;
+        const size_t first = in_first;
+        const uint8_t* fl = live + first;
+        const float* row = slab + first * DGM_SLAB_STRIDE;
+        // eight flags in ONE load (byte-aligned 8-byte access; up to 7 bytes past the Gaussian's own flags, inside the array's padding);
+        // the next eight are asked for before this batch's rows, so that a batch costs one dependent round trip, not two
+        unsigned long long f8_next = n ? *reinterpret_cast<const dgm_u64u*>(fl) : 0ull;
+        for (unsigned k0 = 0; k0 < n; k0 += 8) {
+            const unsigned long long f8 = f8_next;
+            if (k0 + 8 < n) f8_next = *reinterpret_cast<const dgm_u64u*>(fl + k0 + 8);
+            bool on[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) on[j] = k0 + j < n && ((f8 >> (8 * j)) & 0xffull) != 0;
+            float r[8][9];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) r[j][i] = 0.f;
+                if (on[j]) {
+                    const float* rp = row + (size_t)(k0 + j) * DGM_SLAB_STRIDE;
+                    const dgm_f4u a0 = *reinterpret_cast<const dgm_f4u*>(rp), a1 = *reinterpret_cast<const dgm_f4u*>(rp + 4);
+                    r[j][0] = a0.x, r[j][1] = a0.y, r[j][2] = a0.z, r[j][3] = a0.w;
+                    r[j][4] = a1.x, r[j][5] = a1.y, r[j][6] = a1.z, r[j][7] = a1.w;
+                    r[j][8] = rp[8];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) acc[i] += r[j][i];
+            }
+        }
+    }
+
     __syncthreads();
 
     if (idx < P) {
-        const bool vis = radii[idx] > 0;
+        const bool vis = in_radius > 0;
         if (vis) {
             // render_bwd4 rows hold colour sums and the moments of g = G dL/dalpha about the splat centre
             // (d = xy - pixel): acc[3..8] = sum g dx, g dy, g dx^2, g dx dy, g dy^2, g.  The gradients of
             // backward.cu:536-554 are linear in them with per-Gaussian coefficients (dL/dG = opacity dL/dalpha):
             //   dL/dmean2D = -o (a Mx + b My) W/2,  -o (c My + b Mx) H/2        (dG/ddel = -G (a dx + b dy), ...)
             //   dL/dconic  = -o/2 (Mxx, Mxy, Myy),   dL/dopacity = M0
-            const float4 r0 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[0];
-            const float4 r1 = reinterpret_cast<const float4*>(rec + (size_t)idx * DGM_REC_STRIDE)[1];
+            const float4 r0 = in_r0, r1 = in_r1;
             const float ca = r0.z, cb = r0.w, cc = r1.x, op = r1.y;
             const float mx = acc[3], my = acc[4];
             acc[3] = -op * (ca * mx + cb * my) * (0.5f * W);
@@ -176,12 +201,12 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
         float drot[4] = {0.f, 0.f, 0.f, 0.f};
         float* my_sh = lds + threadIdx.x * stride;
         if (vis) {
-            const float m0 = means3D[3 * idx], m1 = means3D[3 * idx + 1], m2 = means3D[3 * idx + 2];
+            const float m0 = in_m[0], m1 = in_m[1], m2 = in_m[2];
             // ---- computeCov2DCUDA (backward.cu:144-274) ----
             {
                 float c3[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) c3[i] = cov3Ds[6 * idx + i];
+                for (int i = 0; i < 6; i++) c3[i] = in_c3[i];
                 float t0 = vm[0] * m0 + vm[4] * m1 + vm[8] * m2 + vm[12];
                 float t1 = vm[1] * m0 + vm[5] * m1 + vm[9] * m2 + vm[13];
                 const float t2 = vm[2] * m0 + vm[6] * m1 + vm[10] * m2 + vm[14];
@@ -268,7 +293,7 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
                 const float d0 = m0 - campos[0], d1 = m1 - campos[1], d2 = m2 - campos[2];
                 const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
                 const float x = d0 / len, y = d1 / len, z = d2 / len;
-                const uint8_t cl = clamped[idx];
+                const uint8_t cl = in_cl;
                 float dRGB[3] = {(cl & 1) ? 0.f : acc[0], (cl & 2) ? 0.f : acc[1], (cl & 4) ? 0.f : acc[2]};
                 float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
                 float Bk[16];
@@ -350,8 +375,7 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
             }
             // ---- cov3D -> scale / rotation (backward.cu:278-341) ----
             if (scales != nullptr) {
-                const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2],
-                            z = rotations[4 * idx + 3];
+                const float r = in_rot.x, x = in_rot.y, y = in_rot.z, z = in_rot.w;
                 float Rm[3][3];
                 Rm[0][0] = 1.f - 2.f * (y * y + z * z);
                 Rm[1][0] = 2.f * (x * y - r * z);
@@ -362,8 +386,7 @@ preprocess_bwd_kernel(int P, int D, int M, int gridx, const float* __restrict__ 
                 Rm[0][2] = 2.f * (x * z - r * y);
                 Rm[1][2] = 2.f * (y * z + r * x);
                 Rm[2][2] = 1.f - 2.f * (x * x + y * y);
-                const float s[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
-                                    scale_modifier * scales[3 * idx + 2]};
+                const float s[3] = {scale_modifier * in_s[0], scale_modifier * in_s[1], scale_modifier * in_s[2]};
                 const float Dm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
                                         {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
                                         {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
