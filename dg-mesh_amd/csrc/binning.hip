@@ -861,7 +861,10 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, cons
     // big launch, sixteen waves x four pairs per tile -- 3.6 us less with a few dozen mid tiles, 3.4 us more with a few hundred, which
     // 256 workgroups of 145 KB LDS take in turns.  Also round 5: hipExtAnyOrderLaunch on the second and third launch -- packets without
     // the barrier bit, so that the classes, which sort disjoint tiles, run side by side.  The runtime ignores the flag on gfx9: the gap
-    // between the scatter's end and render_fwd's start stayed at the sum of the three kernels, `tools/chain_wall.py`.)
+    // between the scatter's end and render_fwd's start stayed at the sum of the three kernels, `tools/chain_wall.py`.  And: ONE launch
+    // of 512-thread workgroups in which a short segment keeps waves 0-3 with the code below unchanged (the others leave at once) and a
+    // long one all eight, its keys and payloads crossing the 16 KB exchange buffer one after the other -- 64.6 us against 31.7 + 24.9
+    // late in the bench: 100 registers and eight wave slots per workgroup at dispatch thin out the short class.)
     if (n_mid > 0u)
         hipLaunchKernelGGL(tile_sort_radix_mid_kernel, dim3(n_mid < 768u ? n_mid : 768u), dim3(512), 0, st, tiles, big_list, big_count + 1,
                            ranges, inst, point_list);
