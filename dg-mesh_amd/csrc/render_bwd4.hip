@@ -171,6 +171,8 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
         const unsigned x = blockIdx.x & 7u, t = blockIdx.x >> 3;
         if (t >= per_f + per_l) return;
         const bool is_last = t >= per_f;
+        // (measured: consecutive units on consecutive XCDs -- u = 8 t + x -- instead of an eighth of the list per XCD: 0.0658 against
+        // 0.0632 ms on the trained-like scene, 0.2764 against 0.2739 on the initial one; a Gaussian's rows then fill up in eight L2s)
         const unsigned u = is_last ? x * per_l + (t - per_f) : x * per_f + t;
         if (u >= (is_last ? nl : nf)) return;
         d = is_last ? ulist_last[u] : ulist_full[u];
