@@ -924,6 +924,9 @@ struct Dw4Cfg {
     static constexpr int LDS = 2 * (XU + GU) * 16;
 };
 
+// (round 5, measured and not kept: a second register set so that the loads of TWO tiles are in flight -- for the stand-alone
+// launches, the embedding rows' gradient <3, 8> and the heads' <8, 1>, whose 18 / 6 MFMAs per tile hide little: 36.9 -> 36.4 us and
+// 31.0 -> 31.6 us.  Their 3.3-3.8 TB/s is not one outstanding round trip per workgroup.)
 template <int MT, int NT, int XROWB, int XPLANEB, int GROWB, int GPLANEB>
 __device__ __forceinline__ void dw4_body(const Dw4Args& a, const int chunk, unsigned char* smem) {
     using Cfg = Dw4Cfg<MT, NT, XROWB, XPLANEB, GROWB, GPLANEB>;
