@@ -1097,6 +1097,8 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     }
     // (tried: the previous layer's partial tiles summed by the GEMM workgroups of the next paired launch, before their weight
     // prologue: the launch grows by 9 us (87 -> 96), six launches, while this reduction only shrinks 87 -> 52 us: a net loss)
+    // (tried, round 5: each layer's tiles summed by a launch of its own right behind the layer's paired launch, while they are still
+    // in the 256 MB MALL -- nine launches of 23 us against this one of 89: a single layer's 256 workgroups do not fill the chip)
     // (tried: each layer's reduction on a side stream under the next layer's launch -- its small workgroups do fit beside a
     // resident pair workgroup -- 265 vs 274 it/s: slower, the pair kernel's HBM-bound half gets the competition)
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
