@@ -233,3 +233,12 @@ def test_binning_buffer_sizes_are_bucketed():
         else:
             assert b & (b - 1) == 0 and b < 2 * n
     assert len({R._bucket(n) for n in range(400 * 10 ** 6, 500 * 10 ** 6, 10 ** 6)}) <= 4
+
+
+def test_graft_entry_build_checks_the_current_abi():
+    """__graft_entry__.build() must accept exactly the library it builds (it once pinned a literal ABI number)."""
+    import re
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "lib.ABI_VERSION" in src and not re.search(r"dgm_abi_version\(\)\s*==\s*\d", src)
+    hdr = open(os.path.join(ROOT, "include", "dgmesh_hip.h")).read()
+    assert int(re.search(r"#define DGM_ABI_VERSION (\d+)", hdr).group(1)) == pkg("_lib").ABI_VERSION
