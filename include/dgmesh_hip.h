@@ -47,6 +47,10 @@
 extern "C" {
 #endif
 
+/* ABI history (a binding must check dgm_abi_version() against the header it was generated from):
+ *   3: dgm_knn_mean_dist2 takes a caller-owned scratch buffer (dgm_knn_scratch_bytes); two replay-unit lists in dgm_state_layout.
+ *   4: dgm_state_layout lost `upos` and `block_offs`, `inst` became uint2[R] (8-byte instance records; the backward forms the
+ *      gradient row of an instance itself); dgm_laplace_* added.  Entry points' signatures are unchanged from 3. */
 #define DGM_ABI_VERSION 4
 
 /* Allocator callback: must return a device pointer to at least `bytes` bytes (128-byte aligned),
