@@ -21,6 +21,13 @@
 
 namespace dgm {
 
+#ifndef RF_TRACE
+#define RF_TRACE 0  // 1: every wave records (start, first blend, end, hardware id, entries staged / tested / rounds): tools/raster_bench.py --trace-fwd
+#endif
+#if RF_TRACE
+__device__ unsigned long long rf_trace[4 * 65536 + 1];
+#endif
+
 template <bool SPARSE>
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
@@ -46,6 +53,11 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int rounds = (n + 255) >> 8;
+#if RF_TRACE
+    const unsigned long long tr_t0 = __builtin_readcyclecounter(), tr_w0 = wall_clock64();
+    unsigned long long tr_t_first = 0;
+    unsigned tr_tested = 0;
+#endif
     // liveness bytes of the backward's per-instance gradient rows (render_bwd4.hip sets the ones it writes): the tiles' list
     // ranges partition the row index space, so each tile clears a stretch as long as its list
     for (int i = threadIdx.x; i < n; i += 256) live[range.x + i] = 0;
@@ -140,6 +152,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
             // waiting out each instruction's latency; the blends themselves stay in list order.  (Odd counts: the last entry is
             // evaluated twice and blended once.)
             while (m) {
+#if RF_TRACE
+                if (tr_t_first == 0) tr_t_first = __builtin_readcyclecounter();
+                tr_tested += (unsigned)__popcll(m) >= 2u ? 2u : 1u;
+#endif
                 const int ja = (sw << 6) + __builtin_ctzll(m);
                 m &= m - 1;
                 const bool two = m != 0ull;
@@ -234,7 +250,31 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
         out_color[plane + pid] = C1 + T * bg[1];
         out_color[2 * plane + pid] = C2 + T * bg[2];
     }
+#if RF_TRACE
+    if (lane == 0) {
+        const unsigned long long tr_t1 = __builtin_readcyclecounter(), tr_w1 = wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        const unsigned long long i = atomicAdd(&rf_trace[4 * 65536], 1ull) & 65535ull;
+        // start / end on the constant 100 MHz clock; | xcc, hw id | duration (shader cycles) << 32, cycles before the first blend | list
+        // length << 32, entries this wave tested << 8, wave
+        rf_trace[4 * i] = (tr_w0 & ((1ull << 48) - 1ull)) | ((tr_w1 - tr_w0) << 48);
+        rf_trace[4 * i + 1] = ((unsigned long long)xcc << 32) | hw;
+        rf_trace[4 * i + 2] = ((tr_t1 - tr_t0) << 32) | ((tr_t_first ? tr_t_first - tr_t0 : 0ull) & 0xffffffffull);
+        rf_trace[4 * i + 3] = ((unsigned long long)(unsigned)n << 32) | ((unsigned long long)tr_tested << 8) | (unsigned)wv;
+    }
+#endif
 }
+#if RF_TRACE
+}  // namespace dgm
+extern "C" int dgm_debug_rf_trace(void* dst, size_t bytes, int reset) {
+    int e = (int)hipDeviceSynchronize();
+    if (!e) e = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dgm::rf_trace), bytes);
+    unsigned long long z = 0;
+    if (!e && reset) e = (int)hipMemcpyToSymbol(HIP_SYMBOL(dgm::rf_trace), &z, 8, 4 * 65536 * 8);
+    return e;
+}
+namespace dgm {
+#endif
 
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--kind", default="init")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--profile", type=int, default=1)
+    ap.add_argument("--trace-fwd", action="store_true", help="per-wave timeline of render_fwd (needs a library built with -DRF_TRACE=1)")
     ap.add_argument("--trace", action="store_true", help="per-wave timeline of render_bwd4 (needs a library built with -DRB4_TRACE=1)")
     ap.add_argument("--hist", action="store_true", help="tile-list length / replay-bound statistics of the frame")
     args = ap.parse_args()
@@ -80,6 +81,43 @@ def main():
     res.update(cfg=args.cfg, kind=args.kind, P=P, W=W, H=H, R=int(n), vis=float((radii > 0).float().mean()),
                meanT=float(0))
     print(json.dumps(res), flush=True)
+    if args.trace_fwd:
+        import ctypes
+        fn = L.lib().dgm_debug_rf_trace
+        fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int], ctypes.c_int
+        buf = np.zeros(4 * 65536 + 1, np.uint64)
+        fn(buf.ctypes.data, buf.nbytes, 1)
+        R._C.rasterize_gaussians(bg, means3D, e, opac, scales, rots, 1.0, e, vm, pm, tanx, tany, H, W, sh, 3, campos, False, False)
+        fn(buf.ctypes.data, buf.nbytes, 0)
+        cnt = min(int(buf[-1]), 65536)
+        t = buf[:4 * cnt].reshape(cnt, 4)
+        w0 = (t[:, 0] & ((1 << 48) - 1)).astype(np.int64)
+        wd = (t[:, 0] >> 48).astype(np.int64)                       # lifetime on the 100 MHz clock
+        hw, xcc = (t[:, 1] & 0xffffffff).astype(np.int64), (t[:, 1] >> 32).astype(np.int64) & 15
+        dur, first = (t[:, 2] >> 32).astype(np.int64), (t[:, 2] & 0xffffffff).astype(np.int64)
+        nlist, tested = (t[:, 3] >> 32).astype(np.int64), ((t[:, 3] >> 8) & 0xffffff).astype(np.int64)
+        base = w0.min()
+        us = lambda v: round(float(v) * 0.01, 2)
+        pc = lambda v, ps=(10, 50, 90, 100): [int(np.percentile(v, p)) for p in ps]
+        print("fwd waves", cnt, "| kernel span", us((w0 + wd).max() - base), "us | starts p50/p90/p99/max", [us(np.percentile(w0 - base, p)) for p in (50, 90, 99, 100)],
+              "| ends p10/p50/p90", [us(np.percentile(w0 + wd - base, p)) for p in (10, 50, 90)])
+        print("wave lifetime us p10/p50/p90/max", [us(np.percentile(wd, p)) for p in (10, 50, 90, 100)], "| shader cycles p10/p50/p90/max", pc(dur),
+              "| cycles before the first blend p10/p50/p90/max", pc(first[first > 0]) if (first > 0).any() else None)
+        print("list length p10/p50/p90/max", pc(nlist), "| entries a wave tested p10/p50/p90/max", pc(tested),
+              "| cycles per tested entry (after the first blend) p10/p50/p90", pc(((dur - first)[tested > 8] / tested[tested > 8]), (10, 50, 90)) if (tested > 8).any() else None)
+        simd, cu, sh_, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+        key = (((xcc * 8 + se) * 2 + sh_) * 16 + cu) * 4 + simd
+        uniq, inv = np.unique(key, return_inverse=True)
+        per = np.bincount(inv)
+        work = np.bincount(inv, weights=tested)
+        endt = np.zeros(len(uniq)); np.maximum.at(endt, inv, w0 + wd - base)
+        print("SIMDs", len(uniq), "| waves per SIMD p10/p50/p90/max", pc(per), "| tested entries per SIMD p10/p50/p90/max", pc(work),
+              "| last end per SIMD (us) p10/p50/p90/max", [us(np.percentile(endt, p)) for p in (10, 50, 90, 100)],
+              "| corr(end, work)", round(float(np.corrcoef(endt, work)[0, 1]), 3))
+        order = np.argsort(w0)
+        late = order[-max(1, cnt // 20):]
+        print("the last 5 % of the waves to start: list length p50", int(np.median(nlist[late])), "tested p50", int(np.median(tested[late])),
+              "lifetime us p50", us(np.median(wd[late])), "| first 5 %: list length p50", int(np.median(nlist[order[:max(1, cnt // 20)]])))
     if args.trace:
         import ctypes
         fn = L.lib().dgm_debug_rb4_trace
