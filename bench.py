@@ -54,6 +54,7 @@ MFMA_FP32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32
 MFMA_16BIT_PEAK_TF = 2500.0  # dense f16 / bf16 MFMA
 STEADY_STEPS = int(os.environ.get("DGM_BENCH_STEADY_STEPS", "200"))
 WORKLOAD = "cfg2"
+TARGETS = "teacher"  # --targets: "teacher" (renders of a perturbed copy of the scene: stationary R) | "noise" (rounds 1-5)
 
 
 def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase="gs", dpsr_res=288, n_verts=60000, densify=False):
@@ -73,9 +74,22 @@ def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase=
     with torch.no_grad():
         g._features_rest.add_(0.05 * torch.randn(g._features_rest.shape, device=dev, generator=gen))
     g.active_sh_degree = 3
-    gts = [torch.tensor(syn.gt_image(W, H, seed=i), device=dev) for i in range(n_gt)]
-    cams = [S.TorchCamera(syn.config_camera(WORKLOAD, frame=f, n_frames=n_frames), dev, gts[f % n_gt])
-            for f in range(n_frames)]
+    cams = [S.TorchCamera(syn.config_camera(WORKLOAD, frame=f, n_frames=n_frames), dev) for f in range(n_frames)]
+    bg = torch.tensor([1.0, 1.0, 1.0] if c["white_bg"] else [0.0, 0.0, 0.0], device=dev)
+    if TARGETS == "teacher":
+        # every frame's target = that camera's render of a perturbed copy of the scene (synthetic.TEACHER): the loss has a
+        # reachable optimum with the student's own footprint statistics, so R is stationary over the run
+        tgen = torch.Generator(device=dev)
+        tgen.manual_seed(syn.TEACHER["seed"] + seed)
+        teacher = syn.teacher_torch(S.GaussianModel, g, tgen)
+        with torch.no_grad():
+            for cam in cams:
+                cam.original_image = S.render(cam, teacher, S.PipelineParams(), bg, 0.0, 0.0, 0.0)["render"].detach().clamp(0.0, 1.0).clone()
+        del teacher
+    else:  # "noise": rounds 1-5's smoothed-noise targets (the optimiser inflates the splats under them; kept for comparison)
+        gts = [torch.tensor(syn.gt_image(W, H, seed=i), device=dev) for i in range(n_gt)]
+        for f, cam in enumerate(cams):
+            cam.original_image = gts[f % n_gt].clamp(0.0, 1.0)
     torch.manual_seed(seed)
     deform = D.DeformModelNormal(is_blender=c["is_blender"], model_name="deform", device=dev, trunk_impl=mlp_impl)
     deform_back = D.DeformModelNormal(is_blender=c["is_blender"], model_name="deform_back", device=dev, trunk_impl=mlp_impl)
@@ -87,7 +101,6 @@ def build_scene(dev, rank, world, mlp_impl, n_frames=200, n_gt=4, seed=0, phase=
             for head in (m.gaussian_warp, m.gaussian_rotation, m.gaussian_scaling, m.gaussian_normal):
                 head.weight.mul_(0.01)
                 head.bias.mul_(0.01)
-    bg = torch.tensor([1.0, 1.0, 1.0] if c["white_bg"] else [0.0, 0.0, 0.0], device=dev)
     mesh = None
     if phase == "mesh":
         # mesh co-training phase (R/train.py:165-176, 243-285): the two normal networks on the P Gaussians, DPSR on the deformed
@@ -156,14 +169,25 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None):
     xyz0 = ((np.random.RandomState(0).rand(P, 3) * 2 - 1) * 1.3).astype(np.float32)  # the points build_scene() draws
     g = syn.make_gaussians(P, seed=0, dist2=orc.knn(xyz0))  # same initialisation as create_from_pcd (simple-knn scales)
     cam = syn.config_camera(WORKLOAD, frame=0)
-    gt = torch.tensor(syn.gt_image(W, H, 0))
+    tanx, tany = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    white = bool(syn.CONFIGS[WORKLOAD]["white_bg"])
+    bg = np.ones(3, np.float32) if white else np.zeros(3, np.float32)
+    orc.lib()
+    if TARGETS == "teacher":  # the same recipe as build_scene(): frame 0's target = the oracle's render of the perturbed copy
+        at = syn.activate(syn.teacher_np(g))
+        ft = orc.forward(bg, at["means3D"], None, at["opacities"], at["scales"], at["rotations"], 1.0, None, cam.world_view_transform,
+                         cam.full_proj_transform, tanx, tany, H, W, at["shs"], 3, cam.camera_center)
+        gt = torch.tensor(np.clip(ft["color"], 0.0, 1.0))
+    else:
+        gt = torch.tensor(syn.gt_image(W, H, 0))
     torch.manual_seed(0)
     ref = reference_host_modules()
+    is_blender = bool(syn.CONFIGS[WORKLOAD]["is_blender"])
     if ref is not None:
-        nets = [ref[0].DeformNetworkNormal(is_blender=True) for _ in range(2)]
+        nets = [ref[0].DeformNetworkNormal(is_blender=is_blender) for _ in range(2)]
         l1_loss, ssim = ref[1].l1_loss, ref[1].ssim
     else:
-        nets = [D.DeformNetworkNormal(is_blender=True, trunk_impl="torch") for _ in range(2)]
+        nets = [D.DeformNetworkNormal(is_blender=is_blender, trunk_impl="torch") for _ in range(2)]
         l1_loss, ssim = S.l1_loss, S.ssim
     with torch.no_grad():  # same small-deformation heads as the GPU workload (build_scene), so R is comparable
         for m in nets:
@@ -174,9 +198,6 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None):
     opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15)
     xyz = torch.tensor(g["xyz"])
     t_in = torch.tensor([[0.3]]).expand(P, -1)
-    tanx, tany = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
-    bg = np.ones(3, np.float32)
-    orc.lib()
 
     def one_step():
         for p in params:
@@ -211,9 +232,10 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None):
     return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": kind,
             "sample": f"{n_steps} full {WORKLOAD} train steps ({W}x{H}, P={P}, R={f['num_rendered']}): oracle rasterizer "
                       f"fwd+bwd (C/OpenMP; the reference has no CPU rasterizer) + {what} + torch.optim.Adam on PyTorch-CPU, "
-                      f"{dt:.1f} s each.  Inputs are NOT identical to the GPU headline's: fresh networks and frame 0 here "
-                      f"(R={f['num_rendered']}), the headline's scene after its warm-up Adam steps"
-                      + (f" (R={headline_R})" if headline_R else "")}
+                      f"{dt:.1f} s each.  Same workload recipe as the GPU headline (teacher-rendered targets, frame 0, fresh networks); "
+                      f"R here {f['num_rendered']}" + (f", the headline's last frame R={headline_R} "
+                                                     f"({100.0 * (f['num_rendered'] / headline_R - 1.0):+.1f} %)" if headline_R else ""),
+            "num_rendered": int(f["num_rendered"])}
 
 
 def trained_like_render_bwd(dev, iters=12):
@@ -264,12 +286,14 @@ def trained_like_render_bwd(dev, iters=12):
                 ((40.0 * R + 20.0 * W * H) / (med["render_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if med.get("render_fwd") else None}
 
 
-def frac_valu_from_profiles():
-    """VALU lane operations / (78.6 T lane-op/s x kernel time) of the blend kernels from the newest committed PMC pass
-    (profiles/r0*_pmc_sq*.json; offline data of the same workload, named in `source`)."""
+def frac_valu_from_profiles(scene):
+    """VALU lane operations per launch of the blend kernels from the newest committed PMC pass OF THE NAMED SCENE
+    (profiles/r0*_pmc_sq_<scene>*.json, scene = "bench" | "trained"; offline data, named in `source`) -- the caller divides by the
+    kernel time it measured on the same scene.  `valu_busy_of_chip` is the pass's own busy fraction (VALU quad-cycles x 4 over wall
+    cycles x 1024 SIMDs), the cross-check for the `frac_valu` derived here."""
     import glob
     out = {}
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*pmc_sq*.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0*pmc_sq_{scene}*.json")), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
@@ -279,8 +303,8 @@ def frac_valu_from_profiles():
                 if short in k and short not in out and "SQ_ACTIVE_INST_VALU" in v and "wall_cycles" in v:
                     # SQ_ACTIVE_INST_VALU: quad-cycles of VALU execution summed over waves; x4 cycles x 32 lanes per cycle
                     lane_ops = 4.0 * v["SQ_ACTIVE_INST_VALU"] * 32.0
-                    out[short] = {"valu_lane_ops_per_launch": lane_ops, "frac_valu_at_profiled_clock": lane_ops / (v["wall_cycles"] * 256 * 4 * 32.0),
-                                  "source": "profiles/" + os.path.basename(f)}
+                    out[short] = {"valu_lane_ops_per_launch": lane_ops, "valu_busy_of_chip": v.get("valu_busy_of_chip"),
+                                  "scene": scene, "source": "profiles/" + os.path.basename(f)}
     return out
 
 
@@ -295,14 +319,17 @@ def main():
                     help="BASELINE.json config the synthetic scene follows; the metric is quoted on cfg2 (default), the others are "
                          "informational")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode and trained-like extra regions")
+    ap.add_argument("--targets", default=os.environ.get("DGM_BENCH_TARGETS", "teacher"), choices=["teacher", "noise"],
+                    help="ground-truth frames: renders of a perturbed copy of the scene (default; R stays put) or rounds 1-5's smoothed noise")
     ap.add_argument("--phase", default="gs", choices=["gs", "mesh"],
                     help="gs: dynamic-Gaussian phase (deform + deform_back; the metric's configuration).  mesh: the mesh co-training "
                          "phase -- four networks on P, DPSR chain, deform_back + appearance on V (BASELINE config 5's 'DPSR mesh step')")
     ap.add_argument("--dpsr-res", type=int, default=288)
     ap.add_argument("--verts", type=int, default=60000)
     args = ap.parse_args()
-    global WORKLOAD
+    global WORKLOAD, TARGETS
     WORKLOAD = args.workload
+    TARGETS = args.targets
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: become one.  N ranks on this node, one per GPU, rendezvous on 127.0.0.1.
@@ -420,7 +447,12 @@ def main():
         steady = {"steps": STEADY_STEPS, "value": STEADY_STEPS * world / s_dt, "ms_per_step": 1e3 * s_dt / STEADY_STEPS}
 
     n_inst_timed = int(RZ.LAST_NUM_RENDERED)  # tile instances R of the timed workload's last frame (the extras below render other scenes)
-    n_live_timed = RZ.live_rows() if rank == 0 else None  # gradient rows its backward wrote (what preprocess_bwd reads)
+    # gradient rows a backward of this workload writes (what preprocess_bwd reads): counted on ONE extra untimed step, the only one
+    # that runs with the counting switch on
+    RZ.RECORD_LIVE_ROWS = True
+    tr.step(it0 + args.warmup + args.steps)
+    RZ.RECORD_LIVE_ROWS = False
+    n_live_timed = RZ.live_rows() if rank == 0 else None
     # the gradient buckets' all-reduce on its own (what one step exchanges; in the step the larger bucket runs under the MLP
     # backward passes)
     allreduce = None
@@ -507,41 +539,55 @@ def main():
         achieved = (alg_bytes / (bwd_ms * 1e-3) / 1e9) if bwd_ms > 0 else 0.0
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 
-        def pmc_traffic(name):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload); offline data
+        def pmc_traffic(name, kernel=None, launches_per_step=None):
+            """HBM bytes per launch from a committed rocprofv3 --pmc pass -- counters cannot be read without the profiler, so this
+            is offline data; it is only printed when the file describes THIS run's launch: same workload, same kernel, same row
+            count N = P and (where the file records it) the same launches per step.  Returns (bytes, file, commit) or Nones + why."""
             try:
                 with open(os.path.join(prof_dir, name)) as fh:
                     pmc = json.load(fh)
-                if pmc.get("workload") == WORKLOAD:
-                    return float(pmc["fetch_bytes"]) + float(pmc["write_bytes"]), name
-            except (OSError, ValueError, KeyError):
-                pass
-            return None, None
+            except (OSError, ValueError):
+                return None, None, f"{name}: not readable"
+            why = None
+            if pmc.get("workload") != WORKLOAD:
+                why = f"workload {pmc.get('workload')} != {WORKLOAD}"
+            elif kernel is not None and pmc.get("kernel", "").split("<")[0] not in kernel:
+                why = f"kernel {pmc.get('kernel')} is not this run's {kernel.split(' ')[0]}"
+            elif pmc.get("N") is not None and int(pmc["N"]) != P:
+                why = f"N {pmc['N']} != {P}"
+            elif pmc.get("launches_per_step") is not None and launches_per_step is not None and \
+                    abs(float(pmc["launches_per_step"]) - launches_per_step) > 0.02 * launches_per_step:
+                why = f"launches per step {pmc['launches_per_step']} != {launches_per_step}"
+            elif pmc.get("N") is None or pmc.get("commit") is None:
+                why = "the file records neither N nor the commit it was taken at (a pass of an earlier round)"
+            if why is not None:
+                return None, None, f"profiles/{name} refused: {why}"
+            return float(pmc["fetch_bytes"]) + float(pmc["write_bytes"]), name, pmc["commit"]
 
         gemm_mode = L.lib().dgm_mlp_set_gemm(-1) if mlp_impl == "hip" else -1  # (-1: query, mode unchanged)
-        f16x3 = gemm_mode == 3
         mfma_per_product = 3.0  # f16x3 / f16x3p: 3 MFMAs per fp32 product on the f16 pipe
         layer_flops = 2.0 * P * 256 * 256                       # SURVEY.md section 8d: one 256 -> 256 layer over N = P rows
         layer_bytes = 2.0 * P * 256 * 4 + P * 32 + 256 * 256 * 4  # A in + C out (fp32) + ReLU mask bits + the weights once
         dw_bytes = 2.0 * P * 256 * 4 + 256 * 256 * 4  # X in + G in + the gradient once (the per-CU partial tiles are overhead)
-        planes = gemm_mode == 3
-        kn = {3: ("mlp_gemm4_kernel<16,1024,512,0> (256->256 layer forward on planes, N rows)",
-                  "mlp_gemm4_kernel<16,1024,512,1> (256->256 layer backward-data on planes, N rows)",
-                  "mlp_dw4_kernel<8,8> (256x256 weight gradient over N rows, planes)")}.get(
-            gemm_mode, ("mlp_gemm_kernel<0> (fp32 MFMA)", "mlp_gemm_kernel<1> (fp32 MFMA)", "mlp_dw_kernel (fp32 MFMA)"))
-        pm = ("r05_pmc_gemm4_fwd.json", "r03_pmc_gemm4_bwd.json", "r03_pmc_dw4.json") if planes else (None, None, None)
+        planes = gemm_mode >= 3
+        kn = (("mlp_gemm4_kernel<16,1024,512,0> (256->256 layer forward on planes, N rows)",
+               "mlp_gemm4_kernel<16,1024,512,1> (256->256 layer backward-data on planes, N rows)",
+               "mlp_dw4_kernel<8,8> (256x256 weight gradient over N rows, planes)") if planes else
+              ("mlp_gemm_kernel<0> (fp32 MFMA)", "mlp_gemm_kernel<1> (fp32 MFMA)", "mlp_dw_kernel (fp32 MFMA)"))
+        pm = ("r06_pmc_gemm4_fwd.json", None, None) if planes else (None, None, None)
         kern = {  # stage -> (kernel name, algorithmic flops, algorithmic bytes, committed PMC file)
             "mlp_layer_fwd": (kn[0], layer_flops, layer_bytes, pm[0]),
             "mlp_layer_bwd": (kn[1], layer_flops, layer_bytes, pm[1]),
             "mlp_layer_dw": (kn[2], layer_flops, dw_bytes, pm[2]),
             # backward data + weight gradient of one layer in one launch (plane arithmetic): G_l read once algorithmically
             "mlp_bwd_pair": ("mlp_bwd_pair_kernel (256->256 backward-data on part of the CUs + 256x256 weight gradient on the rest)",
-                             2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r05_pmc_bwd_pair.json"),
-            "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r05_pmc_render_bwd4.json"),
-            "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "r05_pmc_render_fwd.json"),
-            "tile_sort": ("tile_sort_radix_kernel (+ the mid / big worklists' launch)", 0.0, 12.0 * n_inst, "r05_pmc_tile_sort_radix.json"),  # 8-byte records in, point_list out
+                             2.0 * layer_flops, 3.0 * P * 256 * 4 + P * 32 + 2 * 256 * 256 * 4, "r06_pmc_bwd_pair.json"),
+            "render_bwd": ("render_bwd4_kernel", 0.0, alg_bytes, "r06_pmc_render_bwd4.json"),
+            "render_fwd": ("render_fwd_kernel", 0.0, 40.0 * n_inst + 20.0 * W * H, "r06_pmc_render_fwd.json"),
+            "tile_sort": ("tile_sort_radix_kernel (+ the mid / big worklists' launch)", 0.0, 12.0 * n_inst, "r06_pmc_tile_sort_radix.json"),  # 8-byte records in, point_list out
             # 559 B per Gaussian + the 36-byte rows some pixel blended (live rows; the others are neither written nor read)
             "preprocess_bwd": ("preprocess_bwd_kernel", 0.0, 559.0 * P + 36.0 * (n_live_timed if n_live_timed is not None else n_inst),
-                               "r05_pmc_preprocess_bwd.json"),
+                               "r06_pmc_preprocess_bwd.json"),
             "preprocess_fwd": ("preprocess_fwd_kernel", 0.0, 311.0 * P, None),
         }
         kernels, best, best_ms = {}, None, -1.0
@@ -564,26 +610,28 @@ def main():
         if best is not None:
             r = kernels[best]
             kname, fl, by, pmc_file = kern[best]
-            traffic, src = pmc_traffic(pmc_file) if pmc_file else (None, None)
+            traffic, src, commit = pmc_traffic(pmc_file, kname, r["launches_per_step"]) if pmc_file else (None, None, "no PMC pass committed for this kernel")
             if r.get("frac_mfma_pipe", 0.0) > r["frac_hbm"]:
                 roof = {"kernel": kname, "bound": "mfma", "achieved": r["mfma_issued_TFLOPs"], "peak": MFMA_16BIT_PEAK_TF,
                         "unit": "TFLOP/s", "frac": r["frac_mfma_pipe"]}
             else:
                 roof = {"kernel": kname, "bound": "hbm", "achieved": r["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac_hbm"]}
-            roof.update({"traffic": traffic, "traffic_source": (f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                                                 "workload, committed (not measured in this run)") if src else None,
+            roof.update({"traffic": traffic, "traffic_source": (f"profiles/{src} taken at commit {commit}: rocprofv3 --pmc FETCH_SIZE / "
+                                                                 "WRITE_SIZE passes of this workload, kernel, N and launch count, "
+                                                                 "committed (counters cannot be read without the profiler: not "
+                                                                 "measured in this run)") if src else commit,
                          "algorithmic_bytes": by, "algorithmic_flops": fl, "avg_ms": r["avg_ms"], "launches_per_step": r["launches_per_step"],
                          "ms_per_step": r["ms_per_step"], "frac_hbm": r["frac_hbm"], "frac_mfma_pipe": r.get("frac_mfma_pipe"),
                          "arithmetic": ("f16x3p: activations / gradients stored as 2 binary16 planes with one exponent per 32-row tile, "
                                         "split once by the producer, 3 MFMAs per product" if planes else "native fp32 MFMA")})
-        rb_traffic, rb_src = pmc_traffic("r05_pmc_render_bwd4.json")
+        rb_traffic, rb_src, _ = pmc_traffic("r06_pmc_render_bwd4.json", "render_bwd4_kernel")
         out = {
             "metric": ("train-step iters/sec (800x800, ~100k Gaussians)" if WORKLOAD == "cfg2"
                        else f"train-step iters/sec ({WORKLOAD}: {W}x{H}, P={P}; informational, the metric is quoted on cfg2)"),
             "value": args.steps * world / elapsed,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("f32 (f16x3p split products, fp32 accumulate)" if mlp_impl == "hip" and gemm_mode == 3 else
+            "vs_baseline": None, "dtype": ("f32 (f16x3p split products, fp32 accumulate)" if mlp_impl == "hip" and gemm_mode >= 3 else
                                           "f32 (native fp32 MFMA)" if gemm_mode == 1 else "f32"), "data": "synthetic",
             "phase": ("dynamic Gaussian splatting (deform + deform_back)" if args.phase == "gs" else
                       f"mesh co-training: deform, deform_normal, deform_back, deform_back_normal on P + DPSR {args.dpsr_res}^3 (splat, "
@@ -623,12 +671,21 @@ def main():
             out["with_densify"] = with_densify
         if trained is not None:
             out["roofline_render_bwd_trained"] = trained
-        fv = frac_valu_from_profiles()
+        # VALU fraction of the blend kernels: lane operations counted by the committed PMC pass OF THE SAME SCENE over the kernel time
+        # measured here on that scene, against the 2.4 GHz peak (256 CU x 4 SIMD x 32 lanes = 78.6 T lane-op/s)
+        fv = frac_valu_from_profiles("bench")
         for short, st_name in (("render_bwd4_kernel", "render_bwd"), ("render_fwd_kernel", "render_fwd")):
-            if short in fv and st_name in out["kernels"]:  # against the 2.4 GHz peak: 256 CU x 4 SIMD x 32 lanes = 78.6 T lane-op/s
+            if short in fv and st_name in out["kernels"]:
                 fv[short]["frac_valu"] = fv[short]["valu_lane_ops_per_launch"] / (out["kernels"][st_name]["avg_ms"] * 1e-3 * 78.6e12)
         if fv:
             out["frac_valu"] = fv
+        if trained is not None and "avg_ms" in trained:
+            fvt = frac_valu_from_profiles("trained")
+            for short, key in (("render_bwd4_kernel", "avg_ms"), ("render_fwd_kernel", "render_fwd_ms")):
+                if short in fvt and trained.get(key):
+                    fvt[short]["frac_valu"] = fvt[short]["valu_lane_ops_per_launch"] / (trained[key] * 1e-3 * 78.6e12)
+            if fvt:
+                trained["frac_valu"] = fvt
         if steady is not None:
             out["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:
@@ -638,9 +695,11 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         if WORKLOAD == "cfg2":  # informational, offline: the reference's own step on this GPU model (a -m gpu test measures it)
             try:
-                r = json.load(open(os.path.join(ROOT, "profiles", "r05_ref_vs_ours_step.json")))
+                import glob
+                src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_ref_vs_ours_step.json")))[-1]
+                r = json.load(open(src))
                 out["reference_same_gpu"] = {"value": r["reference_shaped_it_s"], "unit": "it/s",
-                                             "source": "profiles/r05_ref_vs_ours_step.json (committed measurement of "
+                                             "source": f"profiles/{os.path.basename(src)} (committed measurement of "
                                                        "tests/test_gpu_vs_reference.py, not taken in this run)"}
             except Exception:
                 pass

@@ -349,6 +349,9 @@ __device__ __forceinline__ unsigned radix_varying_bits(const unsigned (&key)[RS_
     return v;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "binning.hip uses v_bitop3_b32 and wave64 DPP row_bcast: gfx950 only"
+#endif
 // Lanes of the wave that hold the same 8-bit digit as this one (among the `valid` lanes), as the two halves of a 64-bit mask: per bit
 // one ballot and m &= (bit set ? ballot : ~ballot) = m & ~(ballot ^ x) with x = 0 / -1 the sign-extended bit -- ONE v_bitop3_b32 per
 // half (truth table 0x90 over (m, ballot, x)), 4 instructions per bit; the select form (`bs ? bb : ~bb`) compiled to 9.
@@ -359,7 +362,9 @@ __device__ __forceinline__ void match_digit(unsigned d, bool valid, unsigned& m_
     for (int bit = 0; bit < 8; bit++) {
         const int x = __builtin_amdgcn_sbfe((int)d, bit, 1);
         unsigned long long bb;  // = __ballot(x != 0), as the compare of x itself (the compiler shifts d again for its own: +1 per bit)
-        asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(bb) : "v"(x));
+        // (volatile: the result depends on EXEC, which the compiler cannot see -- it must not be hoisted, sunk or merged across
+        // divergent control flow)
+        asm volatile("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(bb) : "v"(x));
         m_lo = __builtin_amdgcn_bitop3_b32(m_lo, (unsigned)bb, (unsigned)x, 0x90);
         m_hi = __builtin_amdgcn_bitop3_b32(m_hi, (unsigned)(bb >> 32), (unsigned)x, 0x90);
     }

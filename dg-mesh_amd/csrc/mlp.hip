@@ -27,6 +27,7 @@
 
 #include "dgm_common.hpp"
 #include "mlp_planes.hpp"
+#include "mlp_planes5.hpp"
 
 namespace dgm {
 
@@ -323,6 +324,7 @@ __global__ void mlp_reduce_dw_kernel(int chunks, int db_chunks, int Kp, int in_f
 // The same reduction in ONE pass for the matrix-core paths (256 partial tiles of 256 KB per layer: the read is the cost).
 struct ReduceDwJob {
     int chunks, db_rows, Kp, in_features, nblocks;
+    int emb_rows, k_valid;  // Kp != 256 jobs: rows [0, emb_rows) are the embedding's (the first k_valid of them real columns), the rest the trunk's
     int dst_off;  // Kp == 256 jobs: first input feature the rows go to (the skip layer's trunk rows as a job of their own)
     const float* partial;
     const float* partial_db;
@@ -419,8 +421,8 @@ mlp_reduce_dw_all_kernel(const ReduceDwBatch rb) {
         const int k = k0 + kk;
         int dst;
         if (Kp == MLP_W) dst = k + jb.dst_off;
-        else if (k < MLP_EMB) dst = k < emb_dim ? k : -1;
-        else dst = k - MLP_EMB + emb_dim;
+        else if (k < jb.emb_rows) dst = k < jb.k_valid ? k : -1;
+        else dst = k - jb.emb_rows + emb_dim;
         if (dst >= 0) dW[(size_t)(j0 + jj) * in_features + dst] = s;
     }
     if (do_db && tid < 8) {
@@ -725,6 +727,7 @@ struct Ws {
     unsigned* matmax;
     uint4 *Wh4f, *Wh4b;
     float *wsc_hf, *wsc_hb;
+    float *beff[2], *temb_row;  // round 6: biases of layer 0 / the skip layer with the call's time row folded in; that row (for the backward pass)
     size_t bytes;
 };
 int num_cus() {
@@ -741,13 +744,21 @@ int num_cus() {
 }
 // 3: f16x3p (default; mlp_planes.hpp): power-of-two scaled operands split into 2 binary16, 3 partial products on the f16 matrix
 //    cores, on plane-format activations -- split once by the producer, one exponent per 32-row tile.
-// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3p|f32.
+// 4: the same arithmetic on round 3-5's kernel forms ("f16x3p8": eight waves x 32 columns per layer GEMM, the skip layer's
+//    embedding half as an fp32 `Cin` stream written by layer 0) -- what mode 3 still runs for a time input PER ROW; kept
+//    selectable as the A/B partner of round 6's forms (one wave per SIMD, K = 320 skip layer, time row folded into the biases).
+// 5: mode 3 with EVERY 256-wide layer GEMM in the one-wave-per-SIMD form ("f16x3p5": mlp_gemm5_kernel<0, 0> forward, <0, 1> in
+//    unpaired backward passes).  Measured slower than the eight-wave form (50.5 vs 48.9 us under the power probe, 54.5
+//    vs 48.4 inside a network pass), so mode 3 uses that form for the K = 320 skip layer only; kept selectable for the record.
+// 1: native fp32 MFMA (v_mfma_f32_32x32x2_f32).  Initial value from DGM_MLP_GEMM=f16x3p|f16x3p8|f16x3p5|f32.
 // (0 = "bf16x6 for every GEMM" was retired in round 4, 2 = "f16x3" on fp32 rows in round 5: both are ignored by dgm_mlp_set_gemm.)
 int g_gemm_mode = [] {
     const char* e = getenv("DGM_MLP_GEMM");
     if (e == nullptr) return 3;
     if (strcmp(e, "f32") == 0) return 1;
-    if (strcmp(e, "f16x3p") != 0) fprintf(stderr, "libdgmesh_hip: unknown DGM_MLP_GEMM=\"%s\" (f16x3p | f32): using f16x3p\n", e);
+    if (strcmp(e, "f16x3p8") == 0) return 4;
+    if (strcmp(e, "f16x3p5") == 0) return 5;
+    if (strcmp(e, "f16x3p") != 0) fprintf(stderr, "libdgmesh_hip: unknown DGM_MLP_GEMM=\"%s\" (f16x3p | f16x3p8 | f32): using f16x3p\n", e);
     return 3;
 }();
 // arithmetic the last forward pass on a workspace ran in: the backward pass must match (its scales and masks were produced by
@@ -835,6 +846,9 @@ Ws carve(char* base, int N) {
     w.Wh4b = (uint4*)take((size_t)16 * MLP_W * 4);
     w.wsc_hf = take(64);
     w.wsc_hb = take(64);
+    w.beff[0] = take(MLP_W * 4);
+    w.beff[1] = take(MLP_W * 4);
+    w.temb_row = take(64 * 4);
     w.bytes = (size_t)(p - base) + 256;
     return w;
 }
@@ -875,12 +889,24 @@ hipError_t p4_lds_attr(K kernel, int bytes, bool* done) {  // dynamic LDS above 
             return mlp_fail("mlp: cannot raise the LDS limit of a plane-path kernel");                                 \
         hipLaunchKernelGGL(kernel_, dim3(grid_), dim3(512), cfg_lds_, st_, args_);                                     \
     }
+#define P5_LAUNCH(kernel_, cfg_lds_, grid_, st_, args_)                                                                \
+    {                                                                                                                  \
+        static bool done_[DGM_MAX_DEVICES] = {false};                                                                  \
+        if (p4_lds_attr(kernel_, cfg_lds_, &done_[current_device_slot()]) != hipSuccess)                               \
+            return mlp_fail("mlp: cannot raise the LDS limit of a plane-path kernel");                                 \
+        hipLaunchKernelGGL(kernel_, dim3(grid_), dim3(256), cfg_lds_, st_, args_);                                     \
+    }
 typedef Gemm4Cfg<16, 1024, 512, 0, false, 8> CfgFwd;
 typedef Gemm4Cfg<16, 1024, 512, 2, false, 8> CfgSkip;
 typedef Gemm4Cfg<16, 1024, 512, 1, false, 8> CfgBwd;
 typedef Gemm4Cfg<6, 384, 192, 0, true, 8> CfgL0;
 typedef Gemm4Cfg<16, 1024, 512, 3, false, 1> CfgHeads;
 typedef Gemm4Cfg<1, 128, 64, 1, false, 8> CfgG7;
+typedef Gemm4Cfg<4, 256, 128, 0, false, 8> CfgL0F;   // layer 0 on the 64-column embedding
+typedef Gemm5Cfg<0, 0> Cfg5Fwd;
+typedef Gemm5Cfg<0, 1> Cfg5Bwd;
+typedef Gemm5Cfg<4, 0> Cfg5Skip;
+typedef Dw4Cfg<2, 8, 256, 128, 1024, 512> CfgDwE64;
 typedef Dw4Cfg<8, 8, 1024, 512, 1024, 512> CfgDw;
 typedef Dw4Cfg<3, 8, 384, 192, 1024, 512> CfgDwE;
 typedef Dw4Cfg<8, 1, 1024, 512, 128, 64> CfgDwH;
@@ -913,18 +939,28 @@ int p4_pair_split(int ntiles, int gx) {
     return n;
 }
 
+// fold: one time value per call (temb_stride == 0) on round 6's kernel forms -- the embedding is 64 columns wide, the time row sits
+// in the biases of layer 0 and the skip layer, the skip layer is one K = 320 GEMM (no `Cin`), the 256-wide layers run one wave per SIMD.
 int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* temb, int temb_stride, const Ws& w, float* out,
-                   hipStream_t st) {
+                   hipStream_t st, const bool fold, const bool all5) {
     const P4Plan pl = p4_plan(N);
     const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
     const int sk = p->skip_layer;
+    const int EW = fold ? 64 : MLP_EMB;
     // embedding planes + the maxima of the nine weight tensors (W_0 .. W_7, Wh)
     AbsMaxBatch am;
     am.n_jobs = 9;
     for (int l = 0; l < 8; l++) am.job[l].W = p->W[l], am.job[l].n = MLP_W * layer_in(p, l);
     am.job[8].W = p->Wh, am.job[8].n = p->n_out * MLP_W;
     hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, temb_stride, p->t_dim,
-                       (unsigned char*)w.emb, w.Eexp, am, w.matmax);
+                       (unsigned char*)w.emb, w.Eexp, am, w.matmax, EW);
+    if (fold) {
+        FoldBiasArgs f;
+        f.W[0] = p->W[0], f.b[0] = p->b[0], f.beff[0] = w.beff[0], f.in_features[0] = layer_in(p, 0);
+        f.W[1] = p->W[sk], f.b[1] = p->b[sk], f.beff[1] = w.beff[1], f.in_features[1] = layer_in(p, sk);
+        f.temb = temb, f.T = p->t_dim, f.temb_row = w.temb_row;
+        hipLaunchKernelGGL(mlp_fold_bias_kernel, dim3(2, 8), dim3(256), 0, st, f);
+    }
     // every weight matrix as two binary16 planes, one power-of-two scale per matrix
     Prep4Batch pb;
     int nj = 0;
@@ -935,7 +971,9 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
         q.j.k_valid = k_valid, q.j.col_valid = col_valid, q.j.W = Wp, q.j.Bp = Bp, q.j.inv_scale = inv_scale, q.mat = mat;
     };
     for (int l = 0; l < 8; l++) {
-        if (l == sk) {  // K = 352 = embedding half (rides along with layer 0) | trunk half
+        if (fold && l == 0) add(0, 64, MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_f[l], l);
+        else if (fold && l == sk) add(0, 320, MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_f[l], l);
+        else if (l == sk) {  // K = 352 = embedding half (rides along with layer 0) | trunk half
             add(0, MLP_EMB, MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_e, l);
             add(0, MLP_W, MLP_W, layer_in(p, l), p->emb_dim, MLP_W, MLP_W, p->W[l], w.Wt3[l] + (size_t)MLP_EMB * MLP_W / 4, w.wsc_f[l], l);
         } else
@@ -949,6 +987,34 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     Gemm4Args a;
     memset(&a, 0, sizeof(a));
     a.ntiles = nt, a.M = N, a.exps_limit = p4_exps_limit();
+    if (fold) {
+        // layer 0: K = 64, eight waves (HBM-bound: 26 MB in, 102 MB of planes out)
+        a.A = (const unsigned char*)w.emb, a.Aexp = w.Eexp, a.Bp = w.Wt3[0], a.b_inv = w.wsc_f[0], a.bias = w.beff[0];
+        a.mask_out = w.mask[0], a.C = (unsigned char*)w.Y[0], a.Cexp = w.Yexp[0];
+        P4_LAUNCH((mlp_gemm4_kernel<4, 256, 128, 0, false, 8>), CfgL0F::LDS, gx, st, a)
+        Gemm5Args b;
+        memset(&b, 0, sizeof(b));
+        b.ntiles = nt, b.M = N, b.exps_limit = p4_exps_limit();
+        for (int l = 1; l < 8; l++) {
+            b.A = (const unsigned char*)w.Y[l - 1], b.Aexp = w.Yexp[l - 1], b.Bp = w.Wt3[l], b.b_inv = w.wsc_f[l];
+            b.mask_out = w.mask[l], b.C = (unsigned char*)w.Y[l], b.Cexp = w.Yexp[l];
+            if (l == sk) {  // K = 320: the embedding's four K steps, then the trunk's sixteen
+                b.A2 = (const unsigned char*)w.emb, b.A2exp = w.Eexp, b.bias = w.beff[1];
+                P5_LAUNCH((mlp_gemm5_kernel<4, 0>), Cfg5Skip::LDS, gx, st, b)
+                b.A2 = nullptr, b.A2exp = nullptr;
+            } else if (all5) {
+                b.bias = p->b[l];
+                dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
+                P5_LAUNCH((mlp_gemm5_kernel<0, 0>), Cfg5Fwd::LDS, gx, st, b)
+                dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
+            } else {  // the eight-wave form (measured faster for K = 256)
+                a.A = b.A, a.Aexp = b.Aexp, a.Bp = b.Bp, a.b_inv = b.b_inv, a.bias = p->b[l], a.mask_out = b.mask_out, a.C = b.C, a.Cexp = b.Cexp;
+                dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
+                P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>), CfgFwd::LDS, gx, st, a)
+                dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
+            }
+        }
+    } else {
     // layer 0 (K = 96) with the embedding half of the skip layer as second output
     a.A = (const unsigned char*)w.emb, a.Aexp = w.Eexp, a.Bp = w.Wt3[0], a.b_inv = w.wsc_f[0], a.bias = p->b[0];
     a.mask_out = w.mask[0], a.C = (unsigned char*)w.Y[0], a.Cexp = w.Yexp[0];
@@ -969,6 +1035,8 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
             dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
         }
     }
+    }
+    a.Bp2 = nullptr, a.b_inv2 = nullptr, a.bias2 = nullptr, a.out2 = nullptr, a.cin = nullptr;
     // heads: out = Y7 Wh^T + bh (one computing wave per workgroup; HBM-bound: one pass over Y7)
     a.A = (const unsigned char*)w.Y[7], a.Aexp = w.Yexp[7], a.Bp = w.Wh4f, a.b_inv = w.wsc_hf, a.bias = p->bh;
     a.mask_out = nullptr, a.C = nullptr, a.Cexp = nullptr, a.out = out, a.ldo = p->n_out, a.n_valid = p->n_out;
@@ -979,10 +1047,12 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
 }
 
 int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_stride, const Ws& w, float* const* dW, float* const* db,
-                    float* dWh, float* dbh, float* dtemb, hipStream_t st, const float* x_in = nullptr, float* dX = nullptr) {
+                    float* dWh, float* dbh, float* dtemb, hipStream_t st, const bool fold, const bool all5, const float* x_in = nullptr,
+                    float* dX = nullptr) {
     const P4Plan pl = p4_plan(N);
     const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
     const int sk = p->skip_layer;
+    const int EW = fold ? 64 : MLP_EMB;  // rows of the embedding's block of the K = EW / EW + 256 weight gradients (fold: see forward_planes)
     // dOut -> planes (zero columns / rows beyond n_out / N) + the heads' bias-gradient partial sums
     hipLaunchKernelGGL(mlp_dout4_kernel, dim3((nt + 3) / 4), dim3(256), 0, st, N, nt, p->n_out, dOut, w.Dp, w.Dexp, w.partial_hb);
     unsigned char* G = (unsigned char*)w.Ga;
@@ -1012,6 +1082,7 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
                        const float* partial_db, float* dWp, float* dbp) {
         ReduceDwJob& jb = rb.job[slot];
         jb.chunks = chunks, jb.db_rows = db_rows, jb.Kp = Kp, jb.in_features = in_features, jb.nblocks = reduce_dw_blocks(Kp);
+        jb.emb_rows = EW, jb.k_valid = fold ? MLP_XE : p->emb_dim;
         jb.dst_off = dst_off, jb.partial = partial, jb.partial_db = partial_db, jb.dW = dWp, jb.db = dbp;
         if (jb.nblocks > rb_blocks) rb_blocks = jb.nblocks;
     };
@@ -1024,7 +1095,7 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     const bool per_row_t = temb_stride != 0 && dtemb != nullptr;
     if (per_row_t && dX) return mlp_fail("mlp_backward: position gradients need a broadcast time row");
     for (int l = 7; l >= 0; l--) {
-        const int Kp = layer_kp(p, l);
+        const int Kp = l == 0 ? EW : (l == sk ? EW + MLP_W : MLP_W);
         const bool paired = n_dw > 0 && l >= 1;
         // (the paired launch gives each of its n_dw weight-gradient workgroups ceil(nt / n_dw) tiles: the last few may get none
         // and write no partial tile -- the reduction must only read the ones that exist)
@@ -1043,16 +1114,17 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
                                dtemb, p->t_dim);
         // partial tiles of the layer: [chunk][Kp][256]; paired skip layer: trunk rows [n_dw][256][256], then embedding rows [chunks][96][256]
         float* part_emb = w.partial_l[l];
-        float* part_trunk = w.partial_l[l] + (l == sk ? (size_t)MLP_EMB * MLP_W : 0);
+        float* part_trunk = w.partial_l[l] + (l == sk ? (size_t)EW * MLP_W : 0);
         size_t stride_emb = (size_t)Kp * MLP_W, stride_trunk = (size_t)Kp * MLP_W;
         if (paired && l == sk) {
             part_trunk = w.partial_l[l], stride_trunk = (size_t)MLP_W * MLP_W;
-            part_emb = w.partial_l[l] + (size_t)n_dw * MLP_W * MLP_W, stride_emb = (size_t)MLP_EMB * MLP_W;
+            part_emb = w.partial_l[l] + (size_t)n_dw * MLP_W * MLP_W, stride_emb = (size_t)EW * MLP_W;
         }
         if (l == 0 || l == sk) {  // the embedding's rows of the gradient (rows 0 .. 95 of the K = 96 / 352 partial tile)
             d.tiles_per_chunk = pl.tiles_per_chunk;
             d.X = (const unsigned char*)w.emb, d.Xexp = w.Eexp, d.partial = part_emb, d.chunk_stride = stride_emb, d.partial_db = w.partial_db_l[l];
-            P4_LAUNCH((mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>), CfgDwE::LDS, pl.chunks, st, d)
+            if (fold) P4_LAUNCH((mlp_dw4_kernel<2, 8, 256, 128, 1024, 512>), CfgDwE64::LDS, pl.chunks, st, d)
+            else P4_LAUNCH((mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>), CfgDwE::LDS, pl.chunks, st, d)
         }
         if (l != 0) {
             d.tiles_per_chunk = paired ? tpc_pair : pl.tiles_per_chunk;
@@ -1076,14 +1148,21 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
             dgm::prof_end(DGM_STAGE_MLP_BWD_PAIR, st);
         } else if (l >= 1) {
             dgm::prof_begin(DGM_STAGE_MLP_LAYER_BWD, st);
-            P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
+            if (all5) {
+                Gemm5Args b;
+                memset(&b, 0, sizeof(b));
+                b.ntiles = nt, b.M = N, b.exps_limit = a.exps_limit;
+                b.A = a.A, b.Aexp = a.Aexp, b.Bp = a.Bp, b.b_inv = a.b_inv, b.mask_in = a.mask_in, b.C = a.C, b.Cexp = a.Cexp;
+                P5_LAUNCH((mlp_gemm5_kernel<0, 1>), Cfg5Bwd::LDS, gx, st, b)
+            } else
+                P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
             dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
             dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
             P4_LAUNCH((mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>), CfgDw::LDS, chunks_l, st, d)
             dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
         }
         if (paired && l == sk) {  // two reduction jobs: embedding rows (with the bias gradient), trunk rows
-            add_job(l, pl.chunks, 8 * pl.chunks, MLP_EMB, layer_in(p, l), 0, part_emb, w.partial_db_l[l], dW[l], db[l]);
+            add_job(l, pl.chunks, 8 * pl.chunks, EW, layer_in(p, l), 0, part_emb, w.partial_db_l[l], dW[l], db[l]);
             add_job(8, chunks_l, 0, MLP_W, layer_in(p, l), p->emb_dim, part_trunk, nullptr, dW[l], nullptr);
             rb.n_jobs = 9;
         } else
@@ -1104,6 +1183,13 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
     rb.h_dW = dWh, rb.h_db = dbh;
     hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, rb.n_jobs + 1), dim3(256), 0, st, rb);
+    if (fold) {  // the time columns of dW_0 / dW_skip: db (x) t_emb
+        FoldGradArgs f;
+        f.dW[0] = dW[0], f.db[0] = db[0], f.in_features[0] = layer_in(p, 0);
+        f.dW[1] = dW[sk], f.db[1] = db[sk], f.in_features[1] = layer_in(p, sk);
+        f.temb = w.temb_row, f.T = p->t_dim;
+        hipLaunchKernelGGL(mlp_fold_grad_kernel, dim3(2, p->t_dim), dim3(256), 0, st, f);
+    }
     if (dtemb != nullptr && !per_row_t)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
                            db[sk], p->W[sk], layer_in(p, sk), dtemb);
@@ -1117,7 +1203,7 @@ extern "C" {
 
 int dgm_mlp_set_gemm(int mode) {
     const int prev = g_gemm_mode;
-    if (mode == 1 || mode == 3) g_gemm_mode = mode;  // (0, "bf16x6 for every GEMM", and 2, "f16x3" on fp32 rows, are retired: ignored)
+    if (mode == 1 || mode == 3 || mode == 4 || mode == 5) g_gemm_mode = mode;  // (0, "bf16x6 for every GEMM", and 2, "f16x3" on fp32 rows, are retired: ignored)
     return prev;
 }
 
@@ -1186,8 +1272,16 @@ int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
     d.chunk_stride = (size_t)256 * 256, d.partial_db = pdb;
     int n_dw = p4_pair_split(nt, gx);
     if (n_dw > pl.chunks) n_dw = pl.chunks;
+    Gemm5Args a5;
+    memset(&a5, 0, sizeof(a5));
+    a5.exps_limit = 512, a5.ntiles = nt, a5.M = N, a5.A = (kind == 4) ? A : G, a5.Aexp = ex, a5.Bp = Bp, a5.b_inv = binv, a5.bias = bias;
+    a5.mask_in = mask, a5.mask_out = mask, a5.C = C, a5.Cexp = ex + nt;
     for (int it = 0; it < iters; it++) {
-        if (kind == 0) {
+        if (kind == 4) {  // round 6: the one-wave-per-SIMD forms
+            P5_LAUNCH((mlp_gemm5_kernel<0, 0>), Cfg5Fwd::LDS, gx, st, a5)
+        } else if (kind == 5) {
+            P5_LAUNCH((mlp_gemm5_kernel<0, 1>), Cfg5Bwd::LDS, gx, st, a5)
+        } else if (kind == 0) {
             P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>), CfgFwd::LDS, gx, st, a)
         } else if (kind == 3) {
             P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
@@ -1250,8 +1344,9 @@ int dgm_mlp_forward(const dgm_mlp_params* p, int N, const float* x, const float*
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
     const int mode = g_gemm_mode;
-    remember_ws_mode(workspace, mode);
-    if (mode == 3) return forward_planes(p, N, x, temb, temb_stride, w, out, st);
+    const bool fold = (mode == 3 || mode == 5) && temb_stride == 0;
+    remember_ws_mode(workspace, mode + (fold ? 16 : 0));
+    if (mode >= 3) return forward_planes(p, N, x, temb, temb_stride, w, out, st, fold, fold && mode == 5);
     // ---- native fp32 MFMA
     for (int l = 0; l < 8; l++) {
         const int Kp = layer_kp(p, l);
@@ -1293,16 +1388,21 @@ int dgm_mlp_backward_dx(const dgm_mlp_params* p, int N, const float* dOut, int t
     if (!dOut || !workspace || !dW || !db || !dWh || !dbh) return mlp_fail("mlp_backward: NULL pointer");
     if ((x == nullptr) != (dX == nullptr)) return mlp_fail("mlp_backward: x and dX come together");
     const int mode = g_gemm_mode;
-    if (dX && (mode != 3 || temb_stride != 0))
+    if (dX && (mode < 3 || temb_stride != 0))
         return mlp_fail("mlp_backward: the gradient w.r.t. the positions exists in the plane arithmetic only (f16x3p, broadcast time row)");
     {
         const int fm = recall_ws_mode(workspace);
-        if (fm >= 0 && fm != mode)
+        if (fm >= 0 && (fm & 15) != mode)
             return mlp_fail("mlp_backward: the arithmetic mode changed since the forward pass on this workspace (dgm_mlp_set_gemm)");
+        if (fm >= 0 && ((fm & 16) != 0) != ((mode == 3 || mode == 5) && temb_stride == 0))
+            return mlp_fail("mlp_backward: temb_stride differs from the forward pass on this workspace");
     }
     hipStream_t st = (hipStream_t)stream;
     Ws w = carve(workspace, N);
-    if (mode == 3) return backward_planes(p, N, dOut, temb_stride, w, dW, db, dWh, dbh, dtemb, st, x, dX);
+    if (mode >= 3) {
+        const bool fold = (mode == 3 || mode == 5) && temb_stride == 0;
+        return backward_planes(p, N, dOut, temb_stride, w, dW, db, dWh, dbh, dtemb, st, fold, fold && mode == 5, x, dX);
+    }
     // ---- native fp32 MFMA
     const int chunks = (N + DW_ROWS - 1) / DW_ROWS;
     const int grid = (N + GM - 1) / GM;

@@ -91,6 +91,9 @@ __device__ __forceinline__ float prep3_src(const Prep3Job& j, int k, int col) {
         int src = k + j.hoff;  // (hoff: first input feature of a K = 256 slice -- the skip layer's trunk half)
         if (j.Kp == 96) src = k < j.emb_dim ? k : -1;
         else if (j.Kp == 352) src = k < 96 ? (k < j.emb_dim ? k : -1) : k - 96 + j.emb_dim;
+        // round 6, one time value per call: the embedding is [x, PE(x), 0] (64 columns), the time columns sit in the bias
+        else if (j.Kp == 64) src = k < 63 ? k : -1;
+        else if (j.Kp == 320) src = k < 64 ? (k < 63 ? k : -1) : k - 64 + j.emb_dim;
         return (src >= 0 && col < j.col_valid) ? j.W[(size_t)col * j.in_features + src] : 0.f;
     }
     return k < j.k_valid ? j.W[(size_t)k * j.in_features + j.hoff + col] : 0.f;
@@ -182,14 +185,15 @@ struct AbsMaxBatch {
     AbsMaxJob job[P4_MAX_MATS];
 };
 
-// emb planes [Np][2][96] binary16 + one exponent per 32-row tile, rows >= N zero.
+// emb planes [Np][2][EW] binary16 (EW = 96, or 64 without the time columns) + one exponent per 32-row tile, rows >= N zero.
 //   emb[r] = [x, sin(x 2^0), cos(x 2^0), ..., sin(x 2^9), cos(x 2^9) | t_emb[r] | 0...]   (time_utils.py:24-55)
 // Grid: 8 am.n_jobs workgroups that reduce max |W| of an eighth of one weight tensor each into matmax[job][8] (float bits; the
 // weight preparation folds the eight) -- the scales of the weight planes; riding along here saves a launch in front of the weight
 // preparation, which needs them -- followed by ntiles workgroups (one 32-row tile each).
 __global__ void __launch_bounds__(256)
 mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
-                  unsigned char* __restrict__ Ep, int* __restrict__ Eexp, const AbsMaxBatch am, unsigned* __restrict__ matmax) {
+                  unsigned char* __restrict__ Ep, int* __restrict__ Eexp, const AbsMaxBatch am, unsigned* __restrict__ matmax,
+                  const int EW) {
     __shared__ float se[32][96 + 1];
     __shared__ float smax[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -233,9 +237,11 @@ mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* _
             se[rl][6 + 6 * q + a] = cs;
         }
     }
-    // x, the time embedding, the zero padding: 36 columns per row
-    for (int i = tid; i < 32 * 36; i += 256) {
-        const int rl = i / 36, j = i - 36 * rl, r = r0 + rl;
+    // x, the time embedding, the zero padding: 3 + (EW - 63) columns per row (EW = 64: no time columns -- one time value per call
+    // is folded into the biases, mlp_fold_bias_kernel -- just the zero column 63)
+    const int rest = 3 + EW - 63;
+    for (int i = tid; i < 32 * rest; i += 256) {
+        const int rl = i / rest, j = i - rest * rl, r = r0 + rl;
         float v = 0.f;
         int c;
         if (j < 3) {
@@ -244,7 +250,7 @@ mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* _
         } else {
             const int t = j - 3;
             c = 63 + t;
-            if (r < N && t < T) v = temb[(size_t)r * temb_stride + t];
+            if (EW == 96 && r < N && t < T) v = temb[(size_t)r * temb_stride + t];
         }
         se[rl][c] = v;
         mx = fmaxf(mx, fabsf(v));
@@ -258,15 +264,16 @@ mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* _
     const int e = p4_exp_from_max_bits(__float_as_uint(tm));
     const float sc = p4_pow2(e);
     if (tid == 0) Eexp[tile] = e;
-    // 32 rows x 24 column quads: one 8-byte store per plane and quad
-    for (int i = tid; i < 32 * 24; i += 256) {
-        const int rl = i / 24, c4 = (i - 24 * rl) * 4;
+    // 32 rows x EW / 4 column quads: one 8-byte store per plane and quad
+    const int nq = EW >> 2;
+    for (int i = tid; i < 32 * nq; i += 256) {
+        const int rl = i / nq, c4 = (i - nq * rl) * 4;
         unsigned h0, l0, h1, l1;
         split2h(se[rl][c4] * sc, se[rl][c4 + 1] * sc, h0, l0);
         split2h(se[rl][c4 + 2] * sc, se[rl][c4 + 3] * sc, h1, l1);
-        unsigned char* d = Ep + (size_t)(r0 + rl) * 384 + c4 * 2;
+        unsigned char* d = Ep + (size_t)(r0 + rl) * (EW * 4) + c4 * 2;
         *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(d + 192) = make_uint2(l0, l1);
+        *reinterpret_cast<uint2*>(d + EW * 2) = make_uint2(l0, l1);
     }
 }
 
@@ -710,8 +717,8 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
                 constexpr bool WIDE = H1 >= 5;
                 if (ks == 1) G4_SROW(0)
                 if (ks == (WIDE ? 2 : 1)) G4_SROW(1)
-                if (ks == (WIDE ? 3 : 2)) G4_SROW(2)
-                if (ks == (WIDE ? 4 : 2)) {
+                if (ks == (WIDE ? 3 : (H1 >= 3 ? 2 : 1))) G4_SROW(2)   // (H1 == 2 -- K = 64 -- has the one K step for all four)
+                if (ks == (WIDE ? 4 : (H1 >= 3 ? 2 : 1))) {
                     G4_SROW(3)
                     if (HS.value && (EPI == 0 || EPI == 2) && wv == 7) reinterpret_cast<uint4*>(a.mask_out + (size_t)(tile - 2 * G) * 256)[lane] = smv;
                 }

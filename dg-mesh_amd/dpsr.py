@@ -152,6 +152,7 @@ class _Laplace(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dloss):
         faces, scratch = ctx.saved_tensors
         dl = dloss.reshape(1).contiguous().float()
@@ -170,6 +171,10 @@ def laplace_regularizer_const(v_pos, t_pos_idx):
         faces = t_pos_idx.to(device=v_pos.device, dtype=torch.int32).contiguous()
         if faces.dim() != 2 or faces.shape[1] != 3:
             raise RuntimeError("laplace_regularizer_const: t_pos_idx must be (F, 3)")
+        if faces.numel():  # the kernels scatter with atomicAdd at 3 * index: an index outside [0, V) would be a silent stray write
+            lo, hi = torch.aminmax(faces)  # (one small reduction + read-back per call; the mesh branch, not the train step's hot loop)
+            if int(lo) < 0 or int(hi) >= v_pos.shape[0]:
+                raise IndexError(f"laplace_regularizer_const: face index out of range [0, {v_pos.shape[0]})")
         return _Laplace.apply(v_pos, faces)
     return _laplace_regularizer_torch(v_pos, t_pos_idx)
 

@@ -191,7 +191,7 @@ def network_forward(net, heads, x, t_emb, bcast):
     if x.requires_grad and not bcast:
         raise RuntimeError("trunk_impl='hip' differentiates w.r.t. the positions only with a broadcast time row (the plane "
                            "arithmetic); use trunk_impl='torch' for per-row time inputs")
-    if x.requires_grad and _lib.lib().dgm_mlp_set_gemm(-1) != 3:  # (-1: query) dgm_mlp_backward_dx exists in the plane arithmetic only
+    if x.requires_grad and _lib.lib().dgm_mlp_set_gemm(-1) not in (3, 4, 5):  # (-1: query) dgm_mlp_backward_dx exists in the plane arithmetic only
         raise RuntimeError("trunk_impl='hip' differentiates w.r.t. the positions only in the default f16x3p arithmetic "
                            "(DGM_MLP_GEMM / dgm_mlp_set_gemm select another one): use trunk_impl='torch' for this network")
     check_supported(net, heads, t_emb)

@@ -21,19 +21,24 @@ from . import _lib
 NUM_CHANNELS = 3  # DGR/cuda_rasterizer/config.h:15
 LAST_NUM_RENDERED = 0  # num_rendered of the most recent forward (read by bench.py for the roofline bytes)
 FORWARD_CALL_SECONDS = 0.0  # wall time spent inside dgm_rasterize_forward, i.e. mostly waiting on the R read-back
-LAST_BACKWARD_STATE = None  # (binning buffer, P, W, H, R) of the most recent backward: bench.py counts its live gradient rows
+# Reporting aid (bench.py): with RECORD_LIVE_ROWS set, a backward counts the per-instance gradient rows it wrote and leaves the
+# number in LAST_LIVE_ROWS.  Off by default, and only the int is kept: holding the binning buffer itself (rounds 4-5) kept it from
+# returning to the caching allocator before the next forward asked for its own, which doubled the resident binning memory.
+RECORD_LIVE_ROWS = False
+LAST_LIVE_ROWS = None
 
 
-def live_rows(state=None):
-    """Number of per-instance gradient rows the most recent backward wrote (`live` bytes of the binning buffer, DESIGN.md
-    section 2): what preprocess_bwd actually reads.  One device reduction + read-back; for reporting, not for the step."""
-    state = state or LAST_BACKWARD_STATE
-    if state is None:
-        return None
-    binning, P, W, H, R = state
+def _count_live_rows(binning, P, W, H, R):
+    """`live` bytes of the binning buffer that the backward set: the rows preprocess_bwd reads.  One device
+    reduction + read-back."""
     lay = _lib.StateLayout()
     _lib.check(_lib.lib().dgm_describe_state(int(P), int(W), int(H), int(R), ctypes.byref(lay)))
     return int(binning[lay.live:lay.live + int(R)].sum(dtype=torch.int64).item())
+
+
+def live_rows():
+    """Rows counted by the most recent backward that ran with RECORD_LIVE_ROWS set (None if none did)."""
+    return LAST_LIVE_ROWS
 
 
 def _ptr(t):
@@ -151,8 +156,9 @@ class _CModule:
                     _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL), _ptr(dL_dmeans2D), _ptr(dL_dconic),
                     _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
                     _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)), _stream()))
-            global LAST_BACKWARD_STATE
-            LAST_BACKWARD_STATE = (binningBuffer, P, W, H, int(R))
+            if RECORD_LIVE_ROWS:
+                global LAST_LIVE_ROWS
+                LAST_LIVE_ROWS = _count_live_rows(binningBuffer, P, W, H, int(R))
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
     @staticmethod
@@ -296,8 +302,9 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
                     float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img), _ptr(dL),
                     _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                     _ptr(dL_ddc), _ptr(dL_drest), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(rs.debug)), _stream()))
-            global LAST_BACKWARD_STATE
-            LAST_BACKWARD_STATE = (binning, P, W, H, int(ctx.num_rendered))
+            if RECORD_LIVE_ROWS:
+                global LAST_LIVE_ROWS
+                LAST_LIVE_ROWS = _count_live_rows(binning, P, W, H, int(ctx.num_rendered))
         return dL_dmeans3D, dL_dmeans2D, dL_ddc, dL_drest, dL_dopacity, dL_dscales, dL_drotations, None
 
 

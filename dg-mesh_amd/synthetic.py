@@ -175,6 +175,39 @@ def gt_image(W, H, seed=0):
     return np.clip(acc / 25.0, 0.0, 1.0)
 
 
+# "Teacher" targets for a stationary benchmark workload (round 6): the ground-truth frames are renders of a PERTURBED copy of the
+# scene -- centres moved by a fraction of each splat's own extent, colours, SH detail and opacity logits jittered, extents and
+# orientations kept -- so that the loss pulls the student towards a scene with the same footprint statistics and the number of tile
+# instances R stays where it started.  (Rounds 1-5 used smoothed noise as targets: the optimiser answered by inflating the splats,
+# R drifted 3.0 M -> 4.1 M within 35 steps at cfg2 and 8 M -> 63 M at cfg4, and the CPU leg and the GPU headline timed different R.)
+TEACHER = dict(xyz=0.2, dc=0.3, rest=0.05, opacity=0.5, seed=777)
+
+
+def teacher_np(g, seed=None):
+    """numpy raw-parameter dict of the teacher of `g` (a make_gaussians()-style dict)."""
+    rng = np.random.RandomState(TEACHER["seed"] if seed is None else seed)
+    t = dict(g)
+    t["xyz"] = (g["xyz"] + TEACHER["xyz"] * np.exp(g["scaling"]) * rng.randn(*g["xyz"].shape)).astype(np.float32)
+    t["features_dc"] = (g["features_dc"] + TEACHER["dc"] * rng.randn(*g["features_dc"].shape)).astype(np.float32)
+    t["features_rest"] = (g["features_rest"] + TEACHER["rest"] * rng.randn(*g["features_rest"].shape)).astype(np.float32)
+    t["opacity"] = (g["opacity"] + TEACHER["opacity"] * rng.randn(*g["opacity"].shape)).astype(np.float32)
+    return t
+
+
+def teacher_torch(model_cls, g, generator):
+    """The same recipe on the GPU: a GaussianModel (`model_cls`) holding the perturbed copy of GaussianModel `g`."""
+    import torch
+    dev = g._xyz.device
+    rn = lambda like: torch.randn(like.shape, device=dev, generator=generator)
+    t = model_cls(sh_degree=g.max_sh_degree, device=dev)
+    with torch.no_grad():
+        t.load_raw(g._xyz + TEACHER["xyz"] * torch.exp(g._scaling) * rn(g._xyz), g._features_dc + TEACHER["dc"] * rn(g._features_dc),
+                   g._features_rest + TEACHER["rest"] * rn(g._features_rest), g._scaling.clone(), g._rotation.clone(),
+                   g._opacity + TEACHER["opacity"] * rn(g._opacity), g._normal.clone())
+    t.active_sh_degree = g.active_sh_degree
+    return t
+
+
 # BASELINE.json configs restated as synthetic workloads (SURVEY.md section 8 table)
 CONFIGS = {
     "cfg1": dict(W=400, H=400, P=20_000, white_bg=True, is_blender=True),

@@ -41,6 +41,10 @@ KINDS = {0: ("fwd_gemm", "mlp_gemm4_kernel<16,1024,512,0>", 2.0 * N * 1024 + 32 
          1: ("dw", "mlp_dw4_kernel<8,8>", 2.0 * N * 1024 + 256 * 1024, 1),
          2: ("pair", "mlp_bwd_pair_kernel", 3.0 * N * 1024 + 32 * N + 2 * 256 * 1024, 2),
          3: ("bwd_gemm", "mlp_gemm4_kernel<16,1024,512,1>", 2.0 * N * 1024 + 32 * N + 256 * 1024, 1)}
+# round 6: the one-wave-per-SIMD forms (4 waves x 64 columns; mlp_planes5.hpp)
+KINDS[4] = ("fwd_gemm5", "mlp_gemm5_kernel<0,0>", KINDS[0][2], 1)
+KINDS[5] = ("bwd_gemm5", "mlp_gemm5_kernel<0,1>", KINDS[3][2], 1)
+# (kinds 6 / 7 -- the paired launch and the weight gradient in that form -- were measured once, 3.3x / 4.3x slower: tools/exp/dw5_pair5_r6.hip.txt)
 KINDS[9] = ("copy", "torch copy_ (elementwise kernel), 102.4 MB -> 102.4 MB", 2.0 * N * 1024, 0)
 COPY_SRC = torch.randn(N * 256, device="cuda")
 COPY_DST = torch.empty_like(COPY_SRC)
