@@ -154,7 +154,7 @@ def reference_host_modules():
                 sys.modules[k] = v
 
 
-def cpu_baseline(P, W, H, max_threads=32, headline_R=None):
+def cpu_baseline(P, W, H, max_threads=32, headline_R=None, frame=0):
     """The same train step on the host: the reference's own network and loss modules on PyTorch-CPU (this repo's torch
     restatement of them only if the byte-compiled modules are absent) around the oracle rasterizer (C, OpenMP; the reference
     has no CPU rasterizer).  A few steps of the full cfg2 workload are the bounded sample."""
@@ -168,7 +168,7 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None):
     torch.set_num_threads(cores)
     xyz0 = ((np.random.RandomState(0).rand(P, 3) * 2 - 1) * 1.3).astype(np.float32)  # the points build_scene() draws
     g = syn.make_gaussians(P, seed=0, dist2=orc.knn(xyz0))  # same initialisation as create_from_pcd (simple-knn scales)
-    cam = syn.config_camera(WORKLOAD, frame=0)
+    cam = syn.config_camera(WORKLOAD, frame=frame)  # the view of the headline's last timed step (R differs by a few % between views)
     tanx, tany = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
     white = bool(syn.CONFIGS[WORKLOAD]["white_bg"])
     bg = np.ones(3, np.float32) if white else np.zeros(3, np.float32)
@@ -232,7 +232,8 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None):
     return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": kind,
             "sample": f"{n_steps} full {WORKLOAD} train steps ({W}x{H}, P={P}, R={f['num_rendered']}): oracle rasterizer "
                       f"fwd+bwd (C/OpenMP; the reference has no CPU rasterizer) + {what} + torch.optim.Adam on PyTorch-CPU, "
-                      f"{dt:.1f} s each.  Same workload recipe as the GPU headline (teacher-rendered targets, frame 0, fresh networks); "
+                      f"{dt:.1f} s each.  Same workload recipe as the GPU headline (teacher-rendered targets, the view of its last "
+                      f"timed step -- frame {frame} --, fresh networks); "
                       f"R here {f['num_rendered']}" + (f", the headline's last frame R={headline_R} "
                                                      f"({100.0 * (f['num_rendered'] / headline_R - 1.0):+.1f} %)" if headline_R else ""),
             "num_rendered": int(f["num_rendered"])}
@@ -391,6 +392,7 @@ def main():
         L.lib().dgm_set_profiling(2)
         torch.cuda.synchronize()
         RZ.FORWARD_CALL_SECONDS = 0.0
+        RZ.SETTLE_WAIT_SECONDS = 0.0
         t0 = time.perf_counter()
         pk = None
         for i in range(n_steps):
@@ -403,6 +405,7 @@ def main():
         st = L.collect_stage_ms()
         L.lib().dgm_set_profiling(0)
         blocked = RZ.FORWARD_CALL_SECONDS
+        timed.settle_wait = RZ.SETTLE_WAIT_SECONDS
         if world > 1:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -416,7 +419,9 @@ def main():
     if world > 1:
         tr.exchange_events = []
     dev_allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    redos0 = RZ.OVERFLOW_REDOS
     elapsed, stages, blocked_s, pkg = timed(args.steps, it0 + args.warmup)
+    settle_s, redos = timed.settle_wait, RZ.OVERFLOW_REDOS - redos0
     # hipMalloc calls of torch's caching allocator inside the timed region: 0 at steady state; a scene whose R keeps setting new
     # maxima (cfg4 under the random targets) pays one multi-GB allocation per new size of the binning buffer
     dev_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - dev_allocs0
@@ -447,6 +452,7 @@ def main():
         steady = {"steps": STEADY_STEPS, "value": STEADY_STEPS * world / s_dt, "ms_per_step": 1e3 * s_dt / STEADY_STEPS}
 
     n_inst_timed = int(RZ.LAST_NUM_RENDERED)  # tile instances R of the timed workload's last frame (the extras below render other scenes)
+    last_frame = int(getattr(tr, "last_frame", 0))
     # gradient rows a backward of this workload writes (what preprocess_bwd reads): counted on ONE extra untimed step, the only one
     # that runs with the counting switch on
     RZ.RECORD_LIVE_ROWS = True
@@ -654,10 +660,13 @@ def main():
                                     "launches": bwd_n},
             "kernels": kernels,
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
-            # host side: time blocked in the rasterizer forward (its R read-back is the step's only sync) vs busy
+            # host side: time inside the rasterizer forward call (synchronous protocol: its R read-back is the step's only sync;
+            # DGM_SYNC_FREE=1: the call only enqueues and {R, flags} are looked at after the backward is enqueued -- `settle_wait`)
             "host_ms_per_step": {"blocked_on_gpu": round(1e3 * blocked_s / args.steps, 3),
                                  "busy": round(1e3 * (elapsed - blocked_s) / args.steps, 3),
-                                 "device_allocations_in_timed_region": int(dev_allocs)},
+                                 "device_allocations_in_timed_region": int(dev_allocs),
+                                 "sync_free_forward": bool(RZ.SYNC_FREE), "settle_wait": round(1e3 * settle_s / args.steps, 3),
+                                 "frames_redone_for_capacity": int(redos)},
         }
         out["rccl_world_size"] = dist.get_world_size() if world > 1 else 1
         if dp is not None:
@@ -673,7 +682,7 @@ def main():
             out["roofline_render_bwd_trained"] = trained
         # VALU fraction of the blend kernels: lane operations counted by the committed PMC pass OF THE SAME SCENE over the kernel time
         # measured here on that scene, against the 2.4 GHz peak (256 CU x 4 SIMD x 32 lanes = 78.6 T lane-op/s)
-        fv = frac_valu_from_profiles("bench")
+        fv = frac_valu_from_profiles("bench") if WORKLOAD == "cfg2" else {}  # (the committed passes are cfg2's)
         for short, st_name in (("render_bwd4_kernel", "render_bwd"), ("render_fwd_kernel", "render_fwd")):
             if short in fv and st_name in out["kernels"]:
                 fv[short]["frac_valu"] = fv[short]["valu_lane_ops_per_launch"] / (out["kernels"][st_name]["avg_ms"] * 1e-3 * 78.6e12)
@@ -690,7 +699,7 @@ def main():
             out["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(P, W, H, headline_R=n_inst)
+                out["cpu_baseline"] = cpu_baseline(P, W, H, headline_R=n_inst, frame=last_frame)
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         if WORKLOAD == "cfg2":  # informational, offline: the reference's own step on this GPU model (a -m gpu test measures it)

@@ -46,6 +46,9 @@ SYMBOLS = {
     "dgm_rasterize_forward_split_sh": (_i, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp,
                                             _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp,
                                             _c.POINTER(_i)]),
+    "dgm_rasterize_forward_capacity": (_i, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp,
+                                            _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp,
+                                            _i, _vp]),
     "dgm_rasterize_backward_split_sh": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp,
                                              _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _vp, _vp, _i, _vp]),
@@ -96,7 +99,7 @@ SYMBOLS = {
 }
 
 _LIB = None
-ABI_VERSION = 4  # DGM_ABI_VERSION of include/dgmesh_hip.h
+ABI_VERSION = 5  # DGM_ABI_VERSION of include/dgmesh_hip.h
 
 
 def build(force=False, verbose=False):

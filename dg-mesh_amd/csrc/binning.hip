@@ -158,7 +158,8 @@ count_tiles_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __res
 __global__ void __launch_bounds__(256)
 tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ hist, unsigned* __restrict__ tile_count,
                  unsigned* __restrict__ tile_offset, uint2* __restrict__ ranges, unsigned* __restrict__ big_list,
-                 unsigned* __restrict__ big_count, unsigned* __restrict__ arrive, unsigned* __restrict__ total) {
+                 unsigned* __restrict__ big_count, unsigned* __restrict__ arrive, unsigned* __restrict__ total,
+                 const unsigned capacity, unsigned* __restrict__ tiles_touched, const int P) {
     constexpr int MAXC = DGM_MAX_CHUNKS / 4;  // chunk rows per wave
     __shared__ unsigned wtot[4][64];
     __shared__ unsigned wave_sum[4];
@@ -239,6 +240,16 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
         __syncthreads();  // (wave_sum is rewritten by the next pass)
     }
     if (threadIdx.x == 0) tile_offset[tiles] = run_total, *total = run_total;  // (R: the host reads it back to size the binning buffer)
+    // Capacity mode (dgm_rasterize_forward_capacity: the binning buffer was sized BEFORE R was known): a frame that does not fit is
+    // neutralised here, by the one workgroup that knows R -- every tile's range and both sort worklists emptied, every Gaussian's
+    // tile count zeroed (the scatter and the backward's gather walk those), bit 1 of the flag word raised for the host, which
+    // discards the frame and renders it again with a larger buffer.  Nothing downstream writes or reads past `capacity` rows.
+    if (run_total > capacity) {  // (workgroup-uniform)
+        __syncthreads();
+        for (int t = threadIdx.x; t < tiles; t += 256) ranges[t] = make_uint2(0u, 0u);
+        for (int g = threadIdx.x; g < P; g += 256) tiles_touched[g] = 0u;
+        if (threadIdx.x == 0) big_count[0] = 0u, big_count[1] = 0u, total[1] |= 2u;
+    }
 }
 
 // Workgroup b = 8 * chunk + x runs on XCD x = b % 8 and emits the instances of its chunk that fall on the x-th BAND of tile rows
@@ -835,9 +846,9 @@ hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles
 
 void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
                       unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive,
-                      unsigned* total) {
+                      unsigned* total, unsigned capacity, unsigned* tiles_touched, int P) {
     hipLaunchKernelGGL(tile_scan_kernel, dim3((tiles + 63) / 64), dim3(256), 0, st, tiles, nchunks, kSmallCap, hist, tile_count,
-                       tile_offset, ranges, big_list, big_count, arrive, total);
+                       tile_offset, ranges, big_list, big_count, arrive, total, capacity, tiles_touched, P);
 }
 
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx, int gridy, size_t R,

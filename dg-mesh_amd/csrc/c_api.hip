@@ -32,7 +32,7 @@ hipError_t launch_count(hipStream_t st, int P, int chunk, int nchunks, int tiles
                         unsigned* hist, unsigned* counters);
 void launch_tile_scan(hipStream_t st, int tiles, int nchunks, unsigned* hist, unsigned* tile_count,
                       unsigned* tile_offset, uint2* ranges, unsigned* big_list, unsigned* big_count, unsigned* arrive,
-                      unsigned* total);
+                      unsigned* total, unsigned capacity, unsigned* tiles_touched, int P);
 hipError_t launch_scatter(hipStream_t st, int P, int chunk, int nchunks, int tiles, int gridx, int gridy, size_t R,
                           const unsigned* tiles_touched, const float* rec, const float* depth, const unsigned* hist,
                           const unsigned* tile_offset, uint2* inst);
@@ -287,14 +287,18 @@ int dgm_rasterize_forward(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn 
                                           tan_fovy, prefiltered, out_color, radii, debug, stream, num_rendered);
 }
 
-int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
-                                   dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
-                                   int width, int height, const float* means3D, const float* shs, const float* shs_rest,
-                                   const float* colors_precomp, const float* opacities, const float* scales,
-                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                                   float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
-                                   int* num_rendered) {
+// capacity < 0: the reference's protocol -- R is read back (one blocking 16-byte copy) and the binning buffer sized with it.
+// capacity >= 0 (dgm_rasterize_forward_capacity): the binning buffer is sized for `capacity` instances up front, nothing waits for
+// the device; {R, flags, worklist lengths} are copied to `host_result` asynchronously and a frame with R > capacity is neutralised
+// on the device (tile_scan_kernel) and flagged (flags bit 1).
+static int forward_impl(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                        dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                        int width, int height, const float* means3D, const float* shs, const float* shs_rest,
+                        const float* colors_precomp, const float* opacities, const float* scales,
+                        float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                        float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                        int* num_rendered, const long long capacity, unsigned* host_result) {
     hipStream_t st = (hipStream_t)stream;
     if (num_rendered) *num_rendered = 0;
     if (shs_rest && (!shs || M < 2)) return fail("rasterize_forward: shs_rest needs the DC rows in shs and M >= 2");
@@ -321,6 +325,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
 
     if (P == 0) {  // reference: kernels skipped, rendered = 0, out_color stays 0 (rasterize_points.cu:68,81)
         DGM_HIP(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), st));
+        if (host_result) host_result[0] = host_result[1] = host_result[2] = host_result[3] = 0u;
         return 0;
     }
     if (!means3D || !opacities) return fail("rasterize_forward: NULL required pointer");
@@ -369,9 +374,20 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     tm.end(DGM_STAGE_BIN_COUNT);
 
     tm.begin(DGM_STAGE_BIN_SCAN);
-    launch_tile_scan(st, tiles, L.n_chunks, hist, tile_count, tile_offset, ranges, big_list, counters + 2, counters + 4, counters);
+    launch_tile_scan(st, tiles, L.n_chunks, hist, tile_count, tile_offset, ranges, big_list, counters + 2, counters + 4, counters,
+                     capacity >= 0 ? (unsigned)capacity : 0xffffffffu, tiles_touched, P);
     DGM_CHECK("tile_scan");
     tm.end(DGM_STAGE_BIN_SCAN);
+
+    int R;
+    unsigned n_big, n_mid;
+    if (capacity >= 0) {
+        // no read-back on the critical path: the words go to the caller's (pinned) memory behind the scan, the caller looks at them
+        // after an event of its own; every size below follows `capacity`, both sort worklists are launched (an empty one leaves at once)
+        DGM_HIP(hipMemcpyAsync(host_result, counters, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        R = (int)capacity, n_big = n_mid = 0xffffffffu;
+        if (num_rendered) *num_rendered = R;
+    } else {
 
     // R is needed on the host to size the binning buffer (rasterizer_impl.cu:281 does the same read-back); the
     // "prefiltered but culled" flag of auxiliary.h:156-160 rides in the same 16-byte copy, so it is ALWAYS checked
@@ -388,9 +404,10 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     DGM_HIP(hipStreamSynchronize(st));
     const unsigned R_host = host_words[0];
     if (R_host > 0x7fffffffu) return fail("rasterize_forward: %u tile instances overflow int", R_host);
-    const int R = (int)R_host;
+    R = (int)R_host, n_big = host_words[2], n_mid = host_words[3];
     if (num_rendered) *num_rendered = R;
     if (host_words[1] & 1u) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
 
     compute_layout(P, width, height, R, &L);
     char* bin = binning_alloc(binning_ctx, L.binning_bytes);
@@ -412,7 +429,7 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
         // (segments beyond 4096 entries sort in global memory: their pair buffers are carved from the backward's row slab,
         // 36 bytes per entry -- they need 16 -- and idle during the forward pass)
         DGM_HIP(launch_tile_sort(st, tiles, ranges, inst, (uint2*)(bin + L.slab), (size_t)R, point_list, big_list, counters + 2,
-                                 host_words[2], host_words[3]));
+                                 n_big, n_mid));
         DGM_CHECK("tile_sort");
         tm.end(DGM_STAGE_TILE_SORT);
     }
@@ -425,6 +442,35 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
     tm.end(DGM_STAGE_RENDER_FWD);
     tm.finish();
     return 0;
+}
+
+int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                                   dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                                   int width, int height, const float* means3D, const float* shs, const float* shs_rest,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                                   int* num_rendered) {
+    return forward_impl(geom_alloc, geom_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M, background, width, height,
+                        means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, num_rendered, -1, nullptr);
+}
+
+int dgm_rasterize_forward_capacity(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                                   dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                                   int width, int height, const float* means3D, const float* shs, const float* shs_rest,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                                   int capacity, unsigned* host_result) {
+    if (capacity < 1) return fail("rasterize_forward_capacity: capacity must be >= 1 tile instance");
+    if (!host_result) return fail("rasterize_forward_capacity: host_result is NULL");
+    return forward_impl(geom_alloc, geom_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M, background, width, height,
+                        means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, nullptr, capacity,
+                        host_result);
 }
 
 int dgm_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,

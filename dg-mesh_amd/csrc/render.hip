@@ -16,6 +16,9 @@
 //    SCALAR loop over the set bits of its masks (s_ff1 / s_andn2), so pairs that the reference would discard
 //    with `alpha < 1/255` after evaluating exp() are never issued.  The test is conservative (inflated box;
 //    NaN => keep), hence results are unchanged.
+#include <stdlib.h>
+#include <string.h>
+
 #include "dgm_common.hpp"
 #include "render_common.hpp"
 
@@ -264,6 +267,180 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
     }
 #endif
 }
+// ---- sparse frames (R < 2^20), round 6: the four quadrant waves of a tile run ASYNCHRONOUSLY ------------------------------------------
+// render_fwd_kernel<true> stages 256 list entries per round for the whole tile and its four quadrant waves meet at two barriers a
+// round: the per-wave trace of round 5 (profiles/r05_render_fwd_trace.txt) showed a trained-like frame bound by a few hundred long
+// tiles in which every wave spends ~500 cycles per entry it tests -- ~250 for the blend, the rest waiting at the round's barrier for
+// the tile's busiest quadrant -- so a tile costs the SUM over rounds of the per-round maxima.  Here every wave stages for itself:
+// 64 entries a round into its own 3 KB of LDS (the list slice and the records of the NEXT round are in flight while the current one
+// blends), tested against its own 8 x 8 block only, no barrier inside the loop.  A tile then costs the maximum over its quadrants of
+// their own total work.  The price is four reads of the tile's list and records instead of one (L2 hits; a sparse frame leaves the
+// memory system idle).  Same per-pixel arithmetic, same order of the blends, same outputs as the kernel above -- bit-identical.
+// Checkpoints: a wave writes its pixels' state at the unit boundaries it passes; a quadrant whose pixels have all terminated leaves the
+// loop, and after the tile's one barrier (which yields the replay bound) fills in the boundaries up to that bound with its final state
+// -- exactly the set the backward reads.
+__global__ void __launch_bounds__(256)
+render_fwd_async_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
+                        const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
+                        float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
+                        float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out, const int ulog,
+                        unsigned* __restrict__ uctl, uint4* __restrict__ ulist_full, uint4* __restrict__ ulist_last,
+                        uint8_t* __restrict__ live) {
+    __shared__ float4 sRw[4][64 * 3];  // per wave: the round's 64 staged splats (layout as in render_fwd_kernel)
+    __shared__ unsigned sMaxC[4];
+    __shared__ unsigned sUnitBase;
+    const int tile = blockIdx.x;
+    const int tile_x = tile % gridx, tile_y = tile / gridx;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int px = tile_x * DGM_TILE + (wv & 1) * 8 + (lane & 7);
+    const int py = tile_y * DGM_TILE + (wv >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float qx0 = (float)(tile_x * DGM_TILE + (wv & 1) * 8), qy0 = (float)(tile_y * DGM_TILE + (wv >> 1) * 8);
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const int rounds = (n + 63) >> 6;
+    for (int i = threadIdx.x; i < n; i += 256) live[range.x + i] = 0;
+    const bool shortlist = n <= DGM_SHORT_LIST;
+    const int ulen_log = shortlist ? ulog : 8;          // checkpoint interval: u entries, 256 beyond DGM_SHORT_LIST
+    const int lxy = (((wv >> 1) * 8 + (lane >> 3)) >> 2) * 64 + ((((wv >> 1) * 8 + (lane >> 3)) & 3) << 4) + (wv & 1) * 8 + (lane & 7);
+    // boundary s (the state after s << ulen_log entries) lives at ...
+    float4* const cbase = shortlist ? ckpt64 + (size_t)(range.x >> ulog) * 256 + lxy
+                                    : ckpt + (size_t)(range.x >> 8) * 256 + lxy;  // (+ s * 256; the long form: slot (range.x + 256 s) >> 8)
+    float4* const sR = sRw[wv];
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    unsigned last_contributor = 0;
+    unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
+    int s_next = 1;  // next boundary this wave has not written
+
+    // round 0's entry and record; afterwards the next round's are fetched while the current one blends
+    unsigned g_next = 0u;
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+    float ncb = 0.f;
+    if (lane < n) {
+        g_next = point_list[range.x + lane];
+        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g_next * DGM_REC_STRIDE);
+        n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
+    }
+    for (int i = 0; i < rounds; i++) {
+        if (done_m == ~0ull) break;  // every pixel of this quadrant has terminated (the boundaries left are filled in below)
+        const int at = (i << 6) + lane;
+        bool hit = false;
+        if (at < n) {
+            const float l2e = 1.4426950408889634f;
+            sR[3 * lane] = make_float4(n0.x, n0.y, -0.5f * l2e * n0.z, -l2e * n0.w);
+            sR[3 * lane + 1] = make_float4(-0.5f * l2e * n1.x, n1.y, n1.z, n1.w);
+            sR[3 * lane + 2].x = ncb;
+            hit = quadrant_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx0, qy0);
+        }
+        const unsigned long long mask = uniform_u64(__ballot(hit));
+        const unsigned base = (unsigned)(i << 6);
+        const int at_next = ((i + 1) << 6) + lane;
+        const bool more = i + 1 < rounds;  // (wave-uniform)
+        if (more && at_next < n) g_next = point_list[range.x + at_next];
+        const int nsub = 64 >> (ulen_log < 6 ? ulen_log : 6);  // checkpoint intervals inside a round (2 at u = 32, else 1)
+#pragma unroll 1
+        for (int sb = 0; sb < nsub; sb++) {
+            if (sb == nsub - 1 && more && at_next < n) {  // (the list entry asked for above has arrived by now)
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g_next * DGM_REC_STRIDE);
+                n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
+            }
+            unsigned long long m = mask;
+            if (nsub == 2) m &= sb == 0 ? 0xffffffffull : 0xffffffff00000000ull;
+            while (m) {
+                const int ja = __builtin_ctzll(m);
+                m &= m - 1;
+                const bool two = m != 0ull;
+                const int jb = two ? __builtin_ctzll(m) : ja;
+                m &= m - 1;
+                const float4 Aa = sR[3 * ja], Ab = sR[3 * jb];
+                const float4 Ba = sR[3 * ja + 1], Bb = sR[3 * jb + 1];
+                const float ca = sR[3 * ja + 2].x, cbb = sR[3 * jb + 2].x;
+                const float dxa = Aa.x - pxf, dya = Aa.y - pyf;
+                const float dxb = Ab.x - pxf, dyb = Ab.y - pyf;
+                const float power_a = (Aa.z * dxa + Aa.w * dya) * dxa + (Ba.x * dya) * dya;
+                const float power_b = (Ab.z * dxb + Ab.w * dyb) * dxb + (Bb.x * dyb) * dyb;
+                const float alpha_a = fminf(0.99f, Ba.y * __builtin_amdgcn_exp2f(power_a));
+                const float alpha_b = fminf(0.99f, Bb.y * __builtin_amdgcn_exp2f(power_b));
+                const unsigned long long geo_a = __builtin_amdgcn_ballot_w64(!(power_a > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha_a < 1.0f / 255.0f));
+                const unsigned long long geo_b = __builtin_amdgcn_ballot_w64(!(power_b > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha_b < 1.0f / 255.0f)) &
+                                                 (two ? ~0ull : 0ull);
+                {
+                    const unsigned long long pass = geo_a & ~done_m;
+                    const float test_T = T * (1.0f - alpha_a);
+                    const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                    const unsigned long long valid_m = pass & ~low;
+                    done_m |= pass & low;
+                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+                    const float w = valid ? alpha_a * T : 0.f;
+                    C0 += Ba.z * w;
+                    C1 += Ba.w * w;
+                    C2 += ca * w;
+                    T = valid ? test_T : T;
+                    last_contributor = valid ? base + (unsigned)ja + 1u : last_contributor;
+                }
+                {
+                    const unsigned long long pass = geo_b & ~done_m;
+                    const float test_T = T * (1.0f - alpha_b);
+                    const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                    const unsigned long long valid_m = pass & ~low;
+                    done_m |= pass & low;
+                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+                    const float w = valid ? alpha_b * T : 0.f;
+                    C0 += Bb.z * w;
+                    C1 += Bb.w * w;
+                    C2 += cbb * w;
+                    T = valid ? test_T : T;
+                    last_contributor = valid ? base + (unsigned)jb + 1u : last_contributor;
+                }
+            }
+            // the boundary behind this sub-block: entries processed so far = 64 i + 32 (sb + 1) (u = 32) or 64 (i + 1)
+            const int processed = (i << 6) + ((sb + 1) << (nsub == 2 ? 5 : 6));
+            if ((processed & ((1 << ulen_log) - 1)) == 0 && processed < n) {
+                cbase[(size_t)(processed >> ulen_log) * 256] = make_float4(T, C0, C1, C2);
+                s_next = (processed >> ulen_log) + 1;
+            }
+        }
+    }
+    {
+        const unsigned mx = wave_max_u32(inside ? last_contributor : 0u);
+        if (lane == 0) sMaxC[wv] = mx;
+        __syncthreads();
+        const unsigned np = min(max(max(sMaxC[0], sMaxC[1]), max(sMaxC[2], sMaxC[3])), (unsigned)n);
+        if (threadIdx.x == 0) nproc_out[tile] = np;
+        const unsigned ulen = 1u << ulen_log;
+        const unsigned nunits = n > 0 ? max(1u, (np + ulen - 1u) >> ulen_log) : 0u;
+        // boundaries 1 .. nunits - 1 are read by the backward: the ones this wave did not reach get its final state (it left the loop
+        // with every pixel terminated -- or at the end of the list, where nothing is missing)
+        for (int s = s_next; s < (int)nunits; s++) cbase[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+        if (n > 0) {
+            const unsigned tag = (unsigned)tile | (shortlist ? 0x80000000u : 0u);
+            if (threadIdx.x == 0) {
+                sUnitBase = nunits > 1u ? atomicAdd(&uctl[0], nunits - 1u) : 0u;
+                const unsigned bl = atomicAdd(&uctl[DGM_UCTL_LINE], 1u);
+                ulist_last[bl] = make_uint4(tag, nunits - 1u, range.x, np);
+            }
+            __syncthreads();
+            uint4* dst = ulist_full + sUnitBase;
+            for (unsigned k = threadIdx.x; k + 1u < nunits; k += 256u) dst[k] = make_uint4(tag, k, range.x, np);
+        }
+    }
+    {
+        const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
+        cfin[(size_t)tile * 256 + (size_t)((ly >> 2) * 64 + ((ly & 3) << 4) + lx)] = make_float4(T, C0, C1, C2);
+    }
+    if (inside) {
+        const size_t pid = (size_t)W * py + px;
+        const size_t plane = (size_t)W * H;
+        final_T[pid] = T;
+        n_contrib[pid] = last_contributor;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[plane + pid] = C1 + T * bg[1];
+        out_color[2 * plane + pid] = C2 + T * bg[2];
+    }
+}
+
 #if RF_TRACE
 }  // namespace dgm
 extern "C" int dgm_debug_rf_trace(void* dst, size_t bytes, int reset) {
@@ -281,7 +458,12 @@ void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const uns
                        unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, size_t R, unsigned* uctl,
                        uint4* ulist_full, uint4* ulist_last, uint8_t* live) {
     const int ulog = replay_unit_log2(R);
-    if (ulog < 6)  // sparse frame
+    // sparse frames: the asynchronous-quadrant kernel (DGM_RF_SPARSE=sync selects round 5's barrier-per-round form, for A/B runs)
+    static const bool sparse_sync = [] { const char* e = getenv("DGM_RF_SPARSE"); return e && strcmp(e, "sync") == 0; }();
+    if (ulog < 6 && !sparse_sync)
+        hipLaunchKernelGGL(render_fwd_async_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
+                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
+    else if (ulog < 6)
         hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
                            out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
     else

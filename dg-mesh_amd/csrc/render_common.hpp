@@ -61,6 +61,16 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float a, flo
     return m;
 }
 
+// The same test for ONE 8x8 block of pixel centres with its first pixel at (qx0, qy0): the culling unit of a wave that stages for itself
+// (render_fwd_async_kernel).
+__device__ __forceinline__ bool quadrant_hit(float x, float y, float a, float b, float c, float o, float qx0, float qy0) {
+    const float o255 = o * 255.0f;
+    if (o255 < 1.0f) return false;
+    const float tau = 2.0f * __logf(o255) * 1.001f + 0.01f;
+    const float ra = __builtin_amdgcn_rcpf(a), rc = __builtin_amdgcn_rcpf(c);
+    return !(rect_min_q(x, y, a, b, c, ra, rc, qx0, qx0 + 7.0f, qy0, qy0 + 7.0f) > tau);
+}
+
 // offs[g] + k: the row of Gaussian g's instance on tile (tile_x, tile_y) in the per-Gaussian order -- k counts the tiles of its rectangle
 // row by row, as binning.hip's count / scatter walk them.  rect = rec[g][9] (pack_rect), offs = rec[g][10]: the backward gets both with
 // the third 16-byte load of the splat's record, so the (R x 4)-byte array rounds 2-4 carried through the tile sort is gone.

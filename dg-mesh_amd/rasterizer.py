@@ -79,12 +79,130 @@ def _bucket(nbytes):
     return ((n + (1 << k) - 1) >> k) << k
 
 
+_BIN_CAPACITY = {}  # device index -> bytes: capacity the binning buffers of that device are allocated with
+
+
+def _binning_capacity(device_index, nbytes):
+    """Bytes to allocate for a binning buffer that must hold `nbytes`: a per-device capacity that only moves when a frame does not
+    fit (then to the bucket of 1.25 x the need: headroom for the frames that follow) or needs less than a quarter of it.  R differs
+    from view to view by a few per cent; with sizes that follow it a new maximum late in a run misses torch's caching allocator and
+    costs a hipMalloc (~6 ms for this buffer at cfg2: 9 % of a 20-step timed region) -- with one capacity per device every forward
+    asks for the same block and the allocator hands the previous step's back."""
+    n = int(nbytes)
+    cur = _BIN_CAPACITY.get(device_index, 0)
+    if n > cur or 4 * n < cur:
+        cur = _bucket(n + n // 4)
+        _BIN_CAPACITY[device_index] = cur
+    return cur
+
+
 def _resizer(t, bucket=False):
     """resizeFunctional (DGR/rasterize_points.cu:27-33): grow a byte tensor, hand back its device pointer."""
     def cb(_ctx, nbytes):
-        t.resize_(_bucket(nbytes) if bucket else int(nbytes))
+        t.resize_(_binning_capacity(t.device.index or 0, nbytes) if bucket else int(nbytes))
         return t.data_ptr()
     return _lib.ALLOC_FN(cb)
+
+
+# ---- the forward without the host round trip (dgm_rasterize_forward_capacity; DGM_SYNC_FREE=1 or rasterizer.SYNC_FREE = True) --------
+# The binning buffer is sized for a CAPACITY of tile instances (1.25 x the largest R seen on the device, a few sizes per octave) before
+# the frame's R is known; the call only enqueues, {R, flags} arrive in page-locked memory behind an event.  By default the wrapper
+# waits for that event AFTER everything of the forward is enqueued (the GPU never idles waiting for the host; callers still get the
+# true R and never see an overflowed frame: it is rendered again, transparently, with a larger capacity).  With DEFER_SETTLE set (the
+# training loop) the forward returns at once and `settle()` is called after the backward has been enqueued: the host then waits on
+# an event that has long fired.  The first frame on a device runs the synchronous protocol once to learn R.
+import os as _os
+
+SYNC_FREE = _os.environ.get("DGM_SYNC_FREE") == "1"
+DEFER_SETTLE = False
+SETTLE_WAIT_SECONDS = 0.0       # host time spent waiting in settle() / the inline wait (bench.py reports it)
+OVERFLOW_REDOS = 0              # frames rendered again because R exceeded the capacity
+INJECT_CAPACITY = 0             # test hook: the next capacity-mode forward uses this capacity (then the hook clears itself)
+_SF = {}                        # device index -> {"cap": capacity in instances, "words": pinned int32[4], "event": torch.cuda.Event}
+_PENDING = None                 # (device index, capacity) of a forward whose words have not been looked at yet
+_CAP_OF = {}                    # data_ptr of a capacity-mode binning buffer -> (capacity, true R, numel): the reference-shaped API hands
+                                # the backward ONE integer, the true R; the layout follows the capacity
+
+
+def _sf_state(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SF.get(idx)
+    if st is None:
+        st = _SF[idx] = {"cap": 0, "words": torch.zeros(4, dtype=torch.int32).pin_memory(), "event": torch.cuda.Event(), "idx": idx}
+    return st
+
+
+def _capacity_for(R):
+    """Capacity (tile instances) for a frame of R: 1.25 x, rounded up to m * 2^k, m in 8..15 -- the sizes _bucket() gives bytes."""
+    n = max(int(R) + int(R) // 4, 4096)
+    k = max(n.bit_length() - 4, 0)
+    return ((n + (1 << k) - 1) >> k) << k
+
+
+def _fixed_resizer(t, nbytes_cap):
+    def cb(_ctx, nbytes):
+        if int(nbytes) > nbytes_cap:
+            raise RuntimeError("capacity-mode binning buffer smaller than the layout asks for")
+        t.resize_(nbytes_cap)
+        return t.data_ptr()
+    return _lib.ALLOC_FN(cb)
+
+
+def _read_words(st):
+    w = st["words"]
+    return int(w[0]) & 0xffffffff, int(w[1])
+
+
+def settle():
+    """Look at the words of the most recent capacity-mode forward (waits for its event).  True: the frame is good (LAST_NUM_RENDERED
+    is its R).  False: R exceeded the capacity -- the frame was neutralised on the device, the capacity has been raised, render it
+    again.  No pending forward: True."""
+    global _PENDING, LAST_NUM_RENDERED, SETTLE_WAIT_SECONDS, OVERFLOW_REDOS
+    if _PENDING is None:
+        return True
+    idx, cap = _PENDING
+    _PENDING = None
+    st = _SF[idx]
+    t0 = time.perf_counter()
+    st["event"].synchronize()
+    SETTLE_WAIT_SECONDS += time.perf_counter() - t0
+    R, flags = _read_words(st)
+    if flags & 2:
+        st["cap"] = max(st["cap"], _capacity_for(R))
+        OVERFLOW_REDOS += 1
+        return False
+    if flags & 1:
+        raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    LAST_NUM_RENDERED = R
+    return True
+
+
+def _forward_dispatch(dev, binning, run_sync, run_cap):
+    """run_sync(binning_callback) -> R issues the synchronous C call; run_cap(binning_callback, capacity, words_ptr) the capacity one.
+    Returns (R or None when deferred, R the layout / the backward follows)."""
+    global _PENDING, INJECT_CAPACITY, LAST_NUM_RENDERED
+    if not SYNC_FREE:
+        R = run_sync(_resizer(binning, bucket=True))
+        LAST_NUM_RENDERED = R
+        return R, R
+    st = _sf_state(dev)
+    if st["cap"] == 0 and not INJECT_CAPACITY:  # first frame on this device: the reference's protocol once, to learn R
+        R = run_sync(_resizer(binning, bucket=True))
+        st["cap"] = _capacity_for(R)
+        LAST_NUM_RENDERED = R
+        return R, R
+    settle()  # (a deferred frame nobody settled: its words are about to be overwritten)
+    while True:
+        cap = INJECT_CAPACITY or st["cap"]
+        INJECT_CAPACITY = 0
+        nbytes = int(_lib.lib().dgm_binning_bytes(cap)) + 256
+        run_cap(_fixed_resizer(binning, nbytes), cap, ctypes.c_void_p(st["words"].data_ptr()))
+        st["event"].record(torch.cuda.current_stream(dev))
+        _PENDING = (st["idx"], cap)
+        if DEFER_SETTLE:
+            return None, cap
+        if settle():
+            return LAST_NUM_RENDERED, cap
 
 
 class _CModule:
@@ -111,19 +229,43 @@ class _CModule:
         img = torch.empty((0,), dtype=torch.uint8, device=dev)
         M = sh.size(1) if sh is not None and sh.numel() != 0 else 0
         rendered = ctypes.c_int(0)
-        cbs = (_resizer(geom), _resizer(binning, bucket=True), _resizer(img))
-        t_call = time.perf_counter()
-        with _lib.device_guard(dev):
+        cb_g, cb_i = _resizer(geom), _resizer(img)
+        keep = [cb_g, cb_i]  # (the ctypes callbacks must outlive the call)
+
+        def run_sync(cb_b):
+            keep.append(cb_b)
             _lib.check(L.dgm_rasterize_forward(
-                cbs[0], None, cbs[1], None, cbs[2], None, P, int(degree), M, _ptr(background), W, H, _ptr(means3D),
+                cb_g, None, cb_b, None, cb_i, None, P, int(degree), M, _ptr(background), W, H, _ptr(means3D),
                 _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
                 _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), _ptr(out_color), _ptr(radii), int(bool(debug)), _stream(),
                 ctypes.byref(rendered)))
-        global LAST_NUM_RENDERED, FORWARD_CALL_SECONDS
-        LAST_NUM_RENDERED = rendered.value
-        FORWARD_CALL_SECONDS += time.perf_counter() - t_call  # contains the step's only host<->device sync (R read-back)
-        return rendered.value, out_color, radii, geom, binning, img
+            return rendered.value
+
+        def run_cap(cb_b, cap, words):
+            keep.append(cb_b)
+            _lib.check(L.dgm_rasterize_forward_capacity(
+                cb_g, None, cb_b, None, cb_i, None, P, int(degree), M, _ptr(background), W, H, _ptr(means3D),
+                _ptr(sh), None, _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                int(bool(prefiltered)), _ptr(out_color), _ptr(radii), int(bool(debug)), _stream(), int(cap), words))
+
+        global FORWARD_CALL_SECONDS
+        t_call = time.perf_counter()
+        defer = DEFER_SETTLE
+        with _lib.device_guard(dev):
+            if P == 0 or not SYNC_FREE or defer:  # (this entry hands the caller the true R: it always settles before it returns)
+                R_true = run_sync(_resizer(binning, bucket=True))
+                global LAST_NUM_RENDERED
+                LAST_NUM_RENDERED = R_true
+            else:
+                R_true, R_layout = _forward_dispatch(dev, binning, run_sync, run_cap)
+                if R_layout != R_true:
+                    if len(_CAP_OF) > 64:
+                        _CAP_OF.clear()
+                    _CAP_OF[binning.data_ptr()] = (R_layout, R_true, binning.numel())
+        FORWARD_CALL_SECONDS += time.perf_counter() - t_call  # (synchronous protocol: contains the step's only host<->device sync)
+        return R_true, out_color, radii, geom, binning, img
 
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
@@ -147,6 +289,9 @@ class _CModule:
         dL_dscales, dL_drotations = new(P, 3), new(P, 4)
         sh_active = M > 0 and (colors is None or colors.numel() == 0)
         dL_dsh = new(P, M, 3) if sh_active else torch.zeros((P, M, 3), dtype=torch.float32, device=dev)
+        cap = _CAP_OF.get(binningBuffer.data_ptr()) if binningBuffer is not None and binningBuffer.numel() else None
+        if cap is not None and cap[1] == int(R) and cap[2] == binningBuffer.numel():
+            R = cap[0]  # a capacity-mode forward: the layout follows the capacity, not the frame's R
         if P != 0:
             with _lib.device_guard(dev):
                 _lib.check(L.dgm_rasterize_backward(
@@ -263,18 +408,35 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         geom, binning, img = (torch.empty((0,), dtype=torch.uint8, device=dev) for _ in range(3))
         M = 1 + sh_rest.shape[1]
         rendered = ctypes.c_int(0)
-        cbs = (_resizer(geom), _resizer(binning, bucket=True), _resizer(img))
-        t_call = time.perf_counter()
-        with _lib.device_guard(dev):
+        cb_g, cb_i = _resizer(geom), _resizer(img)
+        keep = [cb_g, cb_i]
+
+        def run_sync(cb_b):
+            keep.append(cb_b)
             _lib.check(L.dgm_rasterize_forward_split_sh(
-                cbs[0], None, cbs[1], None, cbs[2], None, P, int(rs.sh_degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh_dc),
+                cb_g, None, cb_b, None, cb_i, None, P, int(rs.sh_degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh_dc),
                 _ptr(sh_rest), None, _ptr(opacities), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), None, _ptr(view),
                 _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), _ptr(out_color),
                 _ptr(radii), int(bool(rs.debug)), _stream(), ctypes.byref(rendered)))
-        global LAST_NUM_RENDERED, FORWARD_CALL_SECONDS
-        LAST_NUM_RENDERED = rendered.value
+            return rendered.value
+
+        def run_cap(cb_b, cap, words):
+            keep.append(cb_b)
+            _lib.check(L.dgm_rasterize_forward_capacity(
+                cb_g, None, cb_b, None, cb_i, None, P, int(rs.sh_degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh_dc),
+                _ptr(sh_rest), None, _ptr(opacities), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), None, _ptr(view),
+                _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), _ptr(out_color),
+                _ptr(radii), int(bool(rs.debug)), _stream(), int(cap), words))
+
+        global FORWARD_CALL_SECONDS
+        t_call = time.perf_counter()
+        with _lib.device_guard(dev):
+            if P == 0:
+                R_layout = run_sync(_resizer(binning, bucket=True))
+            else:
+                _, R_layout = _forward_dispatch(dev, binning, run_sync, run_cap)
         FORWARD_CALL_SECONDS += time.perf_counter() - t_call
-        ctx.raster_settings, ctx.num_rendered, ctx.consts = rs, rendered.value, (bg, view, proj, campos)
+        ctx.raster_settings, ctx.num_rendered, ctx.consts = rs, R_layout, (bg, view, proj, campos)
         ctx.save_for_backward(means3D, scales, rotations, radii, sh_dc, sh_rest, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return out_color, radii

@@ -39,6 +39,7 @@ import random
 import torch
 import torch.distributed as dist
 
+from . import rasterizer as _RZ
 from . import scene as S
 
 
@@ -429,22 +430,40 @@ class Trainer:
                 m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
             g.oneupSHdegree()
-        cam = self.cameras[frame_schedule(len(self.cameras), self.step_count, self.rank, self.world, self.seed)]
-        if self.pack:
-            for p in self.params:
-                p.grad = None
+        self.last_frame = frame_schedule(len(self.cameras), self.step_count, self.rank, self.world, self.seed)
+        cam = self.cameras[self.last_frame]
+        # Sync-free rasterizer forward (rasterizer.SYNC_FREE / DGM_SYNC_FREE=1): the forward only enqueues; whether the frame fitted
+        # the binning buffer's capacity is looked at here, AFTER the backward has been enqueued -- the event has long fired, the host
+        # does not wait and the GPU never idles -- and BEFORE anything consumes the gradients: a frame that did not fit was neutralised
+        # on the device, so its gradients are discarded and the frame is rendered again with the raised capacity.  (With the
+        # Gaussian bucket's early all-reduce armed the check stays inside the forward call: a discarded backward must not have
+        # started a collective the other ranks do not repeat.)
+        defer = _RZ.SYNC_FREE and not (self.world > 1 and self._early is not None)
+        for _attempt in range(4):
+            if self.pack:
+                for p in self.params:
+                    p.grad = None
+            else:
+                self.bucket.zero()
+            _RZ.DEFER_SETTLE = defer
+            try:
+                losses, pkg = self.loss_terms(cam, iteration)
+                terms = list(losses.values())
+                loss = terms[0]
+                for t in terms[1:]:  # (not sum(): its 0 + ... start is one more launch)
+                    loss = loss + t
+                if self._early is not None:
+                    self._early.update(left=self._early["n"], work=None, views=None, armed=True)
+                loss.backward()
+                if self._early is not None:
+                    self._early["armed"] = False
+            finally:
+                _RZ.DEFER_SETTLE = False
+            if not defer or _RZ.settle():
+                break
+            self.redone_frames = getattr(self, "redone_frames", 0) + 1
         else:
-            self.bucket.zero()
-        losses, pkg = self.loss_terms(cam, iteration)
-        terms = list(losses.values())
-        loss = terms[0]
-        for t in terms[1:]:  # (not sum(): its 0 + ... start is one more launch)
-            loss = loss + t
-        if self._early is not None:
-            self._early.update(left=self._early["n"], work=None, views=None, armed=True)
-        loss.backward()
-        if self._early is not None:
-            self._early["armed"] = False
+            raise RuntimeError("rasterizer capacity: a frame overflowed four times in a row")
         rebound = False
         if self.track_stats and iteration < self.opt.densify_until_iter:  # R/train.py:488-496
             g.track_densification_stats(pkg.get("viewspace_points"), pkg.get("visibility_filter"), pkg["radii"])

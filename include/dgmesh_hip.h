@@ -50,8 +50,10 @@ extern "C" {
 /* ABI history (a binding must check dgm_abi_version() against the header it was generated from):
  *   3: dgm_knn_mean_dist2 takes a caller-owned scratch buffer (dgm_knn_scratch_bytes); two replay-unit lists in dgm_state_layout.
  *   4: dgm_state_layout lost `upos` and `block_offs`, `inst` became uint2[R] (8-byte instance records; the backward forms the
- *      gradient row of an instance itself); dgm_laplace_* added.  Entry points' signatures are unchanged from 3. */
-#define DGM_ABI_VERSION 4
+ *      gradient row of an instance itself); dgm_laplace_* added.  Entry points' signatures are unchanged from 3.
+ *   5: dgm_rasterize_forward_capacity added (a forward that never waits for the device); dgm_mlp_set_gemm knows modes 4 and 5.
+ *      Every entry point of 4 is unchanged. */
+#define DGM_ABI_VERSION 5
 
 /* Allocator callback: must return a device pointer to at least `bytes` bytes (128-byte aligned),
  * valid until the matching backward has run.  Mirrors resizeFunctional, rasterize_points.cu:27-33. */
@@ -97,6 +99,24 @@ int dgm_rasterize_forward_split_sh(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_
                                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                                    float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
                                    int* num_rendered);
+/* The forward WITHOUT the host round trip (round 6).  Replaces -- and improves on -- the one blocking step of
+ * CudaRasterizer::Rasterizer::forward, DGR/cuda_rasterizer/rasterizer_impl.cu:281 (`cudaMemcpy(&num_rendered, ...)` between the
+ * scan and the allocation of the binning state): the caller sizes the binning buffer for `capacity` tile instances UP FRONT (e.g.
+ * 1.25 x the previous frame's R), every array offset follows dgm_describe_state(P, width, height, capacity), and the call only
+ * enqueues.  {R, flags, two worklist lengths} are copied to host_result[0..3] (caller-owned, page-locked host memory) behind the
+ * scan; they are valid once an event the caller records after this call has completed.  flags bit 0: "point is filtered although
+ * prefiltered is set" (auxiliary.h:156-160; the synchronous calls fail on it); bit 1: R > capacity -- the frame was neutralised on
+ * the device (no tile has a range, no Gaussian a tile: image = background, the backward writes zero gradients, nothing is written
+ * or read beyond `capacity` rows) and must be rendered again with capacity >= host_result[0].  The matching backward call takes
+ * R = capacity.  Otherwise exactly dgm_rasterize_forward_split_sh (shs_rest may be NULL). */
+int dgm_rasterize_forward_capacity(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn binning_alloc, void* binning_ctx,
+                                   dgm_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                                   int width, int height, const float* means3D, const float* shs, const float* shs_rest,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                                   int capacity, unsigned* host_result);
 int dgm_rasterize_backward_split_sh(int P, int D, int M, int R, const float* background, int width, int height,
                                     const float* means3D, const float* shs, const float* shs_rest,
                                     const float* colors_precomp, const float* scales, float scale_modifier,

@@ -84,6 +84,34 @@ def mlp_full_gradient_golden():
     print("wrote full gradients", os.path.getsize(os.path.join(HERE, "mlp_full_grads_DeformNetworkNormal_blender.npz")) // 1024, "KiB")
 
 
+def mlp_full_gradient_goldens_all():
+    """Every gradient tensor IN FULL for ALL eight (class, dataset) pairs of mlp_goldens() -- same seeds, same N = 33 inputs, same
+    loss weights: `mlp_fullgrads_<class>_<dataset>.npz` holds exactly the tensors of which mlp_<class>_<dataset>.npz keeps the norm
+    and the first 24 elements (float32; gradients do not compress: ~1.7 MB each)."""
+    sys.path.insert(0, "/root/reference/dgmesh")
+    from utils import time_utils as ref
+
+    rng = np.random.RandomState(0)
+    N = 33
+    x = ((rng.rand(N, 3) * 2 - 1) * 1.3).astype(np.float32)
+    for cls in ("DeformNetwork", "DeformNetworkNormal", "DeformNetworkNormalSep", "AppearanceNetwork"):
+        for blender in (True, False):
+            torch.manual_seed(0)
+            net = getattr(ref, cls)(is_blender=blender)
+            if cls == "DeformNetworkNormalSep":
+                torch.manual_seed(1)
+                torch.nn.init.normal_(net.gaussian_normal.weight, std=0.05)
+            t = torch.tensor([[0.37]]).expand(N, -1)
+            out = net(torch.tensor(x), t)
+            outs = list(out) if isinstance(out, tuple) else [out]
+            g = torch.Generator().manual_seed(5)
+            sum((o * torch.randn(o.shape, generator=g)).sum() for o in outs).backward()
+            rec = {"grad/" + name: p.grad.detach().numpy() for name, p in net.named_parameters() if p.grad is not None}
+            path = os.path.join(HERE, f"mlp_fullgrads_{cls}_{'blender' if blender else 'real'}.npz")
+            np.savez_compressed(path, **rec)
+            print("wrote", os.path.basename(path), os.path.getsize(path) // 1024, "KiB", len(rec), "tensors")
+
+
 def raster_golden():
     syn = importlib.import_module("dg-mesh_amd.synthetic")
     from oracle import oracle as orc
@@ -307,6 +335,8 @@ if __name__ == "__main__":
         mlp_goldens()
     if not which or "mlp_full" in which:
         mlp_full_gradient_golden()
+    if not which or "mlp_full_all" in which:
+        mlp_full_gradient_goldens_all()
     if not which or "raster" in which:
         raster_golden()
     if not which or "state_dict" in which:

@@ -28,8 +28,11 @@ def hip_forward(a, debug=False):
         tens["cov"], tens["vm"], tens["pm"], a["tanfovx"], a["tanfovy"], H, W, tens["sh"], a["degree"], tens["campos"],
         False, debug)
     torch.cuda.synchronize()
+    # (capacity-mode forwards -- rasterizer.SYNC_FREE -- lay the binning buffer out for their capacity, not for the frame's R)
+    cap_entry = R._CAP_OF.get(binning.data_ptr()) if binning.numel() else None
+    n_layout = cap_entry[0] if cap_entry is not None and cap_entry[1] == n and cap_entry[2] == binning.numel() else n
     lay = L.StateLayout()
-    L.check(L.lib().dgm_describe_state(P, W, H, n, ctypes.byref(lay)))
+    L.check(L.lib().dgm_describe_state(P, W, H, n_layout, ctypes.byref(lay)))
     out = dict(num_rendered=n, color=color.cpu().numpy(), radii=radii.cpu().numpy(), tensors=tens,
                buffers=(geom, binning, img), layout=lay)
     if P == 0:
@@ -55,8 +58,8 @@ def hip_forward(a, debug=False):
         n_contrib=view(img, lay.n_contrib, np.uint32, W * H).reshape(H, W),
         ranges=view(img, lay.ranges, np.uint32, tiles * 2).reshape(tiles, 2))
     if n > 0:
-        ulog = 5 if n < (1 << 20) else 6
-        cap = (n >> ulog) + 1
+        ulog = 5 if n_layout < (1 << 20) else 6
+        cap = (n_layout >> ulog) + 1
         point_list = view(binning, lay.point_list, np.uint32, n)
         # the gradient row of every list entry as render_bwd4 forms it (render_common.hpp instance_row): offs[g] + the position of the
         # entry's tile in g's rectangle, row by row

@@ -10,13 +10,14 @@ within 1e-4 fp32.  Concretely:
   * out_color / final_T: |err| <= 1e-4 on pixels without a fragile alpha decision;
   * gradients: max|err| <= 1e-4 * max|ref| per tensor (plus 1e-4 relative).
 """
+import ctypes
 import math
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import oracle_backward, oracle_forward, raster_args
+from conftest import oracle_backward, oracle_forward, pkg, raster_args
 import gpu_util as G
 
 pytestmark = pytest.mark.gpu
@@ -525,3 +526,96 @@ def test_knn_exact(orc, syn):
     pts = (v / np.linalg.norm(v, axis=1, keepdims=True) * 0.8).astype(np.float32)
     got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), orc.knn(pts).view(np.uint32))
+
+
+# ---- the forward without the host round trip (dgm_rasterize_forward_capacity; rasterizer.SYNC_FREE) ---------------------------------
+@pytest.fixture
+def sync_free():
+    R = pkg("rasterizer")
+    prev = (R.SYNC_FREE, dict(R._SF))
+    R.SYNC_FREE = True
+    R._SF.clear()
+    yield R
+    R.SYNC_FREE = prev[0]
+    R._SF.clear()
+    R._SF.update(prev[1])
+    R.INJECT_CAPACITY = 0
+
+
+@pytest.mark.parametrize("kind,P,W,H,seed", [("init", 3000, 200, 136, 1), ("trained", 4000, 160, 160, 3), ("init", 20000, 400, 400, 0)])
+def test_capacity_forward_equals_the_synchronous_one(orc, syn, sync_free, kind, P, W, H, seed):
+    """The same frame through dgm_rasterize_forward (R read back, buffer sized with it) and through
+    dgm_rasterize_forward_capacity (buffer sized for 1.25 x the previous R, nothing waits): image, radii, R, the sorted lists and
+    ranges are BIT-identical, the gradients too (same replay-unit size on both sides here) -- and both pass the oracle checks."""
+    R = sync_free
+    a = raster_args(syn, P, W, H, seed=seed, kind=kind)
+    R.SYNC_FREE = False
+    f0 = G.hip_forward(a)
+    R.SYNC_FREE = True
+    f1 = G.hip_forward(a)   # first capacity-mode call on the device: the synchronous protocol once, to learn R
+    assert R._SF and all(st["cap"] >= f0["num_rendered"] for st in R._SF.values())
+    f2 = G.hip_forward(a)   # capacity mode proper
+    assert f2["layout"].binning_bytes >= f0["layout"].binning_bytes and f2["num_rendered"] == f0["num_rendered"]
+    for f in (f1, f2):
+        for k in ("color", "radii", "point_list", "ranges", "n_contrib", "final_T"):
+            assert np.array_equal(f[k], f0[k]), k
+    f_or = oracle_forward(orc, a)
+    check_forward(orc, a, f2)
+    rng = np.random.RandomState(seed)
+    dL = rng.randn(3, H, W).astype(np.float32)
+    g0, g2 = G.hip_backward(a, f0, dL), G.hip_backward(a, f2, dL)
+    same_units = f0["unit_log2"] == f2["unit_log2"]
+    for k in g0:
+        if same_units:
+            assert np.array_equal(g0[k], g2[k]), k
+        else:
+            assert G.rel_to_max(g2[k], g0[k]) < 1e-5, k
+    check_backward(orc, a, f_or, f2, seed=seed)
+
+
+def test_capacity_overflow_is_caught_and_the_frame_rendered_again(orc, syn, sync_free):
+    """A frame that does not fit its capacity (injected: a third of R) is neutralised on the device -- nothing is written beyond the
+    buffer -- flagged, and rendered again by the wrapper with the raised capacity: the caller sees the correct frame."""
+    R = sync_free
+    a = raster_args(syn, 20000, 400, 400, seed=0, kind="init")
+    R.SYNC_FREE = False
+    f0 = G.hip_forward(a)
+    R.SYNC_FREE = True
+    G.hip_forward(a)
+    redos = R.OVERFLOW_REDOS
+    R.INJECT_CAPACITY = max(f0["num_rendered"] // 3, 4096)
+    f1 = G.hip_forward(a)
+    assert R.OVERFLOW_REDOS == redos + 1 and R.INJECT_CAPACITY == 0
+    for k in ("color", "radii", "point_list", "ranges", "n_contrib"):
+        assert np.array_equal(f1[k], f0[k]), k
+    # the raw C call on an undersized buffer: flagged, background image, zero gradients, canaries behind the buffer intact
+    L = pkg("_lib")
+    lib = L.lib()
+    tn = f0["tensors"]
+    P, W, H = a["means3D"].shape[0], a["W"], a["H"]
+    cap = max(f0["num_rendered"] // 3, 4096)
+    nbytes = int(lib.dgm_binning_bytes(cap)) + 256
+    binning = torch.full((nbytes + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
+    geom, img = torch.empty(0, dtype=torch.uint8, device="cuda"), torch.empty(0, dtype=torch.uint8, device="cuda")
+    words = torch.zeros(4, dtype=torch.int32).pin_memory()
+    color = torch.empty(3, H, W, device="cuda")
+    radii = torch.empty(P, dtype=torch.int32, device="cuda")
+    cb_g, cb_i = R._resizer(geom), R._resizer(img)
+    cb_b = L.ALLOC_FN(lambda _c, n: binning.data_ptr() if n <= nbytes else 0)
+    vp = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None and x.numel() else None
+    L.check(lib.dgm_rasterize_forward_capacity(
+        cb_g, None, cb_b, None, cb_i, None, P, a["degree"], a["sh"].shape[1], vp(tn["bg"]), W, H, vp(tn["means3D"]), vp(tn["sh"]), None,
+        None, vp(tn["opac"]), vp(tn["scales"]), float(a["scale_modifier"]), vp(tn["rots"]), None, vp(tn["vm"]), vp(tn["pm"]),
+        vp(tn["campos"]), float(a["tanfovx"]), float(a["tanfovy"]), 0, vp(color), vp(radii), 0, L.stream_ptr(), cap, vp(words)))
+    torch.cuda.synchronize()
+    assert (int(words[0]) & 0xffffffff) == f0["num_rendered"] and int(words[1]) & 2
+    assert bool((binning[nbytes:] == 0x5A).all())
+    bg = torch.as_tensor(a["bg"], device="cuda").reshape(3, 1, 1)
+    assert torch.equal(color, bg.expand(3, H, W))
+    dL = torch.randn(3, H, W, device="cuda")
+    g = R._C.rasterize_gaussians_backward(tn["bg"], tn["means3D"], radii, tn["colors"], tn["scales"], tn["rots"], a["scale_modifier"],
+                                          tn["cov"], tn["vm"], tn["pm"], a["tanfovx"], a["tanfovy"], dL, tn["sh"], a["degree"],
+                                          tn["campos"], geom, cap, binning[:nbytes], img, False)
+    torch.cuda.synchronize()
+    assert all(float(x.abs().max()) == 0.0 for x in g)
+    assert bool((binning[nbytes:] == 0x5A).all())

@@ -25,7 +25,7 @@ def test_build_and_exports():
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dgm_abi_version() == 4
+    assert lib.dgm_abi_version() == 5
     names = [lib.dgm_stage_name(i).decode() for i in range(L.STAGE_COUNT)]
     assert names[0] == "preprocess_fwd" and names[7] == "preprocess_bwd" and names[-2] == "mlp_layer_dw" and names[-1] == "mlp_bwd_pair"
 
