@@ -376,9 +376,15 @@ def main():
     if args.phase == "mesh":     # every network on, positions unfrozen (it >= dpsr_iter + max(normal_warm_up, 2000))
         it0 = tr.opt.dpsr_iter + importlib.import_module("dg-mesh_amd.trainer").normal_deform_delay(tr.opt) + 1000
 
-    for i in range(10):  # allocator / code-object / clock priming (untimed)
+    # allocator / code-object / clock priming (untimed, before the W warm-up steps): three steps, then the set-up's 267 k objects are
+    # frozen out of the cyclic collector (a full pass costs ~80 ms here) -- the collection that precedes the freeze returns blocks to
+    # the caching allocator and the next five steps run 5-25 % slow while it re-forms its pools (tools/step_times.py), so the freeze
+    # comes BEFORE the rest of the priming, not between priming and warm-up as in rounds 4-5 -- then 30 more steps (0.1 s)
+    for i in range(3):
         tr.step(it0)
-    tr.freeze_gc()  # (a full cyclic-GC pass costs ~80 ms here: keep the set-up's 267 k objects out of later collections)
+    tr.freeze_gc()
+    for i in range(30):
+        tr.step(it0)
     for i in range(args.warmup):
         tr.step(it0 + i)
     RZ = importlib.import_module("dg-mesh_amd.rasterizer")

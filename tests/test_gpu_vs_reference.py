@@ -375,7 +375,8 @@ def test_first_steps_match_the_reference_shaped_step():
     far = tot = 0
     for a, b, a0 in zip(ours.params, ref.params, p0):
         lr = lr_of.get(id(a))
-        if lr is None or lr == 0.0 or b.grad is None:  # (no gradient in this phase -- the normals -- or a frozen group: untouched on both sides)
+        if lr is None or lr == 0.0 or b.grad is None or float(b.grad.abs().max()) == 0.0:
+            # (no gradient in this phase -- the normals, the normal head --, or a frozen group: untouched on both sides)
             assert torch.equal(a.detach(), b.detach()) and torch.equal(a.detach(), a0)
             continue
         d = (a.detach() - b.detach()).abs()

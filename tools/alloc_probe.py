@@ -14,9 +14,17 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda", 0)
 tr, _ = bench.build_scene(dev, 0, 1, "hip")
 it0 = tr.opt.warm_up + 2000
+L = importlib.import_module("dg-mesh_amd._lib")
+mode = os.environ.get("PROBE_MODE", "")  # "bench": freeze the GC and switch the deferred stage timers on after 15 steps, as bench.py does
 st = lambda k: torch.cuda.memory_stats(dev).get(k, 0)
 a0, r0 = st("num_device_alloc"), st("reserved_bytes.all.current")
 for i in range(steps):
+    if mode == "bench" and i == 10:
+        tr.freeze_gc()
+    if mode == "bench" and i == 15:
+        L.lib().dgm_set_profiling_sampling(8)
+        L.lib().dgm_set_profiling(2)
+        print("profiling on at step 15")
     tr.step(it0 + i)
     torch.cuda.synchronize()
     a1, r1 = st("num_device_alloc"), st("reserved_bytes.all.current")
