@@ -276,6 +276,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 // blends), tested against its own 8 x 8 block only, no barrier inside the loop.  A tile then costs the maximum over its quadrants of
 // their own total work.  The price is four reads of the tile's list and records instead of one (L2 hits; a sparse frame leaves the
 // memory system idle).  Same per-pixel arithmetic, same order of the blends, same outputs as the kernel above -- bit-identical.
+// Measured on the trained-like scene (tools/raster_bench.py cfg2 --kind trained, one MI355X): 0.095 ms -> 0.079 ms.  (Tried on top and
+// dropped: the NEXT pair's geometry -- LDS reads, exponent, exp, alpha, threshold ballots -- formed while the current pair blends, a
+// hand-made software pipeline of the bit loop: 0.090 ms; the loop's live state doubles and the scheduler serialises it anyway.)
 // Checkpoints: a wave writes its pixels' state at the unit boundaries it passes; a quadrant whose pixels have all terminated leaves the
 // loop, and after the tile's one barrier (which yields the replay bound) fills in the boundaries up to that bound with its final state
 // -- exactly the set the backward reads.
