@@ -402,6 +402,8 @@ def main():
         t0 = time.perf_counter()
         pk = None
         for i in range(n_steps):
+            pk = None  # (let go of the previous step's render package BEFORE the next step allocates its own: holding it across
+            #            the call kept one extra set of frame tensors alive and cost the region one device allocation)
             _, pk = tr.step(first_it + i)
         torch.cuda.synchronize()
         if world > 1:

@@ -21,7 +21,7 @@ for f in ("${TAG}_bench20", "${TAG}_bench"):
     print('   stages', d['stages_ms'])
 PY
 ( cd /tmp && DGM_BENCH_STEADY_STEPS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof" -o b -- python "$GRAFT_REPO_ROOT/bench.py" --steps 200 --warmup 20 --no-extras --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.log" 2>&1 )
-f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1); python tools/prof_summary.py $f 1 50 > gpurun_out/${TAG}_bench_kernel_stats.txt; head -34 gpurun_out/${TAG}_bench_kernel_stats.txt | cut -c1-120; find gpurun_out/${TAG}_prof -name "*kernel_trace.csv" -delete
+f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1); python tools/prof_summary.py $f 1 50 200 > gpurun_out/${TAG}_bench_kernel_stats.txt; head -34 gpurun_out/${TAG}_bench_kernel_stats.txt | cut -c1-120; find gpurun_out/${TAG}_prof -name "*kernel_trace.csv" -delete
 timeout 600 python bench.py --workload cfg1 --steps 200 --no-extras > gpurun_out/${TAG}_bench_cfg1.json 2>/dev/null
 for w in cfg4 cfg5; do
   timeout 600 python bench.py --workload $w --steps 40 --warmup 10 --no-extras --no-cpu-baseline > gpurun_out/${TAG}_bench_$w.json 2>/dev/null
