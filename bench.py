@@ -154,7 +154,7 @@ def reference_host_modules():
                 sys.modules[k] = v
 
 
-def cpu_baseline(P, W, H, max_threads=32, headline_R=None, frame=0):
+def cpu_baseline(P, W, H, max_threads=32, headline_R=None, frame=0, scene=None):
     """The same train step on the host: the reference's own network and loss modules on PyTorch-CPU (this repo's torch
     restatement of them only if the byte-compiled modules are absent) around the oracle rasterizer (C, OpenMP; the reference
     has no CPU rasterizer).  A few steps of the full cfg2 workload are the bounded sample."""
@@ -166,14 +166,19 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None, frame=0):
     cores = min(os.cpu_count() or 1, max_threads)
     orc.set_threads(cores)
     torch.set_num_threads(cores)
-    xyz0 = ((np.random.RandomState(0).rand(P, 3) * 2 - 1) * 1.3).astype(np.float32)  # the points build_scene() draws
-    g = syn.make_gaussians(P, seed=0, dist2=orc.knn(xyz0))  # same initialisation as create_from_pcd (simple-knn scales)
+    if scene is not None:  # the GPU run's own Gaussians (as they stand after its timed region) and its target for that view
+        g = scene["g"]
+    else:
+        xyz0 = ((np.random.RandomState(0).rand(P, 3) * 2 - 1) * 1.3).astype(np.float32)  # the points build_scene() draws
+        g = syn.make_gaussians(P, seed=0, dist2=orc.knn(xyz0))  # same initialisation as create_from_pcd (simple-knn scales)
     cam = syn.config_camera(WORKLOAD, frame=frame)  # the view of the headline's last timed step (R differs by a few % between views)
     tanx, tany = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
     white = bool(syn.CONFIGS[WORKLOAD]["white_bg"])
     bg = np.ones(3, np.float32) if white else np.zeros(3, np.float32)
     orc.lib()
-    if TARGETS == "teacher":  # the same recipe as build_scene(): frame 0's target = the oracle's render of the perturbed copy
+    if scene is not None:
+        gt = scene["gt"]
+    elif TARGETS == "teacher":  # the same recipe as build_scene(): the view's target = the oracle's render of the perturbed copy
         at = syn.activate(syn.teacher_np(g))
         ft = orc.forward(bg, at["means3D"], None, at["opacities"], at["scales"], at["rotations"], 1.0, None, cam.world_view_transform,
                          cam.full_proj_transform, tanx, tany, H, W, at["shs"], 3, cam.camera_center)
@@ -232,8 +237,11 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None, frame=0):
     return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": kind,
             "sample": f"{n_steps} full {WORKLOAD} train steps ({W}x{H}, P={P}, R={f['num_rendered']}): oracle rasterizer "
                       f"fwd+bwd (C/OpenMP; the reference has no CPU rasterizer) + {what} + torch.optim.Adam on PyTorch-CPU, "
-                      f"{dt:.1f} s each.  Same workload recipe as the GPU headline (teacher-rendered targets, the view of its last "
-                      f"timed step -- frame {frame} --, fresh networks); "
+                      f"{dt:.1f} s each.  " + ("The GPU headline's own Gaussians (copied to the host after its timed region) and its "
+                                               f"target image for the view of its last timed step (frame {frame}); fresh networks; "
+                                               if scene is not None else
+                                               "Same workload recipe as the GPU headline (teacher-rendered targets, the view of its last "
+                                               f"timed step -- frame {frame} --, fresh networks); ") +
                       f"R here {f['num_rendered']}" + (f", the headline's last frame R={headline_R} "
                                                      f"({100.0 * (f['num_rendered'] / headline_R - 1.0):+.1f} %)" if headline_R else ""),
             "num_rendered": int(f["num_rendered"])}
@@ -461,6 +469,13 @@ def main():
 
     n_inst_timed = int(RZ.LAST_NUM_RENDERED)  # tile instances R of the timed workload's last frame (the extras below render other scenes)
     last_frame = int(getattr(tr, "last_frame", 0))
+    cpu_scene = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU leg times THIS scene: the Gaussians as the timed region left them
+        host = lambda t: t.detach().cpu().numpy().copy()
+        gm = tr.g
+        cpu_scene = {"g": dict(xyz=host(gm._xyz), features_dc=host(gm._features_dc), features_rest=host(gm._features_rest),
+                               scaling=host(gm._scaling), rotation=host(gm._rotation), opacity=host(gm._opacity)),
+                     "gt": tr.cameras[last_frame].original_image.detach().cpu().clone()}
     # gradient rows a backward of this workload writes (what preprocess_bwd reads): counted on ONE extra untimed step, the only one
     # that runs with the counting switch on
     RZ.RECORD_LIVE_ROWS = True
@@ -707,7 +722,7 @@ def main():
             out["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(P, W, H, headline_R=n_inst, frame=last_frame)
+                out["cpu_baseline"] = cpu_baseline(P, W, H, headline_R=n_inst, frame=last_frame, scene=cpu_scene)
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         if WORKLOAD == "cfg2":  # informational, offline: the reference's own step on this GPU model (a -m gpu test measures it)
