@@ -71,8 +71,8 @@ def test_rccl_world2_step(overlap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,steps", [("cfg1", 6), ("cfg2", 8)])
-def test_bench_gpus_flag_launches_its_own_ranks(workload, steps):
+@pytest.mark.parametrize("workload,steps,sync_free", [("cfg1", 6, False), ("cfg2", 8, False), ("cfg1", 12, True)])
+def test_bench_gpus_flag_launches_its_own_ranks(workload, steps, sync_free):
     """`python bench.py --gpus 2` with no launcher around it must start two ranks itself and report n_gpus = 2 -- exercised on a
     one-GPU box through DGM_BENCH_SHARE_GPU=1 (both ranks on cuda:0, gloo), which runs the same self-launch, rendezvous,
     barrier / max-over-ranks timing and reporting code as the RCCL configuration; at cfg1 (short) and at cfg2, the metric's own
@@ -80,15 +80,20 @@ def test_bench_gpus_flag_launches_its_own_ranks(workload, steps):
     ONE GPU over gloo, not a scaling number)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DGM_BENCH_SHARE_GPU="1", DGM_BENCH_STEADY_STEPS="0")
+    if sync_free:  # the rasterizer forward that never waits for the device, its capacity check deferred behind the backward (DESIGN 4.3)
+        env.update(DGM_SYNC_FREE="1")
+    else:
+        env.pop("DGM_SYNC_FREE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "2", "--workload",
                           workload, "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"dp2_shared_gpu_{workload}.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", f"dp2_shared_gpu_{workload}{'_sync_free' if sync_free else ''}.json"), "w") as fh:
         json.dump({k: rec.get(k) for k in ("metric", "value", "n_gpus", "steps", "ms_per_step", "rccl_world_size", "replicas_identical",
-                                          "data_parallel", "allreduce", "config")}, fh, indent=1)
+                                          "data_parallel", "allreduce", "config", "host_ms_per_step")}, fh, indent=1)
+    assert rec["host_ms_per_step"]["sync_free_forward"] is sync_free
     assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert rec["allreduce"]["world_size_observed"] == 2 and len(rec["allreduce"]["bucket_bytes"]) == 1  # (default: one flat bucket)
     # the line vouches for itself: parameter + Adam-moment hashes of all ranks compared after the timed region, both exchange forms
