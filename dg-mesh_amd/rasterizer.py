@@ -173,6 +173,8 @@ def settle():
         return False
     if flags & 1:
         raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    if 4 * R < cap and not INJECT_CAPACITY:  # the scene shrank a lot (another scene on this device): follow it down
+        st["cap"] = _capacity_for(R)
     LAST_NUM_RENDERED = R
     return True
 
