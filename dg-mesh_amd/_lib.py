@@ -69,6 +69,10 @@ SYMBOLS = {
     "dgm_image_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "dgm_gaussian_apply_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dgm_gaussian_apply_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dgm_se3_exp_forward": (_i, [_i, _vp, _i, _vp, _vp]),
+    "dgm_se3_exp_backward": (_i, [_i, _vp, _i, _vp, _vp, _i, _vp]),
+    "dgm_se3_transform_forward": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "dgm_se3_transform_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgm_cycle_loss_workspace_bytes": (_c.c_size_t, [_i]),
     "dgm_cycle_loss_forward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dgm_cycle_loss_backward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -162,7 +162,195 @@ int glue_done() {
 }
 }  // namespace
 
+// ---- 6-DoF deformation heads (is_6dof=True): screw motion -> rigid transform -> moved centres ------------------------------------
+// R/utils/time_utils.py:116-123 + R/utils/rigid_utils.py:10-83 (Modern Robotics 3.51 / 3.88) + the 6-DoF branch of render()
+// (R/gaussian_renderer/__init__.py:68-75): from the raw head outputs (w_raw, v_raw) of a row
+//     theta = |w_raw|,  w = w_raw / theta + 1e-5,  v = v_raw / theta + 1e-5          (the reference adds the 1e-5 AFTER the division)
+//     R = I + sin(theta) [w] + (1 - cos(theta)) [w]^2
+//     p = (theta I + (1 - cos(theta)) [w] + (theta - sin(theta)) [w]^2) v
+//     T = [[R, p], [0 0 0 1]]                                                         (N, 4, 4), row-major
+// and, for the renderer, means3D = (T [xyz, 1])[:3] / (T [xyz, 1])[3] = R xyz + p (the bottom row is constant).
+// One thread per row; the backward kernels are the hand-derived adjoints (checked against autograd of the reference's functions).
+struct Se3Row {
+    float th, s, c, w[3], v[3], W[9], W2[9];
+};
+__device__ __forceinline__ void se3_row(const float* __restrict__ o, Se3Row& r) {
+    const float w0 = o[0], w1 = o[1], w2 = o[2];
+    r.th = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+    const float inv = 1.0f / r.th;
+#pragma unroll
+    for (int k = 0; k < 3; k++) r.w[k] = o[k] * inv + 1e-5f, r.v[k] = o[3 + k] * inv + 1e-5f;
+    r.s = sinf(r.th), r.c = cosf(r.th);
+    const float a = r.w[0], b = r.w[1], d = r.w[2];
+    const float W[9] = {0.f, -d, b, d, 0.f, -a, -b, a, 0.f};
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.W[i] = W[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+}
+
+__global__ void __launch_bounds__(256)
+se3_exp_fwd_kernel(int N, const float* __restrict__ wv, int ld, float* __restrict__ T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    Se3Row r;
+    se3_row(wv + (size_t)i * ld, r);
+    float* t = T + (size_t)i * 16;
+    const float omc = 1.0f - r.c, tms = r.th - r.s;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float p = 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const float id = a == b ? 1.f : 0.f;
+            t[4 * a + b] = id + r.s * r.W[3 * a + b] + omc * r.W2[3 * a + b];
+            p += (r.th * id + omc * r.W[3 * a + b] + tms * r.W2[3 * a + b]) * r.v[b];
+        }
+        t[4 * a + 3] = p;
+    }
+    t[12] = 0.f, t[13] = 0.f, t[14] = 0.f, t[15] = 1.f;
+}
+
+// dT (N, 16) -> d(w_raw, v_raw) written to d_wv[i * ldd + 0..5]
+__global__ void __launch_bounds__(256)
+se3_exp_bwd_kernel(int N, const float* __restrict__ wv, int ld, const float* __restrict__ dT, float* __restrict__ d_wv, int ldd) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float* o = wv + (size_t)i * ld;
+    Se3Row r;
+    se3_row(o, r);
+    const float* g = dT + (size_t)i * 16;
+    const float omc = 1.0f - r.c, tms = r.th - r.s;
+    float dR[9], dp[3], dG[9], dv[3], A[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        dp[a] = g[4 * a + 3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) dR[3 * a + b] = g[4 * a + b];
+    }
+    // p = G v:  dv = G^T dp,  dG = dp v^T
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float id = a == b ? 1.f : 0.f;
+            sacc += (r.th * id + omc * r.W[3 * a + b] + tms * r.W2[3 * a + b]) * dp[a];
+            dG[3 * a + b] = dp[a] * r.v[b];
+        }
+        dv[b] = sacc;
+    }
+    // gradient w.r.t. the skew matrix: sin dR + (1 - cos) dG + A W^T + W^T A with A = (1 - cos) dR + (theta - sin) dG
+    float dth = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        A[k] = omc * dR[k] + tms * dG[k];
+        const float id = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+        dth += dR[k] * (r.c * r.W[k] + r.s * r.W2[k]) + dG[k] * (id + r.s * r.W[k] + omc * r.W2[k]);
+    }
+    float dW[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            float x = r.s * dR[3 * a + b] + omc * dG[3 * a + b];
+#pragma unroll
+            for (int k = 0; k < 3; k++) x += A[3 * a + k] * r.W[3 * b + k] + r.W[3 * k + a] * A[3 * k + b];  // (A W^T)[a][b] + (W^T A)[a][b]
+            dW[3 * a + b] = x;
+        }
+    const float dw[3] = {dW[7] - dW[5], dW[2] - dW[6], dW[3] - dW[1]};
+    // w = w_raw / theta + 1e-5, v = v_raw / theta + 1e-5, theta = |w_raw|
+    const float inv = 1.0f / r.th;
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dot += dw[k] * o[k] + dv[k] * o[3 + k];
+    const float dth_tot = dth - dot * inv * inv;
+    float* d = d_wv + (size_t)i * ldd;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d[k] = dw[k] * inv + dth_tot * o[k] * inv;
+        d[3 + k] = dv[k] * inv;
+    }
+}
+
+// out = (T [xyz, 1])[:3] / (T [xyz, 1])[3]   (general 4 x 4 rows: the division is kept, as render() has it)
+__global__ void __launch_bounds__(256)
+se3_transform_fwd_kernel(int N, const float* __restrict__ T, const float* __restrict__ xyz, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float* t = T + (size_t)i * 16;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const float h = t[12] * x + t[13] * y + t[14] * z + t[15];
+#pragma unroll
+    for (int a = 0; a < 3; a++) out[3 * i + a] = (t[4 * a] * x + t[4 * a + 1] * y + t[4 * a + 2] * z + t[4 * a + 3]) / h;
+}
+
+__global__ void __launch_bounds__(256)
+se3_transform_bwd_kernel(int N, const float* __restrict__ T, const float* __restrict__ xyz, const float* __restrict__ g_out,
+                         float* __restrict__ dT, float* __restrict__ d_xyz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float* t = T + (size_t)i * 16;
+    const float hom[4] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 1.0f};
+    float num[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) num[a] = t[4 * a] * hom[0] + t[4 * a + 1] * hom[1] + t[4 * a + 2] * hom[2] + t[4 * a + 3];
+    const float ih = 1.0f / num[3];
+    // out_a = num_a / h:  d num_a = g_a / h (a < 3),  d h = -sum_a g_a num_a / h^2
+    float dn[4];
+    float dh = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float ga = g_out[3 * i + a];
+        dn[a] = ga * ih;
+        dh -= ga * num[a] * ih * ih;
+    }
+    dn[3] = dh;
+    float dx[3] = {0.f, 0.f, 0.f};
+    float* dt = dT + (size_t)i * 16;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            dt[4 * a + b] = dn[a] * hom[b];
+            if (b < 3) dx[b] += dn[a] * t[4 * a + b];
+        }
+    d_xyz[3 * i] = dx[0], d_xyz[3 * i + 1] = dx[1], d_xyz[3 * i + 2] = dx[2];
+}
+
 extern "C" {
+
+int dgm_se3_exp_forward(int N, const float* wv, int ld, float* T, void* stream) {
+    if (N <= 0) return 0;
+    if (!wv || !T) return glue_fail("se3_exp_forward: NULL pointer");
+    if (ld < 6) return glue_fail("se3_exp_forward: rows need at least 6 columns (w, v)");
+    hipLaunchKernelGGL(se3_exp_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, wv, ld, T);
+    return glue_done();
+}
+
+int dgm_se3_exp_backward(int N, const float* wv, int ld, const float* dT, float* d_wv, int ldd, void* stream) {
+    if (N <= 0) return 0;
+    if (!wv || !dT || !d_wv) return glue_fail("se3_exp_backward: NULL pointer");
+    if (ld < 6 || ldd < 6) return glue_fail("se3_exp_backward: rows need at least 6 columns (w, v)");
+    hipLaunchKernelGGL(se3_exp_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, wv, ld, dT, d_wv, ldd);
+    return glue_done();
+}
+
+int dgm_se3_transform_forward(int N, const float* T, const float* xyz, float* out, void* stream) {
+    if (N <= 0) return 0;
+    if (!T || !xyz || !out) return glue_fail("se3_transform_forward: NULL pointer");
+    hipLaunchKernelGGL(se3_transform_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, T, xyz, out);
+    return glue_done();
+}
+
+int dgm_se3_transform_backward(int N, const float* T, const float* xyz, const float* g_out, float* dT, float* d_xyz, void* stream) {
+    if (N <= 0) return 0;
+    if (!T || !xyz || !g_out || !dT || !d_xyz) return glue_fail("se3_transform_backward: NULL pointer");
+    hipLaunchKernelGGL(se3_transform_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, T, xyz, g_out, dT, d_xyz);
+    return glue_done();
+}
 
 int dgm_gaussian_apply_forward(int P, const float* xyz, const float* scaling, const float* rotation, const float* opacity,
                                const float* delta, int ld, float* means3D, float* scales, float* rotations, float* opacities,

@@ -145,7 +145,10 @@ class DeformNetwork(_TrunkNet):
         return warp + [self.gaussian_rotation, self.gaussian_scaling]
 
     def _split(self, o):
-        if self.is_6dof:
+        if self.is_6dof and o.is_cuda and o.dtype == torch.float32 and self.trunk_impl == "hip":
+            from .glue import se3_exp  # one kernel each way (dgm_se3_exp_*) instead of ~25 torch launches
+            d_xyz, o = se3_exp(o[:, 0:6]), o[:, 6:]
+        elif self.is_6dof:
             w, v, o = o[:, 0:3], o[:, 3:6], o[:, 6:]
             theta = torch.norm(w, dim=-1, keepdim=True)
             w = w / theta + 1e-5

@@ -97,3 +97,70 @@ class _CycleLoss(torch.autograd.Function):
 def cycle_loss(delta, delta_back):
     """(l1(-b_xyz, d_xyz) + l1(-b_rot, d_rot) + l1(-b_scale, d_scale)) / 3 on the raw head outputs."""
     return _CycleLoss.apply(delta, delta_back)
+
+
+class _Se3Exp(torch.autograd.Function):
+    """(N, >= 6) raw head outputs [w | v | ...] -> (N, 4, 4) rigid transforms (R/utils/time_utils.py:116-123 + rigid_utils.exp_se3)."""
+
+    @staticmethod
+    def forward(ctx, o):
+        L = _lib.lib()
+        o = _f32c(o, "screw rows")
+        N, ld = o.shape
+        if ld < 6:
+            raise RuntimeError("se3_exp: rows need at least 6 columns (w, v)")
+        T = torch.empty((N, 4, 4), dtype=torch.float32, device=o.device)
+        with _lib.device_guard(o.device):
+            _lib.check(L.dgm_se3_exp_forward(N, _vp(o), ld, _vp(T), _stream()))
+        ctx.save_for_backward(o)
+        return T
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dT):
+        L = _lib.lib()
+        (o,) = ctx.saved_tensors
+        N, ld = o.shape
+        dT = _f32c(dT, "grad")
+        d_o = torch.zeros_like(o)  # (columns beyond w, v get no gradient from here)
+        with _lib.device_guard(o.device):
+            _lib.check(L.dgm_se3_exp_backward(N, _vp(o), ld, _vp(dT), _vp(d_o), ld, _stream()))
+        return d_o
+
+
+class _Se3Transform(torch.autograd.Function):
+    """means3D = (T [xyz, 1])[:3] / (T [xyz, 1])[3]: the 6-DoF branch of render() (R/gaussian_renderer/__init__.py:68-75)."""
+
+    @staticmethod
+    def forward(ctx, T, xyz):
+        L = _lib.lib()
+        T, xyz = _f32c(T, "transforms"), _f32c(xyz, "xyz")
+        N = xyz.shape[0]
+        if tuple(T.shape) != (N, 4, 4):
+            raise RuntimeError("se3_transform: transforms must be (N, 4, 4)")
+        out = torch.empty_like(xyz)
+        with _lib.device_guard(xyz.device):
+            _lib.check(L.dgm_se3_transform_forward(N, _vp(T), _vp(xyz), _vp(out), _stream()))
+        ctx.save_for_backward(T, xyz)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        L = _lib.lib()
+        T, xyz = ctx.saved_tensors
+        N = xyz.shape[0]
+        g = _f32c(g, "grad")
+        dT, d_xyz = torch.empty_like(T), torch.empty_like(xyz)
+        with _lib.device_guard(xyz.device):
+            _lib.check(L.dgm_se3_transform_backward(N, _vp(T), _vp(xyz), _vp(g), _vp(dT), _vp(d_xyz), _stream()))
+        return dT, d_xyz
+
+
+def se3_exp(o):
+    """Raw (w, v) rows (first six columns of `o`) -> (N, 4, 4) transforms, on the HIP kernels."""
+    return _Se3Exp.apply(o)
+
+
+def se3_transform(T, xyz):
+    return _Se3Transform.apply(T, xyz)

@@ -363,6 +363,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, i
     elif is_6dof:
         if torch.is_tensor(d_xyz) is False:
             means3D = pc.get_xyz
+        elif d_xyz.is_cuda and d_xyz.dtype == torch.float32:
+            from .glue import se3_transform  # dgm_se3_transform_*: cat + bmm + divide of the reference as one kernel each way
+            means3D = se3_transform(d_xyz, pc.get_xyz)
         else:
             hom = torch.cat([pc.get_xyz, torch.ones_like(pc.get_xyz[:, :1])], -1)
             out = torch.bmm(d_xyz, hom.unsqueeze(-1)).squeeze(-1)

@@ -51,7 +51,8 @@ extern "C" {
  *   3: dgm_knn_mean_dist2 takes a caller-owned scratch buffer (dgm_knn_scratch_bytes); two replay-unit lists in dgm_state_layout.
  *   4: dgm_state_layout lost `upos` and `block_offs`, `inst` became uint2[R] (8-byte instance records; the backward forms the
  *      gradient row of an instance itself); dgm_laplace_* added.  Entry points' signatures are unchanged from 3.
- *   5: dgm_rasterize_forward_capacity added (a forward that never waits for the device); dgm_mlp_set_gemm knows modes 4 and 5.
+ *   5: dgm_rasterize_forward_capacity added (a forward that never waits for the device); dgm_se3_* added (6-DoF heads);
+ *      dgm_mlp_set_gemm knows modes 4 and 5.
  *      Every entry point of 4 is unchanged. */
 #define DGM_ABI_VERSION 5
 
@@ -323,6 +324,16 @@ int dgm_gaussian_apply_backward(int P, const float* scaling, const float* rotati
                                 const float* g_means3D, const float* g_scales, const float* g_rotations,
                                 const float* g_opacities, float* d_xyz, float* d_scaling, float* d_rotation,
                                 float* d_opacity, float* d_delta, int ld, void* stream);
+
+/* 6-DoF deformation heads (is_6dof=True; round 6).  dgm_se3_exp_*: rows wv[i * ld + 0..5] = the raw outputs (w, v) of branch_w /
+ * branch_v -> T (N, 4, 4) row-major, exactly dgmesh/utils/time_utils.py:116-123 (theta = |w|, w / theta + 1e-5, v / theta + 1e-5)
+ * followed by exp_se3 of dgmesh/utils/rigid_utils.py:60-83 (Rodrigues' formula :40-57, rp_to_se3 :23-37); backward: dT (N, 16) ->
+ * d_wv[i * ldd + 0..5].  dgm_se3_transform_*: the 6-DoF branch of render() (dgmesh/gaussian_renderer/__init__.py:68-75):
+ * out = (T [xyz, 1])[:3] / (T [xyz, 1])[3]; backward writes dT (N, 16) and d_xyz (N, 3) in full. */
+int dgm_se3_exp_forward(int N, const float* wv, int ld, float* T, void* stream);
+int dgm_se3_exp_backward(int N, const float* wv, int ld, const float* dT, float* d_wv, int ldd, void* stream);
+int dgm_se3_transform_forward(int N, const float* T, const float* xyz, float* out, void* stream);
+int dgm_se3_transform_backward(int N, const float* T, const float* xyz, const float* g_out, float* dT, float* d_xyz, void* stream);
 
 /* Cycle-consistency loss of dgmesh/train.py:221-238 on the raw (N, ld) outputs a (deform) and b (deform_back):
  * out[0] = (mean|b_xyz + a_xyz| + mean|b_rot + a_rot| + mean|b_scale + a_scale|) / 3, out[1..3] the three terms.
