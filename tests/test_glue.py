@@ -161,8 +161,6 @@ def test_render_six_dof_branch_on_the_kernels():
         gen = torch.Generator().manual_seed(5)
         o = (0.05 * torch.randn(P, 6, generator=gen)).to(dev).requires_grad_(True)
         T = G.se3_exp(o)
-        if not fused:
-            T = T.double().float() + 0.0  # (same values, but hide the tensor from nothing: the branch below is forced instead)
         bg = torch.ones(3, device=dev)
         if fused:
             pkg_ = S.render(cam, g, S.PipelineParams(), bg, T, 0.0, 0.0, is_6dof=True)
@@ -170,7 +168,7 @@ def test_render_six_dof_branch_on_the_kernels():
             hom = torch.cat([g.get_xyz, torch.ones_like(g.get_xyz[:, :1])], -1)
             out = torch.bmm(T, hom.unsqueeze(-1)).squeeze(-1)
             means = out[..., :3] / out[..., 3:]
-            pkg_ = S.render(cam, g, S.PipelineParams(), bg, means - g.get_xyz.detach() * 0 - g.get_xyz, 0.0, 0.0, is_6dof=False)
+            pkg_ = S.render(cam, g, S.PipelineParams(), bg, means - g.get_xyz, 0.0, 0.0, is_6dof=False)  # means3D = xyz + d_xyz = means
         w = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
         (pkg_["render"] * w).sum().backward()
         grads[fused] = (pkg_["render"].detach(), o.grad.clone(), g._xyz.grad.clone())
