@@ -138,8 +138,19 @@ def test_se3_kernels_match_the_reference_functions(N, ld):
     out = torch.bmm(T64, hom.unsqueeze(-1)).squeeze(-1)
     m64 = out[..., :3] / out[..., 3:]
     ((T64 * wT.double().to(dev)).sum() + (m64 * wX.double().to(dev)).sum()).backward()
+    # the same reference functions evaluated by PyTorch in fp32: the yardstick for the gradient w.r.t. (w, v), which is ill-conditioned
+    # at small angles (terms ~ 1 / theta^2 cancel) in ANY fp32 evaluation
+    of, xf = o.to(dev).requires_grad_(True), xyz.to(dev).requires_grad_(True)
+    wf, vf = of[:, 0:3], of[:, 3:6]
+    thf = torch.norm(wf, dim=-1, keepdim=True)
+    Tf = ref.exp_se3(torch.cat([wf / thf + 1e-5, vf / thf + 1e-5], dim=-1), thf)
+    outf = torch.bmm(Tf, torch.cat([xf, torch.ones_like(xf[:, :1])], -1).unsqueeze(-1)).squeeze(-1)
+    ((Tf * wT.to(dev)).sum() + (outf[..., :3] / outf[..., 3:] * wX.to(dev)).sum()).backward()
+    e_ref = _rel(of.grad.double()[:, :6], o64.grad[:, :6])
     assert _rel(T.detach().double(), T64.detach()) < 2e-5 and _rel(m.detach().double(), m64.detach()) < 2e-5
-    assert _rel(o32.grad.double()[:, :6], o64.grad[:, :6]) < 2e-5 and _rel(x32.grad.double(), x64.grad) < 2e-5
+    e_hip = _rel(o32.grad.double()[:, :6], o64.grad[:, :6])
+    print(f"se3 N={N}: d(w, v) error vs fp64, of the tensor's maximum: kernels {e_hip:.2e}, the reference's functions in fp32 {e_ref:.2e}")
+    assert e_hip < 2e-5 + 2.0 * e_ref and _rel(x32.grad.double(), x64.grad) < 2e-5
     if ld > 6:
         assert float(o32.grad[:, 6:].abs().max()) == 0.0
 
