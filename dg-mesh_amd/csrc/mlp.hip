@@ -727,6 +727,7 @@ struct Ws {
     unsigned* matmax;
     uint4 *Wh4f, *Wh4b;
     float *wsc_hf, *wsc_hb;
+    float *bias_s[8];           // round 6: biases times their layer's column scales (mlp_prep4c_kernel)
     float *beff[2], *temb_row;  // round 6: biases of layer 0 / the skip layer with the call's time row folded in; that row (for the backward pass)
     size_t bytes;
 };
@@ -827,8 +828,8 @@ Ws carve(char* base, int N) {
     w.partial_db = w.partial_db_l[5];
     for (int l = 0; l < 8; l++) w.Wt3[l] = (uint4*)take((size_t)(MLP_EMB + MLP_W) * MLP_W * 4);
     for (int l = 0; l < 8; l++) w.Wd3[l] = (uint4*)take((size_t)MLP_W * MLP_W * 4);
-    for (int l = 0; l < 8; l++) w.wsc_f[l] = take(256);
-    for (int l = 0; l < 8; l++) w.wsc_d[l] = take(256);
+    for (int l = 0; l < 8; l++) w.wsc_f[l] = take(1024);  // (one inverse scale per output column in round 6's kernel forms, [0] = the matrix's otherwise)
+    for (int l = 0; l < 8; l++) w.wsc_d[l] = take(1024);
     w.wsc_e = take(256);
     size_t hchunks = ((size_t)N + HD_ROWS - 1) / HD_ROWS;
     if ((size_t)pp.chunks > hchunks) hchunks = pp.chunks;
@@ -844,10 +845,11 @@ Ws carve(char* base, int N) {
     w.matmax = (unsigned*)take(P4_MAX_MATS * 8 * 4);
     w.Wh4f = (uint4*)take((size_t)MLP_W * 32 * 4);
     w.Wh4b = (uint4*)take((size_t)16 * MLP_W * 4);
-    w.wsc_hf = take(64);
-    w.wsc_hb = take(64);
+    w.wsc_hf = take(1024);
+    w.wsc_hb = take(1024);
     w.beff[0] = take(MLP_W * 4);
     w.beff[1] = take(MLP_W * 4);
+    for (int l = 0; l < 8; l++) w.bias_s[l] = take(MLP_W * 4);
     w.temb_row = take(64 * 4);
     w.bytes = (size_t)(p - base) + 256;
     return w;
@@ -902,7 +904,11 @@ typedef Gemm4Cfg<16, 1024, 512, 1, false, 8> CfgBwd;
 typedef Gemm4Cfg<6, 384, 192, 0, true, 8> CfgL0;
 typedef Gemm4Cfg<16, 1024, 512, 3, false, 1> CfgHeads;
 typedef Gemm4Cfg<1, 128, 64, 1, false, 8> CfgG7;
-typedef Gemm4Cfg<4, 256, 128, 0, false, 8> CfgL0F;   // layer 0 on the 64-column embedding
+typedef Gemm4Cfg<4, 256, 128, 0, false, 8, true> CfgL0F;   // layer 0 on the 64-column embedding
+typedef Gemm4Cfg<16, 1024, 512, 0, false, 8, true> CfgFwdC;   // round 6's forms: one weight scale per output column
+typedef Gemm4Cfg<16, 1024, 512, 1, false, 8, true> CfgBwdC;
+typedef Gemm4Cfg<16, 1024, 512, 3, false, 1, true> CfgHeadsC;
+typedef Gemm4Cfg<1, 128, 64, 1, false, 8, true> CfgG7C;
 typedef Gemm5Cfg<0, 0> Cfg5Fwd;
 typedef Gemm5Cfg<0, 1> Cfg5Bwd;
 typedef Gemm5Cfg<4, 0> Cfg5Skip;
@@ -961,7 +967,27 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
         f.temb = temb, f.T = p->t_dim, f.temb_row = w.temb_row;
         hipLaunchKernelGGL(mlp_fold_bias_kernel, dim3(2, 8), dim3(256), 0, st, f);
     }
-    // every weight matrix as two binary16 planes, one power-of-two scale per matrix
+    if (fold) {  // every weight matrix as two binary16 planes, one power-of-two scale per OUTPUT COLUMN, biases pre-scaled
+        Prep4cBatch pc;
+        int nc = 0;
+        auto addc = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp, uint4* Bp,
+                        float* inv_scale, const float* bias_in, float* bias_out) {
+            Prep4cJob& q = pc.job[nc++];
+            q.j.mode = mode, q.j.Kp = Kp, q.j.ncols = ncols, q.j.in_features = in_features, q.j.emb_dim = p->emb_dim, q.j.hoff = hoff;
+            q.j.k_valid = k_valid, q.j.col_valid = col_valid, q.j.W = Wp, q.j.Bp = Bp, q.j.inv_scale = inv_scale;
+            q.bias_in = bias_in, q.bias_out = bias_out;
+        };
+        for (int l = 0; l < 8; l++) {
+            const int Kp = l == 0 ? 64 : (l == sk ? 320 : MLP_W);
+            const float* bin = l == 0 ? w.beff[0] : (l == sk ? w.beff[1] : p->b[l]);
+            addc(0, Kp, MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_f[l], bin, w.bias_s[l]);
+            if (l >= 1) addc(1, MLP_W, MLP_W, layer_in(p, l), l == sk ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l], w.Wd3[l], w.wsc_d[l], nullptr, nullptr);
+        }
+        addc(0, MLP_W, 32, MLP_W, 0, MLP_W, p->n_out, p->Wh, w.Wh4f, w.wsc_hf, nullptr, nullptr);   // heads forward: B[k][o] = Wh[o][k]
+        addc(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh4b, w.wsc_hb, nullptr, nullptr);    // heads backward: B[o][c] = Wh[o][c]
+        hipLaunchKernelGGL(mlp_prep4c_kernel, dim3(8, nc), dim3(256), 0, st, pc);
+    }
+    // (rounds 3-5's forms: one power-of-two scale per matrix)
     Prep4Batch pb;
     int nj = 0;
     auto add = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp, uint4* Bp,
@@ -982,16 +1008,16 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     }
     add(0, MLP_W, 32, MLP_W, 0, MLP_W, p->n_out, p->Wh, w.Wh4f, w.wsc_hf, 8);   // heads forward: B[k][o] = Wh[o][k]
     add(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh4b, w.wsc_hb, 8);    // heads backward: B[o][c] = Wh[o][c]
-    hipLaunchKernelGGL(mlp_prep4_kernel, dim3(8, nj), dim3(256), 0, st, pb, w.matmax);
+    if (!fold) hipLaunchKernelGGL(mlp_prep4_kernel, dim3(8, nj), dim3(256), 0, st, pb, w.matmax);
 
     Gemm4Args a;
     memset(&a, 0, sizeof(a));
     a.ntiles = nt, a.M = N, a.exps_limit = p4_exps_limit();
     if (fold) {
         // layer 0: K = 64, eight waves (HBM-bound: 26 MB in, 102 MB of planes out)
-        a.A = (const unsigned char*)w.emb, a.Aexp = w.Eexp, a.Bp = w.Wt3[0], a.b_inv = w.wsc_f[0], a.bias = w.beff[0];
+        a.A = (const unsigned char*)w.emb, a.Aexp = w.Eexp, a.Bp = w.Wt3[0], a.b_inv = w.wsc_f[0], a.bias = w.bias_s[0];
         a.mask_out = w.mask[0], a.C = (unsigned char*)w.Y[0], a.Cexp = w.Yexp[0];
-        P4_LAUNCH((mlp_gemm4_kernel<4, 256, 128, 0, false, 8>), CfgL0F::LDS, gx, st, a)
+        P4_LAUNCH((mlp_gemm4_kernel<4, 256, 128, 0, false, 8, true>), CfgL0F::LDS, gx, st, a)
         Gemm5Args b;
         memset(&b, 0, sizeof(b));
         b.ntiles = nt, b.M = N, b.exps_limit = p4_exps_limit();
@@ -999,18 +1025,18 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
             b.A = (const unsigned char*)w.Y[l - 1], b.Aexp = w.Yexp[l - 1], b.Bp = w.Wt3[l], b.b_inv = w.wsc_f[l];
             b.mask_out = w.mask[l], b.C = (unsigned char*)w.Y[l], b.Cexp = w.Yexp[l];
             if (l == sk) {  // K = 320: the embedding's four K steps, then the trunk's sixteen
-                b.A2 = (const unsigned char*)w.emb, b.A2exp = w.Eexp, b.bias = w.beff[1];
+                b.A2 = (const unsigned char*)w.emb, b.A2exp = w.Eexp, b.bias = w.bias_s[sk];
                 P5_LAUNCH((mlp_gemm5_kernel<4, 0>), Cfg5Skip::LDS, gx, st, b)
                 b.A2 = nullptr, b.A2exp = nullptr;
             } else if (all5) {
-                b.bias = p->b[l];
+                b.bias = w.bias_s[l];
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
                 P5_LAUNCH((mlp_gemm5_kernel<0, 0>), Cfg5Fwd::LDS, gx, st, b)
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
             } else {  // the eight-wave form (measured faster for K = 256)
-                a.A = b.A, a.Aexp = b.Aexp, a.Bp = b.Bp, a.b_inv = b.b_inv, a.bias = p->b[l], a.mask_out = b.mask_out, a.C = b.C, a.Cexp = b.Cexp;
+                a.A = b.A, a.Aexp = b.Aexp, a.Bp = b.Bp, a.b_inv = b.b_inv, a.bias = w.bias_s[l], a.mask_out = b.mask_out, a.C = b.C, a.Cexp = b.Cexp;
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
-                P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>), CfgFwd::LDS, gx, st, a)
+                P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 0, false, 8, true>), CfgFwdC::LDS, gx, st, a)
                 dgm::prof_end(DGM_STAGE_MLP_LAYER_FWD, st);
             }
         }
@@ -1040,7 +1066,8 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     // heads: out = Y7 Wh^T + bh (one computing wave per workgroup; HBM-bound: one pass over Y7)
     a.A = (const unsigned char*)w.Y[7], a.Aexp = w.Yexp[7], a.Bp = w.Wh4f, a.b_inv = w.wsc_hf, a.bias = p->bh;
     a.mask_out = nullptr, a.C = nullptr, a.Cexp = nullptr, a.out = out, a.ldo = p->n_out, a.n_valid = p->n_out;
-    P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 3, false, 1>), CfgHeads::LDS, gx, st, a)
+    if (fold) P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 3, false, 1, true>), CfgHeadsC::LDS, gx, st, a)
+    else P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 3, false, 1>), CfgHeads::LDS, gx, st, a)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));
     return 0;
@@ -1066,7 +1093,8 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     {   // one K step per tile: nothing to hide the epilogue's barriers under, so two workgroups per CU (104 VGPRs, 54 KB of LDS)
         static const int mult = [] { const char* e = getenv("DGM_P4_G7_MULT"); return e ? atoi(e) : 2; }();
         const int g7 = nt < mult * num_cus() ? nt : mult * num_cus();
-        P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8>), CfgG7::LDS, g7, st, a)
+        if (fold) P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8, true>), CfgG7C::LDS, g7, st, a)
+        else P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8>), CfgG7::LDS, g7, st, a)
     }
     Dw4Args d;
     memset(&d, 0, sizeof(d));
@@ -1135,15 +1163,17 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
         if (paired) {
             dgm::prof_begin(DGM_STAGE_MLP_BWD_PAIR, st);
             {
-                static bool done_[DGM_MAX_DEVICES] = {false};
-                constexpr int LDS_PAIR = CfgBwd::LDS > CfgDw::LDS ? CfgBwd::LDS : CfgDw::LDS;
-                if (p4_lds_attr(mlp_bwd_pair_kernel, LDS_PAIR, &done_[current_device_slot()]) != hipSuccess)
+                static bool done_[DGM_MAX_DEVICES] = {false}, donec_[DGM_MAX_DEVICES] = {false};
+                constexpr int LDS_PAIR = CfgBwdC::LDS > CfgDw::LDS ? CfgBwdC::LDS : CfgDw::LDS;
+                if ((fold ? p4_lds_attr(mlp_bwd_pair_kernel<true>, LDS_PAIR, &donec_[current_device_slot()])
+                          : p4_lds_attr(mlp_bwd_pair_kernel<false>, LDS_PAIR, &done_[current_device_slot()])) != hipSuccess)
                     return mlp_fail("mlp: cannot raise the LDS limit of mlp_bwd_pair_kernel");
                 const int grid = n_dw + (gx - n_dw > 0 ? gx - n_dw : 1);
                 // chunked: the GEMM role walks the weight-gradient role's row chunks (needs as many GEMM workgroups as chunks)
                 static const int chunk_env = [] { const char* e = getenv("DGM_MLP_PAIR_CHUNKED"); return e ? atoi(e) : 1; }();
                 const int chunked = (chunk_env && grid - n_dw == n_dw && (n_dw % 8) == 0) ? 1 : 0;
-                hipLaunchKernelGGL(mlp_bwd_pair_kernel, dim3(grid), dim3(512), LDS_PAIR, st, a, d, n_dw, chunked);
+                if (fold) hipLaunchKernelGGL(mlp_bwd_pair_kernel<true>, dim3(grid), dim3(512), LDS_PAIR, st, a, d, n_dw, chunked);
+                else hipLaunchKernelGGL(mlp_bwd_pair_kernel<false>, dim3(grid), dim3(512), LDS_PAIR, st, a, d, n_dw, chunked);
             }
             dgm::prof_end(DGM_STAGE_MLP_BWD_PAIR, st);
         } else if (l >= 1) {
@@ -1154,7 +1184,9 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
                 b.ntiles = nt, b.M = N, b.exps_limit = a.exps_limit;
                 b.A = a.A, b.Aexp = a.Aexp, b.Bp = a.Bp, b.b_inv = a.b_inv, b.mask_in = a.mask_in, b.C = a.C, b.Cexp = a.Cexp;
                 P5_LAUNCH((mlp_gemm5_kernel<0, 1>), Cfg5Bwd::LDS, gx, st, b)
-            } else
+            } else if (fold)
+                P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8, true>), CfgBwdC::LDS, gx, st, a)
+            else
                 P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>), CfgBwd::LDS, gx, st, a)
             dgm::prof_end(DGM_STAGE_MLP_LAYER_BWD, st);
             dgm::prof_begin(DGM_STAGE_MLP_LAYER_DW, st);
@@ -1247,7 +1279,7 @@ int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
     if (cap < nt) {
         if (hipMalloc((void**)&A, rows * 1024) != hipSuccess || hipMalloc((void**)&C, rows * 1024) != hipSuccess ||
             hipMalloc((void**)&G, rows * 1024) != hipSuccess || hipMalloc((void**)&ex, (size_t)nt * 4 * 4) != hipSuccess ||
-            hipMalloc((void**)&Bp, 16 * 4 * 256 * 16) != hipSuccess || hipMalloc((void**)&binv, 256) != hipSuccess ||
+            hipMalloc((void**)&Bp, 16 * 4 * 256 * 16) != hipSuccess || hipMalloc((void**)&binv, 1024) != hipSuccess ||
             hipMalloc((void**)&bias, 1024) != hipSuccess || hipMalloc((void**)&mask, (size_t)nt * 1024) != hipSuccess ||
             hipMalloc((void**)&partial, (size_t)256 * 256 * 256 * 4) != hipSuccess || hipMalloc((void**)&pdb, (size_t)256 * 8 * 256 * 4) != hipSuccess)
             return mlp_fail("p4_probe: hipMalloc failed");
@@ -1260,7 +1292,12 @@ int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
     (void)hipMemsetAsync(ex, 0, (size_t)nt * 4 * 4, st);
     (void)hipMemsetAsync(bias, 0, 1024, st);
     const float one = 1.0f / 65536.0f;
-    (void)hipMemcpyAsync(binv, &one, 4, hipMemcpyHostToDevice, st);
+    {
+        float ones[256];
+        for (int i = 0; i < 256; i++) ones[i] = one;
+        (void)hipMemcpyAsync(binv, ones, sizeof(ones), hipMemcpyHostToDevice, st);
+        (void)hipStreamSynchronize(st);
+    }
     Gemm4Args a;
     memset(&a, 0, sizeof(a));
     a.exps_limit = 512;
@@ -1291,7 +1328,7 @@ int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
             if (n_dw <= 0) return mlp_fail("p4_probe: no pair split at this size");
             static bool done_[DGM_MAX_DEVICES] = {false};
             constexpr int LDS_PAIR = CfgBwd::LDS > CfgDw::LDS ? CfgBwd::LDS : CfgDw::LDS;
-            if (p4_lds_attr(mlp_bwd_pair_kernel, LDS_PAIR, &done_[current_device_slot()]) != hipSuccess) return mlp_fail("p4_probe: LDS attribute");
+            if (p4_lds_attr(mlp_bwd_pair_kernel<false>, LDS_PAIR, &done_[current_device_slot()]) != hipSuccess) return mlp_fail("p4_probe: LDS attribute");
             Dw4Args dp = d;
             dp.tiles_per_chunk = (nt + n_dw - 1) / n_dw;
 #ifdef P4_XCD_REDUCE
@@ -1308,7 +1345,7 @@ int dgm_p4_probe(int N, int kind, int iters, int zero, void* stream) {
 #endif
             const int grid = n_dw + (gx - n_dw > 0 ? gx - n_dw : 1);
             const int chunked = (grid - n_dw == n_dw && (n_dw % 8) == 0) ? 1 : 0;
-            hipLaunchKernelGGL(mlp_bwd_pair_kernel, dim3(grid), dim3(512), LDS_PAIR, st, a, dp, n_dw, chunked);
+            hipLaunchKernelGGL(mlp_bwd_pair_kernel<false>, dim3(grid), dim3(512), LDS_PAIR, st, a, dp, n_dw, chunked);
         }
     }
     hipError_t e = hipGetLastError();

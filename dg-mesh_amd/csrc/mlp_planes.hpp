@@ -321,6 +321,68 @@ mlp_prep4_kernel(const Prep4Batch b, const unsigned* __restrict__ matmax) {
     }
 }
 
+// ---- weight planes with ONE power-of-two scale PER OUTPUT COLUMN (round 6; COLSC kernels) ---------------------------------------------
+// One scale per matrix keeps 22 bits of an entry only down to 2^-17 of the MATRIX maximum: a network whose hidden units differ in
+// scale by 2^+-10 (ReLU is positively homogeneous: such a network computes the same function) has rows and columns 2^+-10 apart in
+// every matrix, the entries of one matrix span 2^40, and the smallest -- which multiply the largest activations -- are flushed
+// (tests/test_mlp.py::test_plane_format_envelope...).  Here column c of B (forward: output unit c, i.e. row c of W; backward data:
+// input feature c, i.e. column hoff + c of W) is scaled by its own power of two: B'[k][c] = B[k][c] 2^ls[c], maximum -> [2^14, 2^15);
+// the GEMM's epilogue multiplies output column c by inv_scale[c] = 2^-ls[c] (a power of two: exact), and the forward's bias enters
+// pre-scaled, bias_out[c] = bias_in[c] 2^ls[c], so that ReLU still reads the sign of one fused multiply-add.  What is left inside a
+// column is the spread over the contraction index only.  The block computes its columns' maxima itself (no maxima pass in front).
+struct Prep4cJob {
+    Prep3Job j;             // j.inv_scale: [ncols] floats
+    const float* bias_in;   // may be NULL
+    float* bias_out;        // [ncols]
+};
+struct Prep4cBatch {
+    Prep4cJob job[P4_MAX_JOBS];
+};
+__global__ void __launch_bounds__(256)
+mlp_prep4c_kernel(const Prep4cBatch b) {
+    __shared__ float smax[8][32];
+    const Prep4cJob& pj = b.job[blockIdx.y];
+    const Prep3Job& j = pj.j;
+    if ((int)blockIdx.x * 32 >= j.ncols) return;
+    const int tid = threadIdx.x, cl = tid & 31, col = blockIdx.x * 32 + cl, slot = tid >> 5, nkg = j.Kp >> 3;
+    float e[6][8];
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int kg = slot + 8 * it;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            e[it][i] = kg < nkg ? prep3_src(j, kg * 8 + i, col) : 0.f;
+            m = fmaxf(m, fabsf(e[it][i]));
+        }
+    }
+    smax[slot][cl] = m;
+    __syncthreads();
+    float cm = smax[0][cl];
+#pragma unroll
+    for (int q = 1; q < 8; q++) cm = fmaxf(cm, smax[q][cl]);
+    float sc, inv;
+    scale_from_max_bits(__float_as_uint(cm), sc, inv);
+    if (slot == 0) {
+        j.inv_scale[col] = inv;
+        if (pj.bias_out != nullptr) pj.bias_out[col] = (pj.bias_in != nullptr && col < j.col_valid) ? pj.bias_in[col] * sc : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int kg = slot + 8 * it;
+        if (kg < nkg) {
+            uint4 H, L;
+            split2h(e[it][0] * sc, e[it][1] * sc, H.x, L.x);
+            split2h(e[it][2] * sc, e[it][3] * sc, H.y, L.y);
+            split2h(e[it][4] * sc, e[it][5] * sc, H.z, L.z);
+            split2h(e[it][6] * sc, e[it][7] * sc, H.w, L.w);
+            uint4* dst = j.Bp + ((size_t)(kg >> 1) * 4 + (kg & 1)) * j.ncols + col;
+            dst[0] = H;
+            dst[2 * j.ncols] = L;
+        }
+    }
+}
+
 // ---- dOut (N, n_out) fp32 -> planes [Np][2][32] + exponents, and the heads' bias-gradient partial sums --------------------
 // One wave per 32-row tile (lane = row, column half); columns >= n_out and rows >= N are zero, which is what makes every
 // gradient tensor's padded rows exactly zero.  partial_b[tile][16] = column sums of the tile (the heads' bias gradient).
@@ -407,7 +469,7 @@ struct Gemm4Args {
     int exps_limit;             // tiles of a workgroup whose input exponents come from its LDS table (<= Gemm4Cfg::EXPS); later ones from HBM
 };
 
-template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
+template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW, bool COLSC = false>
 struct Gemm4Cfg {
     static constexpr int PITCH = ROWB + 16;
     static constexpr int ABYTES = 32 * PITCH;
@@ -417,7 +479,7 @@ struct Gemm4Cfg {
     static constexpr bool PLANES_OUT = EPI != 3;
     static constexpr int O_BYTES = PLANES_OUT ? 32768 : 0;          // staging tile of the output planes
     static constexpr int EXPS = 512;                                // input exponents of the workgroup's tiles
-    static constexpr int LDS = A_END + MI_BYTES + O_BYTES + 2 * 1024 + EXPS * 4 + 64 + 1024;  // (+ the bias vector)
+    static constexpr int LDS = A_END + MI_BYTES + O_BYTES + 2 * 1024 + EXPS * 4 + 64 + 1024 + (COLSC ? 1024 : 0);  // (+ the bias vector, + the column scales)
 };
 
 // Schedule of one tile step j (all waves; MFMAs of tile j in the A buffer j % 3):
@@ -433,9 +495,12 @@ struct Gemm4Cfg {
 // All vector-memory traffic of a step is one burst with a full step of slack, so neither HBM latency nor a momentary
 // shortage of bandwidth stalls the matrix cores; loads and stores may complete in any order (the counter is only ever
 // waited down to zero).
-template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
+// COLSC: a.b_inv points to one inverse scale per output column (mlp_prep4c_kernel) instead of one per matrix, a.bias (EPI 0) is
+// pre-scaled; the epilogue multiplies output column c by b_inv[c] behind the ReLU / the mask (powers of two: exact).
+template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW, bool COLSC = false>
 __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, const int G, unsigned char* smem, const int tiles_in = -1) {
-    using Cfg = Gemm4Cfg<KS, ROWB, PLANEB, EPI, DUAL, NCW>;
+    using Cfg = Gemm4Cfg<KS, ROWB, PLANEB, EPI, DUAL, NCW, COLSC>;
+    static_assert(!COLSC || (!DUAL && EPI != 2), "column scales: the round-6 kernel forms only");
     constexpr int PITCH = Cfg::PITCH, ABYTES = Cfg::ABYTES;
     constexpr int LPR = ROWB / 16;                           // 16-byte pieces (lanes) per row
     constexpr int RPI = LPR == 64 ? 1 : 64 / (LPR + 1);      // rows per copy instruction (one idle lane = the row pad)
@@ -449,6 +514,7 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
     float* tmaxs = reinterpret_cast<float*>(mbuf + 512);                         // [8] wave maxima
     int* exps = reinterpret_cast<int*>(tmaxs + 16);                              // [EXPS]
     float* biasl = reinterpret_cast<float*>(exps + Cfg::EXPS);                   // [256] (EPI 0: read per tile, not held in registers)
+    float* scl = biasl + 256;                                                    // [256] (COLSC: inverse column scales)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
     // tiles bx, bx + G, ... (tiles_in < 0: all of them up to a.ntiles; else exactly tiles_in of them)
@@ -485,6 +551,7 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
     if (my_tiles > 1) G4_COPY(bx + G, 1)
     for (int t = tid; t < my_tiles && t < Cfg::EXPS; t += 512) exps[t] = a.Aexp[bx + t * G];
     if (EPI == 0 && tid < 256) biasl[tid] = a.bias[tid];
+    if (COLSC && EPI != 3 && tid < 256) scl[tid] = tid < NCOLS ? a.b_inv[tid] : 1.0f;
 #ifdef P4_TIMING
     const unsigned long long t_p1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -494,6 +561,7 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
     f16x8 wh2[DUAL ? KS : 1], wl2[DUAL ? KS : 1];
     float binv = 0.f, binv2 = 0.f;
     float bias[16], bias2[DUAL ? 16 : 1];
+    float scol[(COLSC && EPI == 3) ? 16 : 1];
     if (computing) {
         const int col = wv * 32 + li;
 #pragma unroll
@@ -505,13 +573,14 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
                 wh2[DUAL ? ks : 0] = as_f16x8(b2[0]), wl2[DUAL ? ks : 0] = as_f16x8(b2[2 * NCOLS]);
             }
         }
-        binv = a.b_inv[0];
+        binv = COLSC ? 1.0f : a.b_inv[0];
         if (DUAL) binv2 = a.b_inv2[0];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int o = wv * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
             bias[i] = 0.f;
             if (EPI == 3) bias[i] = o < a.n_valid ? a.bias[o] : 0.f;
+            if (COLSC && EPI == 3) scol[(COLSC && EPI == 3) ? i : 0] = o < a.n_valid ? a.b_inv[o] : 0.f;
             if (DUAL) bias2[DUAL ? i : 0] = a.bias2[o];
         }
     }
@@ -596,7 +665,8 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const int o = (i & 3) + 8 * (i >> 2) + 4 * g;
-                    if (o < a.n_valid && row < a.M) a.out[(size_t)row * a.ldo + o] = (P4_CH2 ? acc[i] + acc2[i] : acc[i]) * c + bias[i];
+                    if (o < a.n_valid && row < a.M)
+                        a.out[(size_t)row * a.ldo + o] = (P4_CH2 ? acc[i] + acc2[i] : acc[i]) * (COLSC ? c * scol[(COLSC && EPI == 3) ? i : 0] : c) + bias[i];
                 }
             }
             ab = ab == 2 ? 0 : ab + 1;
@@ -656,6 +726,7 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
         float m = 0.f;
         int eo = 0;
         float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+        float4 sq = make_float4(1.f, 1.f, 1.f, 1.f);
         uint4 sv[4], smv = make_uint4(0u, 0u, 0u, 0u);
         const unsigned char* ps = Abuf + ab * ABYTES + li * PITCH + g * 16;
         if (HS.value && KS > 1) {  // tile j-2's staged rows (and its mask block) back from LDS, long before E2 overwrites the tile
@@ -671,6 +742,8 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
 #define G4_E1(i_)                                                                                                      \
     {                                                                                                                  \
         float t_;                                                                                                      \
+        if (COLSC && ((i_) & 3) == 3) sq = *reinterpret_cast<const float4*>(scl + wv * 32 + 8 * ((i_) >> 2) + 4 * g);   \
+        const float s_ = ((i_) & 3) == 0 ? sq.x : ((i_) & 3) == 1 ? sq.y : ((i_) & 3) == 2 ? sq.z : sq.w;              \
         if (EPI == 0) {                                                                                                \
             const float4 bb_ = bq[EPI == 0 ? ((i_) >> 2) : 0];                                                         \
             t_ = pv[i_] * c + (((i_) & 3) == 0 ? bb_.x : ((i_) & 3) == 1 ? bb_.y : ((i_) & 3) == 2 ? bb_.z : bb_.w);    \
@@ -678,10 +751,10 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
             const float4 cq_ = cin_prev[EPI == 2 ? ((i_) >> 2) : 0];                                                   \
             t_ = pv[i_] * c + (((i_) & 3) == 0 ? cq_.x : ((i_) & 3) == 1 ? cq_.y : ((i_) & 3) == 2 ? cq_.z : cq_.w);    \
         } else t_ = pv[i_] * c;                                                                                        \
-        if (EPI == 1) pv[i_] = ((mh_prev >> (i_)) & 1u) ? t_ : 0.f;                                                    \
+        if (EPI == 1) pv[i_] = ((mh_prev >> (i_)) & 1u) ? (COLSC ? t_ * s_ : t_) : 0.f;                                \
         else {                                                                                                         \
             asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(t_) : "vcc"); \
-            pv[i_] = p4_max(t_, 0.f);                                                                                  \
+            pv[i_] = COLSC ? p4_max(t_, 0.f) * s_ : p4_max(t_, 0.f);                                                   \
         }                                                                                                              \
         m = p4_max_abs(m, pv[i_]);                                                                                     \
     }
@@ -876,11 +949,11 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
 #undef G4_MFMA
 }
 
-template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW>
+template <int KS, int ROWB, int PLANEB, int EPI, bool DUAL, int NCW, bool COLSC = false>
 __global__ void __launch_bounds__(512)
 mlp_gemm4_kernel(const Gemm4Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char p4_smem[];
-    gemm4_body<KS, ROWB, PLANEB, EPI, DUAL, NCW>(a, (int)blockIdx.x, (int)gridDim.x, p4_smem);
+    gemm4_body<KS, ROWB, PLANEB, EPI, DUAL, NCW, COLSC>(a, (int)blockIdx.x, (int)gridDim.x, p4_smem);
 }
 
 // ---- weight gradient on planes -----------------------------------------------------------------------------------------------
@@ -1144,6 +1217,7 @@ mlp_dw4_kernel(const Dw4Args a) {
 // in the matrix cores at ~0.5 of the HBM roof, the weight gradient by HBM.  The first n_dw workgroups run the weight-gradient
 // body on n_dw row chunks, the others the layer GEMM on the remaining CUs.  Besides running a memory-bound and a compute-bound
 // stream side by side this cuts the per-chunk partial tiles (and the reduction that reads them) from one per CU to n_dw.
+template <bool COLSC>
 __global__ void __launch_bounds__(512)
 mlp_bwd_pair_kernel(const Gemm4Args ga, const Dw4Args da, const int n_dw, const int chunked) {
     extern __shared__ __attribute__((aligned(16))) unsigned char p4_smem[];
@@ -1156,9 +1230,9 @@ mlp_bwd_pair_kernel(const Gemm4Args ga, const Dw4Args da, const int n_dw, const 
         const int w = (int)blockIdx.x - n_dw;
         const int first = w * da.tiles_per_chunk;
         const int cnt = min(da.tiles_per_chunk, ga.ntiles - first);
-        gemm4_body<16, 1024, 512, 1, false, 8>(ga, first, 1, p4_smem, cnt > 0 ? cnt : 0);
+        gemm4_body<16, 1024, 512, 1, false, 8, COLSC>(ga, first, 1, p4_smem, cnt > 0 ? cnt : 0);
     } else {
-        gemm4_body<16, 1024, 512, 1, false, 8>(ga, (int)blockIdx.x - n_dw, (int)gridDim.x - n_dw, p4_smem);
+        gemm4_body<16, 1024, 512, 1, false, 8, COLSC>(ga, (int)blockIdx.x - n_dw, (int)gridDim.x - n_dw, p4_smem);
     }
 }
 

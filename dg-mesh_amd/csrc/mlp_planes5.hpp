@@ -23,8 +23,11 @@
 #ifndef P5_W_AGPR
 #define P5_W_AGPR 12  // K steps whose weight fragments live in AGPRs (16 registers each); the accumulators take 32 more
 #endif
+#ifndef P5_BQ_AHEAD
+#define P5_BQ_AHEAD 1  // the bias of an E1 slice fetched one slice ahead (0: with the slice's column scales, just in time)
+#endif
 #ifndef P5_W_AGPR_SKIP
-#define P5_W_AGPR_SKIP 13  // the same for the K = 320 form (13: the one split that leaves no scratch access inside the steady-state
+#define P5_W_AGPR_SKIP 14  // the same for the K = 320 form (13: the one split that leaves no scratch access inside the steady-state
                            // loop -- a scratch load there waits for vmcnt(0), i.e. for the tile copies just issued)
 #endif
 
@@ -37,7 +40,7 @@ struct Gemm5Args {
     const unsigned char* A2;    // KS2 > 0: embedding planes [Np][2][64]
     const int* A2exp;           // [ntiles]
     const uint4* Bp;            // weight planes, K steps in execution order: KS2 embedding steps, then the 16 trunk steps
-    const float* b_inv;         // [1] 1 / weight scale
+    const float* b_inv;         // [256] inverse column scales (mlp_prep4c_kernel); bias is pre-scaled
     const float* bias;          // [256] (EPI 0)
     const unsigned* mask_in;    // EPI 1
     unsigned* mask_out;         // EPI 0
@@ -56,8 +59,8 @@ struct Gemm5Cfg {
     static constexpr int A_END = NBUF * ABYTES;
     static constexpr int MI_BYTES = EPI == 1 ? NBUF * 1024 : 0;      // mask blocks of the same three tiles (EPI 1)
     static constexpr int O_BYTES = 32768;                            // staging tile of the output planes
-    static constexpr int EXPS = 128;                                 // input exponents of the workgroup's tiles (1 M rows on 256 CUs)
-    static constexpr int LDS = A_END + MI_BYTES + O_BYTES + 2 * 1024 + 64 + EXPS * 4 * (KS2 > 0 ? 2 : 1) + 1024;
+    static constexpr int EXPS = KS2 > 0 ? 64 : 128;                  // input exponents of the workgroup's tiles (>= 0.5 M rows on 256 CUs)
+    static constexpr int LDS = A_END + MI_BYTES + O_BYTES + 2 * 1024 + 64 + EXPS * 4 * (KS2 > 0 ? 2 : 1) + 1024 + 1024;  // (+ bias, + column scales)
     static_assert(LDS <= 160 * 1024, "LDS budget of a gfx950 CU");
 };
 
@@ -77,6 +80,7 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
     int* exps = reinterpret_cast<int*>(tmaxs + 16);                               // [EXPS]
     int* exps2 = exps + Cfg::EXPS;                                                // [EXPS] (KS2)
     float* biasl = reinterpret_cast<float*>(exps2 + (KS2 > 0 ? Cfg::EXPS : 0));   // [256]
+    float* scl = biasl + 256;                                                     // [256] inverse column scales
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
     const int my_tiles = tiles_in >= 0 ? tiles_in : (a.ntiles - bx + G - 1) / G;
@@ -87,8 +91,7 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
     // + one idle lane = the 16-byte row pad).  A wave issues instructions i = 0..7 (trunk row 4 i + wv) and, with KS2, 8..10
     // (embedding instruction n = 4 (i - 8) + wv < 11).
     const unsigned abuf_lds = p4_lds_addr(Abuf), mibuf_lds = p4_lds_addr(Mibuf);
-    const int c2_row = lane / 17, c2_piece = lane - 17 * c2_row;
-    const bool c2_ok = c2_piece < 16 && c2_row < 3;
+    // (the embedding copies' lane geometry -- row lane / 17, piece lane % 17 -- is recomputed at each use: three registers matter here)
     constexpr int NCP = KS2 > 0 ? 11 : 8;  // copy instructions per wave and tile
 #define G5_COPY1(tile_, buf_, i_)                                                                                      \
     {                                                                                                                  \
@@ -99,6 +102,11 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
         } else if (KS2 > 0) {                                                                                          \
             const int n_ = 4 * ((i_) - 8) + wv;                                                                        \
             if (n_ < 11) {                                                                                             \
+                int l2_ = lane;                                                                                        \
+                asm volatile("" : "+v"(l2_));  /* (opaque: keeps the compiler from hoisting this lane geometry out of the tile  \
+                                                  loop into a register pair it then spills to scratch) */                      \
+                const int c2_row = l2_ / 17, c2_piece = l2_ - 17 * c2_row;                                             \
+                const bool c2_ok = c2_piece < 16 && c2_row < 3;                                                        \
                 const int row_ = 3 * n_ + c2_row;                                                                      \
                 if (c2_ok && row_ < 32)                                                                                \
                     p4_glds16(a.A2 + ((size_t)(tile_) * 32 + row_) * 256 + c2_piece * 16,                              \
@@ -125,6 +133,7 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
         if (KS2 > 0) exps2[t] = a.A2exp[bx + t * G];
     }
     if (EPI == 0) biasl[tid] = a.bias[tid];
+    scl[tid] = a.b_inv[tid];
 
     // stationary weights: the M-side fragments of this wave's two 32-column blocks (blocks 2 wv, 2 wv + 1 of the eight)
     // The first P5_W_AGPR K steps' fragments are loaded straight into accumulation registers (an asm load with an "a" result:
@@ -144,7 +153,6 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
                 wh[cb][ks] = as_f16x8(b[0]), wl[cb][ks] = as_f16x8(b[512]);
         }
     }
-    const float binv = a.b_inv[0];
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc0 = zero16, acc1 = zero16;
@@ -212,7 +220,7 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
                 mh_next0 = mp[0], mh_next1 = mp[2];
             }
         }
-        const float c = binv * p4_pow2(-e_prev);
+        const float c = p4_pow2(-e_prev);
         unsigned bits0 = 0u, bits1 = 0u;
         float m = 0.f;
         int eo = 0;
@@ -221,30 +229,31 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
         const unsigned char* ps1 = Abuf + ab * ABYTES + li * P1 + g * 16;
         const unsigned char* ps2 = Abuf + ab * ABYTES + A1BYTES + li * P2 + g * 16;
         // E1 of elements 4 q + 3 .. 4 q of block cb_ of tile j-1: unscale, bias / mask, ReLU bit, running maximum -- in place
-#define G5_E1_ONE(pv_, bits_, mh_, i_, b_)                                                                             \
+#define G5_E1_ONE(pv_, bits_, mh_, i_, b_, s_)                                                                         \
     {                                                                                                                  \
         float t_ = EPI == 0 ? pv_[i_] * c + (b_) : pv_[i_] * c;                                                        \
-        if (EPI == 1) pv_[i_] = (((mh_) >> (i_)) & 1u) ? t_ : 0.f;                                                     \
+        if (EPI == 1) pv_[i_] = (((mh_) >> (i_)) & 1u) ? t_ * (s_) : 0.f;                                              \
         else {                                                                                                         \
             asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits_) : "v"(t_) : "vcc"); \
-            pv_[i_] = p4_max(t_, 0.f);                                                                                 \
+            pv_[i_] = p4_max(t_, 0.f) * (s_);                                                                          \
         }                                                                                                              \
         m = p4_max_abs(m, pv_[i_]);                                                                                    \
     }
 #define G5_E1(s_)                                                                                                      \
     {                                                                                                                  \
         constexpr int cb_ = (s_) >> 2, q_ = 3 - ((s_) & 3);                                                            \
-        const float4 bb_ = bq;                                                                                         \
-        if (EPI == 0 && (s_) < 7) {                                                                                    \
+        const float4 bb_ = (EPI == 0 && !P5_BQ_AHEAD) ? *reinterpret_cast<const float4*>(biasl + (2 * wv + cb_) * 32 + 8 * q_ + 4 * g) : bq; \
+        const float4 ss_ = *reinterpret_cast<const float4*>(scl + (2 * wv + cb_) * 32 + 8 * q_ + 4 * g);               \
+        if (EPI == 0 && P5_BQ_AHEAD && (s_) < 7) {                                                                                    \
             constexpr int cn_ = ((s_) + 1) >> 2, qn_ = 3 - (((s_) + 1) & 3);                                           \
             bq = *reinterpret_cast<const float4*>(biasl + (2 * wv + cn_) * 32 + 8 * qn_ + 4 * g);                       \
         }                                                                                                              \
         if (cb_ == 0) {                                                                                                \
-            G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 3, bb_.w) G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 2, bb_.z)     \
-            G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 1, bb_.y) G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 0, bb_.x)     \
+            G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 3, bb_.w, ss_.w) G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 2, bb_.z, ss_.z) \
+            G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 1, bb_.y, ss_.y) G5_E1_ONE(pv0, bits0, mh_prev0, 4 * q_ + 0, bb_.x, ss_.x) \
         } else {                                                                                                       \
-            G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 3, bb_.w) G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 2, bb_.z)     \
-            G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 1, bb_.y) G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 0, bb_.x)     \
+            G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 3, bb_.w, ss_.w) G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 2, bb_.z, ss_.z) \
+            G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 1, bb_.y, ss_.y) G5_E1_ONE(pv1, bits1, mh_prev1, 4 * q_ + 0, bb_.x, ss_.x) \
         }                                                                                                              \
     }
         // E2 of the same four elements: scale to the tile exponent, split, 8 bytes per plane into the staging tile
@@ -289,13 +298,15 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
             }
             if (ks < H1) {
                 if (HS.value) {  // tile j-2's rows: LDS reads up front, two row stores per K step early in the first half
+                    // (two rows at a time, read one K step ahead of their stores: eight staged rows in flight at once cost the K = 320
+                    // form the registers it does not have -- one weight fragment went to scratch, and a scratch reload waits for vmcnt(0))
                     if (ks == 0) {
-                        G5_SREAD(0) G5_SREAD(1) G5_SREAD(2) G5_SREAD(3)
+                        G5_SREAD(0) G5_SREAD(1)
                         if (EPI == 0 && wv == 3) smv = reinterpret_cast<const uint4*>(mbuf + pb * 256)[lane];
                     }
-                    if (ks == 1) { G5_SROW(0) G5_SROW(1) }
-                    if (ks == 2) { G5_SROW(2) G5_SROW(3) G5_SREAD(4) G5_SREAD(5) G5_SREAD(6) G5_SREAD(7) }
-                    if (ks == 3) { G5_SROW(4) G5_SROW(5) }
+                    if (ks == 1) { G5_SROW(0) G5_SROW(1) G5_SREAD(2) G5_SREAD(3) }
+                    if (ks == 2) { G5_SROW(2) G5_SROW(3) G5_SREAD(4) G5_SREAD(5) }
+                    if (ks == 3) { G5_SROW(4) G5_SROW(5) G5_SREAD(6) G5_SREAD(7) }
                     if (ks == 4) {
                         G5_SROW(6) G5_SROW(7)
                         if (EPI == 0 && wv == 3) reinterpret_cast<uint4*>(a.mask_out + (size_t)(tile - 2 * G) * 256)[lane] = smv;
@@ -370,12 +381,12 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
                 const unsigned char* ps2 = Abuf + abn * ABYTES + A1BYTES + li * P2 + g * 16;
                 G5_FRAG(0)
             }
-            if (EPI == 0) bq = *reinterpret_cast<const float4*>(biasl + (2 * wv) * 32 + 8 * 3 + 4 * g);
+            if (EPI == 0 && P5_BQ_AHEAD) bq = *reinterpret_cast<const float4*>(biasl + (2 * wv) * 32 + 8 * 3 + 4 * g);
         }
         // END: the staging tile and the A buffer change hands (the reads just issued stay in flight: this wave's LDS writes are
         // older and LDS operations complete in order)
-        if (HM.value && j + 1 < my_tiles) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"((EPI == 0 ? 1 : 0) + 2) : "memory");
-        else if (HM.value && EPI == 0) asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" ::: "memory");
+        if (HM.value && j + 1 < my_tiles) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"((EPI == 0 && P5_BQ_AHEAD ? 1 : 0) + 2) : "memory");
+        else if (HM.value && EPI == 0 && P5_BQ_AHEAD) asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" ::: "memory");
         else P4_LDS_BARRIER();
     };
     {   // first fragments of tile 0
