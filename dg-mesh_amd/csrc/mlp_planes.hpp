@@ -698,6 +698,7 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
     // of the tile and the bias of this lane's sixteen columns (from LDS: held in registers only through the first half)
     f16x8 fh[P4_PD + 1], fl[P4_PD + 1];
     float4 bq[EPI == 0 ? 4 : 1];
+    float4 sqn = make_float4(1.f, 1.f, 1.f, 1.f);  // COLSC: the column scales of the next E1 group (fetched a group ahead)
     // the copy of a tile, one instruction at a time (spread over the second half's K steps)
 #define G4_COPY1(tile_, buf_, n0_)                                                                                     \
     {                                                                                                                  \
@@ -742,7 +743,10 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
 #define G4_E1(i_)                                                                                                      \
     {                                                                                                                  \
         float t_;                                                                                                      \
-        if (COLSC && ((i_) & 3) == 3) sq = *reinterpret_cast<const float4*>(scl + wv * 32 + 8 * ((i_) >> 2) + 4 * g);   \
+        if (COLSC && ((i_) & 3) == 3) {  /* this group's scales were asked for a group ago (the first: at the previous step's end) */ \
+            sq = sqn;                                                                                                  \
+            if ((i_) >= 4) sqn = *reinterpret_cast<const float4*>(scl + wv * 32 + 8 * (((i_) >> 2) - 1) + 4 * g);       \
+        }                                                                                                              \
         const float s_ = ((i_) & 3) == 0 ? sq.x : ((i_) & 3) == 1 ? sq.y : ((i_) & 3) == 2 ? sq.z : sq.w;              \
         if (EPI == 0) {                                                                                                \
             const float4 bb_ = bq[EPI == 0 ? ((i_) >> 2) : 0];                                                         \
@@ -902,13 +906,14 @@ __device__ __forceinline__ void gemm4_body(const Gemm4Args& a, const int bx, con
 #pragma unroll
                 for (int q = 0; q < 4; q++) bq[EPI == 0 ? q : 0] = *reinterpret_cast<const float4*>(biasl + wv * 32 + 8 * q + 4 * g);
             }
+            if (COLSC) sqn = *reinterpret_cast<const float4*>(scl + wv * 32 + 8 * 3 + 4 * g);
         }
         P4_T(5)
         // END: the staging tile and the A buffer change hands (the reads just issued stay in flight: this wave's LDS writes are
         // older and LDS operations complete in order)
         if (HM.value && j + 1 < my_tiles)
-            asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"((EPI == 0 ? 4 : 0) + 2 * (P4_PD < KS ? P4_PD : KS)) : "memory");
-        else if (HM.value && EPI == 0) asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"((EPI == 0 ? 4 : 0) + 2 * (P4_PD < KS ? P4_PD : KS) + (COLSC ? 1 : 0)) : "memory");
+        else if (HM.value && EPI == 0) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(4 + (COLSC ? 1 : 0)) : "memory");
         else P4_LDS_BARRIER();
         P4_T(6)
     };

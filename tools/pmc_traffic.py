@@ -17,12 +17,12 @@ KERNELS = {"render_bwd4": "render_bwd4_kernel", "render_fwd": "render_fwd_kernel
            "tile_sort_radix": "tile_sort_radix_kernel", "reduce_dw": "mlp_reduce_dw_all_kernel", "scatter": "dgm::scatter_kernel",
            "count_tiles": "count_tiles_kernel", "tile_scan": "tile_scan_kernel",
            # the plane arithmetic
-           "gemm4_fwd": "mlp_gemm4_kernel<16, 1024, 512, 0, false, 8>", "gemm4_bwd": "mlp_gemm4_kernel<16, 1024, 512, 1, false, 8>",
+           "gemm4_fwd": "mlp_gemm4_kernel<16, 1024, 512, 0, false, 8", "gemm4_bwd": "mlp_gemm4_kernel<16, 1024, 512, 1, false, 8",
            "dw4": "mlp_dw4_kernel<8, 8, 1024, 512, 1024, 512>", "gemm4_skip": "mlp_gemm4_kernel<16, 1024, 512, 2, false, 8>",
            "gemm4_l0": "mlp_gemm4_kernel<6, 384, 192, 0, true, 8>", "dw4_emb": "mlp_dw4_kernel<3, 8, 384, 192, 1024, 512>",
            "embed4": "mlp_embed4_kernel", "bwd_pair": "mlp_bwd_pair_kernel",
            # round 6: one time row per call folded into the biases
-           "gemm5_skip": "mlp_gemm5_kernel<4, 0>", "gemm4_l0f": "mlp_gemm4_kernel<4, 256, 128, 0, false, 8>",
+           "gemm5_skip": "mlp_gemm5_kernel<4, 0>", "gemm4_l0f": "mlp_gemm4_kernel<4, 256, 128, 0, false, 8",
            "dw4_emb64": "mlp_dw4_kernel<2, 8, 256, 128, 1024, 512>"}
 # kernels whose reads are gathers of short records: the x2 streaming-read correction of FETCH_SIZE is not calibrated for them
 GATHER = {"render_bwd4", "render_fwd", "preprocess_bwd", "tile_sort_radix", "scatter", "count_tiles", "tile_scan"}
