@@ -157,17 +157,30 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
     v = DGM_DPP_STEP(OP, v, ident, 0x118, 0xf); /* row_shr:8 */  \
     v = DGM_DPP_STEP(OP, v, ident, 0x142, 0xa); /* row_bcast:15 -> rows 1, 3 */ \
     v = DGM_DPP_STEP(OP, v, ident, 0x143, 0xc); /* row_bcast:31 -> rows 2, 3 */
+// (row_bcast exists on gfx9-family hardware only, and these helpers return garbage from a partially active wave: a -DDGM_DEBUG build
+// traps on both instead of computing on)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "dgm_common.hpp: the DPP wave scans use row_bcast15 / row_bcast31 (wave64, gfx9 family): gfx950 only"
+#endif
+#ifdef DGM_DEBUG
+#define DGM_ASSERT_FULL_WAVE() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define DGM_ASSERT_FULL_WAVE() do { } while (0)
+#endif
 __device__ __forceinline__ unsigned dgm_op_add(unsigned a, unsigned b) { return a + b; }
 __device__ __forceinline__ unsigned dgm_op_max(unsigned a, unsigned b) { return a > b ? a : b; }
 __device__ __forceinline__ unsigned wave_inclusive_scan_u32(unsigned v) {
+    DGM_ASSERT_FULL_WAVE();
     DGM_DPP_SCAN(dgm_op_add, v, 0u)
     return v;
 }
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {  // (in every lane)
+    DGM_ASSERT_FULL_WAVE();
     DGM_DPP_SCAN(dgm_op_add, v, 0u)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {  // (in every lane)
+    DGM_ASSERT_FULL_WAVE();
     DGM_DPP_SCAN(dgm_op_max, v, 0u)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
