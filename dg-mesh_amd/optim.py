@@ -78,7 +78,9 @@ class MultiAdam:
         """The call that repeats the previous one -- the same entries have a gradient (and the others still have none), each where
         it sat -- only rewrites the gradient pointers, one learning rate per run of a param_group and the common step count:
         ~0.6 us per tensor instead of ~5.  Anything unusual returns False and the general path below does the work (and re-validates
-        the bound state every 64 calls)."""
+        the bound state every 64 calls).  Known limit: an IN-PLACE edit of a step tensor (`state[p]["step"].fill_(k)`) keeps the
+        tensor's identity, so this path goes on counting from its own `cnt` and the edit takes effect at the next re-validation --
+        within 64 calls; replacing the tensor (what checkpoint loading and the densification surgery do) is seen at once."""
         f32, ptrs = torch.float32, []
         params, shapes = pl["params"], pl["shapes"]
         # the bound state must still be the live one: in-place surgery on an unchanged Parameter (state[p] replaced, a moment or
