@@ -42,7 +42,7 @@ hipError_t launch_tile_sort(hipStream_t st, int tiles, const uint2* ranges, cons
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
                        unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, size_t R, unsigned* uctl,
-                       uint4* ulist_full, uint4* ulist_last, uint8_t* live);
+                       uint4* ulist_full, uint4* ulist_last, uint8_t* live, const unsigned* tile_order);
 void launch_render_bwd4(hipStream_t st, int tiles, size_t R, const uint2* ranges, const unsigned* point_list, int W, int H,
                         int gridx, const float* bg, const float* rec, const float4* cfin, const float4* ckpt,
                         const float4* ckpt64, const unsigned* n_contrib, const float* dL_dpix, float* slab,
@@ -437,7 +437,7 @@ static int forward_impl(dgm_alloc_fn geom_alloc, void* geom_ctx, dgm_alloc_fn bi
     tm.begin(DGM_STAGE_RENDER_FWD);
     launch_render_fwd(st, tiles, ranges, point_list, width, height, gridx, rec, background, out_color, final_T,
                       n_contrib, ckpt, cfin, ckpt64, nproc, (size_t)R, counters + 8, (uint4*)(bin + L.ulist_full),
-                      (uint4*)(img + L.ulist_last), (uint8_t*)(bin + L.live));
+                      (uint4*)(img + L.ulist_last), (uint8_t*)(bin + L.live), tile_count);
     DGM_CHECK("render_fwd");
     tm.end(DGM_STAGE_RENDER_FWD);
     tm.finish();

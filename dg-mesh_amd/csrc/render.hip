@@ -288,11 +288,13 @@ render_fwd_async_kernel(const uint2* __restrict__ ranges, const unsigned* __rest
                         float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
                         float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out, const int ulog,
                         unsigned* __restrict__ uctl, uint4* __restrict__ ulist_full, uint4* __restrict__ ulist_last,
-                        uint8_t* __restrict__ live) {
+                        uint8_t* __restrict__ live, const unsigned* __restrict__ tile_order) {
     __shared__ float4 sRw[4][64 * 3];  // per wave: the round's 64 staged splats (layout as in render_fwd_kernel)
     __shared__ unsigned sMaxC[4];
     __shared__ unsigned sUnitBase;
-    const int tile = blockIdx.x;
+    // (tiles in descending order of their list length, tile_scan_kernel: every workgroup of a sparse frame is resident at once, so
+    // what balances the CUs is the order in which the tiles are handed out)
+    const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int px = tile_x * DGM_TILE + (wv & 1) * 8 + (lane & 7);
@@ -303,6 +305,11 @@ render_fwd_async_kernel(const uint2* __restrict__ ranges, const unsigned* __rest
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int rounds = (n + 63) >> 6;
+#if RF_TRACE
+    const unsigned long long tr_t0 = __builtin_readcyclecounter(), tr_w0 = wall_clock64();
+    unsigned long long tr_t_first = 0, tr_t_loop_end = 0;
+    unsigned tr_tested = 0;
+#endif
     for (int i = threadIdx.x; i < n; i += 256) live[range.x + i] = 0;
     const bool shortlist = n <= DGM_SHORT_LIST;
     const int ulen_log = shortlist ? ulog : 8;          // checkpoint interval: u entries, 256 beyond DGM_SHORT_LIST
@@ -317,14 +324,28 @@ render_fwd_async_kernel(const uint2* __restrict__ ranges, const unsigned* __rest
     unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
     int s_next = 1;  // next boundary this wave has not written
 
-    // round 0's entry and record; afterwards the next round's are fetched while the current one blends
-    unsigned g_next = 0u;
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
-    float ncb = 0.f;
-    if (lane < n) {
-        g_next = point_list[range.x + lane];
-        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g_next * DGM_REC_STRIDE);
-        n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
+    // Staging is two dependent gathers (list slice -> records).  A quadrant that culls most of a round's entries has little work
+    // to hide them behind -- its rounds then cost the memory round trips, not the blend -- so both are asked for well ahead: at the
+    // top of round i the records of round i + 2 (their list entries were asked for a round earlier) and the list slice of round i + 3.
+    // (First version: the next round's list slice at the top of a round and its records half way through: 0.079-0.086 ms on the
+    // trained-like scene; two, or four, entries per trip made no difference -- the rounds were waiting for memory.)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = z4, n1 = z4, m0 = z4, m1 = z4;   // n: records of the round about to be staged, m: of the round behind it
+    float ncb = 0.f, mcb = 0.f;
+    unsigned g3 = 0u;                            // list entry of the round two behind it
+    {
+        unsigned ga = 0u, gb = 0u;
+        if (lane < n) ga = point_list[range.x + lane];
+        if (64 + lane < n) gb = point_list[range.x + 64 + lane];
+        if (128 + lane < n) g3 = point_list[range.x + 128 + lane];
+        if (lane < n) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)ga * DGM_REC_STRIDE);
+            n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
+        }
+        if (64 + lane < n) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)gb * DGM_REC_STRIDE);
+            m0 = r4[0], m1 = r4[1], mcb = r4[2].x;
+        }
     }
     for (int i = 0; i < rounds; i++) {
         if (done_m == ~0ull) break;  // every pixel of this quadrant has terminated (the boundaries left are filled in below)
@@ -339,19 +360,22 @@ render_fwd_async_kernel(const uint2* __restrict__ ranges, const unsigned* __rest
         }
         const unsigned long long mask = uniform_u64(__ballot(hit));
         const unsigned base = (unsigned)(i << 6);
-        const int at_next = ((i + 1) << 6) + lane;
-        const bool more = i + 1 < rounds;  // (wave-uniform)
-        if (more && at_next < n) g_next = point_list[range.x + at_next];
+        n0 = m0, n1 = m1, ncb = mcb;  // (staged: the next round's records move up)
+        if (((i + 2) << 6) + lane < n) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g3 * DGM_REC_STRIDE);
+            m0 = r4[0], m1 = r4[1], mcb = r4[2].x;
+        }
+        if (((i + 3) << 6) + lane < n) g3 = point_list[range.x + ((i + 3) << 6) + lane];
         const int nsub = 64 >> (ulen_log < 6 ? ulen_log : 6);  // checkpoint intervals inside a round (2 at u = 32, else 1)
 #pragma unroll 1
         for (int sb = 0; sb < nsub; sb++) {
-            if (sb == nsub - 1 && more && at_next < n) {  // (the list entry asked for above has arrived by now)
-                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g_next * DGM_REC_STRIDE);
-                n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
-            }
             unsigned long long m = mask;
             if (nsub == 2) m &= sb == 0 ? 0xffffffffull : 0xffffffff00000000ull;
             while (m) {
+#if RF_TRACE
+                if (tr_t_first == 0) tr_t_first = __builtin_readcyclecounter();
+                tr_tested += (unsigned)__popcll(m) >= 2u ? 2u : 1u;
+#endif
                 const int ja = __builtin_ctzll(m);
                 m &= m - 1;
                 const bool two = m != 0ull;
@@ -406,6 +430,9 @@ render_fwd_async_kernel(const uint2* __restrict__ ranges, const unsigned* __rest
             }
         }
     }
+#if RF_TRACE
+    tr_t_loop_end = __builtin_readcyclecounter();
+#endif
     {
         const unsigned mx = wave_max_u32(inside ? last_contributor : 0u);
         if (lane == 0) sMaxC[wv] = mx;
@@ -416,6 +443,262 @@ render_fwd_async_kernel(const uint2* __restrict__ ranges, const unsigned* __rest
         const unsigned nunits = n > 0 ? max(1u, (np + ulen - 1u) >> ulen_log) : 0u;
         // boundaries 1 .. nunits - 1 are read by the backward: the ones this wave did not reach get its final state (it left the loop
         // with every pixel terminated -- or at the end of the list, where nothing is missing)
+        for (int s = s_next; s < (int)nunits; s++) cbase[(size_t)s * 256] = make_float4(T, C0, C1, C2);
+        if (n > 0) {
+            const unsigned tag = (unsigned)tile | (shortlist ? 0x80000000u : 0u);
+            if (threadIdx.x == 0) {
+                sUnitBase = nunits > 1u ? atomicAdd(&uctl[0], nunits - 1u) : 0u;
+                const unsigned bl = atomicAdd(&uctl[DGM_UCTL_LINE], 1u);
+                ulist_last[bl] = make_uint4(tag, nunits - 1u, range.x, np);
+            }
+            __syncthreads();
+            uint4* dst = ulist_full + sUnitBase;
+            for (unsigned k = threadIdx.x; k + 1u < nunits; k += 256u) dst[k] = make_uint4(tag, k, range.x, np);
+        }
+    }
+    {
+        const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
+        cfin[(size_t)tile * 256 + (size_t)((ly >> 2) * 64 + ((ly & 3) << 4) + lx)] = make_float4(T, C0, C1, C2);
+    }
+    if (inside) {
+        const size_t pid = (size_t)W * py + px;
+        const size_t plane = (size_t)W * H;
+        final_T[pid] = T;
+        n_contrib[pid] = last_contributor;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[plane + pid] = C1 + T * bg[1];
+        out_color[2 * plane + pid] = C2 + T * bg[2];
+    }
+#if RF_TRACE
+    if (lane == 0) {
+        const unsigned long long tr_t1 = __builtin_readcyclecounter(), tr_w1 = wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        const unsigned long long i = atomicAdd(&rf_trace[4 * 65536], 1ull) & 65535ull;
+        // as render_fwd_kernel's record, with the loop's share of the lifetime in the otherwise unused bits 32..47 of word 1 (units of 16 cycles)
+        rf_trace[4 * i] = (tr_w0 & ((1ull << 48) - 1ull)) | ((tr_w1 - tr_w0) << 48);
+        rf_trace[4 * i + 1] = ((unsigned long long)(xcc & 15u) << 32) | hw | ((((tr_t_loop_end - tr_t0) >> 4) & 0xffffull) << 36);
+        rf_trace[4 * i + 2] = ((tr_t1 - tr_t0) << 32) | ((tr_t_first ? tr_t_first - tr_t0 : 0ull) & 0xffffffffull);
+        rf_trace[4 * i + 3] = ((unsigned long long)(unsigned)n << 32) | ((unsigned long long)tr_tested << 8) | (unsigned)wv;
+    }
+#endif
+}
+
+// ---- sparse frames, second form (round 6): shared staging WITHOUT the lock step -------------------------------------------------------
+// render_fwd_async_kernel removed the barriers by letting every quadrant wave stage the whole list for itself; its trace
+// (tools/raster_bench.py --trace-fwd on a -DRF_TRACE=1 build) shows what that costs: a busy wave spends ~370 cycles per LIST entry --
+// not per entry it blends --, i.e. ~23 k cycles per 64-entry round, waiting for its own gathers of 48-byte records (64 distinct lines
+// per load instruction, ten waves per SIMD doing the same: the CU's address unit, not the blend, sets the pace), and every record is
+// gathered four times.  Here the tile's four waves share the staging again -- wave w gathers rounds w, w + 4, w + 8, ... into a ring
+// of RING slots in LDS and tests them against all four quadrants -- but nobody waits at a barrier: a round is published through a
+// per-wave counter in LDS, a consumer takes round c as soon as wave c % 4 has published it, and a stager refills a slot as soon as the
+// slowest consumer has left it.  A quadrant may run up to RING - 1 rounds ahead of the slowest one: a tile again costs the maximum
+// over its quadrants of their own work, with the gather traffic of the barrier form.  A wave whose pixels have all terminated keeps
+// serving its staging duty until every wave of the tile is through.  Every wait is bounded (a wave that spins too long raises a flag
+// in the frame's counter words and leaves: the frame is then wrong, but the GPU is not hung).  Same arithmetic, same blend order,
+// same outputs as the two kernels above, bit for bit; checkpoints as in the asynchronous form.
+#ifndef RF_RING
+#define RF_RING 8
+#endif
+__global__ void __launch_bounds__(256)
+render_fwd_ring_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list, int W, int H, int gridx,
+                       const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
+                       float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
+                       float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out, const int ulog,
+                       unsigned* __restrict__ uctl, uint4* __restrict__ ulist_full, uint4* __restrict__ ulist_last,
+                       uint8_t* __restrict__ live) {
+    constexpr int RING = RF_RING;
+    static_assert(RING % 4 == 0 && RING >= 4, "a slot belongs to one staging wave");
+    __shared__ float4 sRing[RING][64 * 3];
+    __shared__ unsigned long long sMaskQ[RING][4];  // [slot][quadrant]
+    __shared__ int sStaged[4], sConsumed[4], sFinished;
+    __shared__ unsigned sMaxC[4];
+    __shared__ unsigned sUnitBase;
+    const int tile = blockIdx.x;
+    const int tile_x = tile % gridx, tile_y = tile / gridx;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int px = tile_x * DGM_TILE + (wv & 1) * 8 + (lane & 7);
+    const int py = tile_y * DGM_TILE + (wv >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float tx0 = (float)(tile_x * DGM_TILE), ty0 = (float)(tile_y * DGM_TILE);
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const int rounds = (n + 63) >> 6;
+    if (threadIdx.x < 4) sStaged[threadIdx.x] = 0, sConsumed[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sFinished = 0;
+    for (int i = threadIdx.x; i < n; i += 256) live[range.x + i] = 0;
+    const bool shortlist = n <= DGM_SHORT_LIST;
+    const int ulen_log = shortlist ? ulog : 8;
+    const int lxy = (((wv >> 1) * 8 + (lane >> 3)) >> 2) * 64 + ((((wv >> 1) * 8 + (lane >> 3)) & 3) << 4) + (wv & 1) * 8 + (lane & 7);
+    float4* const cbase = shortlist ? ckpt64 + (size_t)(range.x >> ulog) * 256 + lxy : ckpt + (size_t)(range.x >> 8) * 256 + lxy;
+    volatile int* const vStaged = sStaged;
+    volatile int* const vConsumed = sConsumed;
+    volatile int* const vFinished = &sFinished;
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    unsigned last_contributor = 0;
+    unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);
+    int s_next = 1;
+
+    // this wave's staging duty: rounds wv, wv + 4, ...; the records of the next two duties and the list slice of the third are in
+    // flight (as in the asynchronous form)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = z4, n1 = z4, m0 = z4, m1 = z4;
+    float ncb = 0.f, mcb = 0.f;
+    unsigned g3 = 0u;
+    {
+        unsigned ga = 0u, gb = 0u;
+        const int a0 = (wv << 6) + lane, a1 = ((wv + 4) << 6) + lane, a2 = ((wv + 8) << 6) + lane;
+        if (a0 < n) ga = point_list[range.x + a0];
+        if (a1 < n) gb = point_list[range.x + a1];
+        if (a2 < n) g3 = point_list[range.x + a2];
+        if (a0 < n) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)ga * DGM_REC_STRIDE);
+            n0 = r4[0], n1 = r4[1], ncb = r4[2].x;
+        }
+        if (a1 < n) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)gb * DGM_REC_STRIDE);
+            m0 = r4[0], m1 = r4[1], mcb = r4[2].x;
+        }
+    }
+    __syncthreads();  // the counters are initialised
+
+    int c = 0;            // next round this wave consumes
+    int sp = wv;          // next round this wave stages
+    bool active = true;   // still consuming (wave-uniform)
+    int spins = 0;
+    while (true) {
+        if (!active && *vFinished >= 4) break;  // every quadrant is through: nobody left to stage for
+        // ---- 1. staging duty: as far ahead as the ring allows
+        if (sp < rounds) {
+            const int cmin = min(min(vConsumed[0], vConsumed[1]), min(vConsumed[2], vConsumed[3]));
+            if (sp < cmin + RING) {
+                const int slot = sp & (RING - 1);
+                float4* const sR = sRing[slot];
+                const int at = (sp << 6) + lane;
+                unsigned qm = 0u;
+                if (at < n) {
+                    const float l2e = 1.4426950408889634f;
+                    sR[3 * lane] = make_float4(n0.x, n0.y, -0.5f * l2e * n0.z, -l2e * n0.w);
+                    sR[3 * lane + 1] = make_float4(-0.5f * l2e * n1.x, n1.y, n1.z, n1.w);
+                    sR[3 * lane + 2].x = ncb;
+                    qm = quadrant_mask(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tx0, ty0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned long long bal = __ballot((qm >> q) & 1u);
+                    if (lane == 0) sMaskQ[slot][q] = bal;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) vStaged[wv] = (sp >> 2) + 1;
+                n0 = m0, n1 = m1, ncb = mcb;
+                if (((sp + 8) << 6) + lane < n) {
+                    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g3 * DGM_REC_STRIDE);
+                    m0 = r4[0], m1 = r4[1], mcb = r4[2].x;
+                }
+                if (((sp + 12) << 6) + lane < n) g3 = point_list[range.x + ((sp + 12) << 6) + lane];
+                sp += 4;
+                spins = 0;
+                continue;
+            }
+        }
+        // ---- 2. consume the next round, if its stager has published it
+        if (active) {
+            if (c >= rounds || done_m == ~0ull) {
+                active = false;
+                if (lane == 0) {
+                    vConsumed[wv] = 0x3fffffff;  // (never holds a stager back again)
+                    atomicAdd(&sFinished, 1);
+                }
+                continue;
+            }
+            if (vStaged[c & 3] > (c >> 2)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int slot = c & (RING - 1);
+                const float4* const sR = sRing[slot];
+                const unsigned long long mask = uniform_u64(sMaskQ[slot][wv]);
+                const unsigned base = (unsigned)(c << 6);
+                const int nsub = 64 >> (ulen_log < 6 ? ulen_log : 6);
+#pragma unroll 1
+                for (int sb = 0; sb < nsub; sb++) {
+                    unsigned long long m = mask;
+                    if (nsub == 2) m &= sb == 0 ? 0xffffffffull : 0xffffffff00000000ull;
+                    while (m) {
+                        const int ja = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const bool two = m != 0ull;
+                        const int jb = two ? __builtin_ctzll(m) : ja;
+                        m &= m - 1;
+                        const float4 Aa = sR[3 * ja], Ab = sR[3 * jb];
+                        const float4 Ba = sR[3 * ja + 1], Bb = sR[3 * jb + 1];
+                        const float ca = sR[3 * ja + 2].x, cbb = sR[3 * jb + 2].x;
+                        const float dxa = Aa.x - pxf, dya = Aa.y - pyf;
+                        const float dxb = Ab.x - pxf, dyb = Ab.y - pyf;
+                        const float power_a = (Aa.z * dxa + Aa.w * dya) * dxa + (Ba.x * dya) * dya;
+                        const float power_b = (Ab.z * dxb + Ab.w * dyb) * dxb + (Bb.x * dyb) * dyb;
+                        const float alpha_a = fminf(0.99f, Ba.y * __builtin_amdgcn_exp2f(power_a));
+                        const float alpha_b = fminf(0.99f, Bb.y * __builtin_amdgcn_exp2f(power_b));
+                        const unsigned long long geo_a = __builtin_amdgcn_ballot_w64(!(power_a > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha_a < 1.0f / 255.0f));
+                        const unsigned long long geo_b = __builtin_amdgcn_ballot_w64(!(power_b > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha_b < 1.0f / 255.0f)) &
+                                                         (two ? ~0ull : 0ull);
+                        {
+                            const unsigned long long pass = geo_a & ~done_m;
+                            const float test_T = T * (1.0f - alpha_a);
+                            const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                            const unsigned long long valid_m = pass & ~low;
+                            done_m |= pass & low;
+                            const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+                            const float w = valid ? alpha_a * T : 0.f;
+                            C0 += Ba.z * w;
+                            C1 += Ba.w * w;
+                            C2 += ca * w;
+                            T = valid ? test_T : T;
+                            last_contributor = valid ? base + (unsigned)ja + 1u : last_contributor;
+                        }
+                        {
+                            const unsigned long long pass = geo_b & ~done_m;
+                            const float test_T = T * (1.0f - alpha_b);
+                            const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                            const unsigned long long valid_m = pass & ~low;
+                            done_m |= pass & low;
+                            const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+                            const float w = valid ? alpha_b * T : 0.f;
+                            C0 += Bb.z * w;
+                            C1 += Bb.w * w;
+                            C2 += cbb * w;
+                            T = valid ? test_T : T;
+                            last_contributor = valid ? base + (unsigned)jb + 1u : last_contributor;
+                        }
+                    }
+                    const int processed = (c << 6) + ((sb + 1) << (nsub == 2 ? 5 : 6));
+                    if ((processed & ((1 << ulen_log) - 1)) == 0 && processed < n) {
+                        cbase[(size_t)(processed >> ulen_log) * 256] = make_float4(T, C0, C1, C2);
+                        s_next = (processed >> ulen_log) + 1;
+                    }
+                }
+                c++;
+                if (lane == 0) vConsumed[wv] = c;  // (behind this wave's reads of the slot: LDS operations of a wave complete in order)
+                spins = 0;
+                continue;
+            }
+        } else if (sp >= rounds) {
+            break;  // through, and nothing left to stage
+        }
+        // ---- 3. nothing to do right now
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) {  // (~seconds: a protocol error must not hang the device)
+            if (lane == 0) atomicOr(&uctl[1], 1u);
+            break;
+        }
+    }
+    {
+        const unsigned mx = wave_max_u32(inside ? last_contributor : 0u);
+        if (lane == 0) sMaxC[wv] = mx;
+        __syncthreads();
+        const unsigned np = min(max(max(sMaxC[0], sMaxC[1]), max(sMaxC[2], sMaxC[3])), (unsigned)n);
+        if (threadIdx.x == 0) nproc_out[tile] = np;
+        const unsigned ulen = 1u << ulen_log;
+        const unsigned nunits = n > 0 ? max(1u, (np + ulen - 1u) >> ulen_log) : 0u;
         for (int s = s_next; s < (int)nunits; s++) cbase[(size_t)s * 256] = make_float4(T, C0, C1, C2);
         if (n > 0) {
             const unsigned tag = (unsigned)tile | (shortlist ? 0x80000000u : 0u);
@@ -459,13 +742,19 @@ namespace dgm {
 void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const unsigned* point_list, int W, int H,
                        int gridx, const float* rec, const float* bg, float* out_color, float* final_T,
                        unsigned* n_contrib, float4* ckpt, float4* cfin, float4* ckpt64, unsigned* nproc, size_t R, unsigned* uctl,
-                       uint4* ulist_full, uint4* ulist_last, uint8_t* live) {
+                       uint4* ulist_full, uint4* ulist_last, uint8_t* live, const unsigned* tile_order) {
     const int ulog = replay_unit_log2(R);
+    static const bool no_order = [] { const char* e = getenv("DGM_RF_ORDER"); return e && strcmp(e, "0") == 0; }();
     // sparse frames: the asynchronous-quadrant kernel (DGM_RF_SPARSE=sync selects round 5's barrier-per-round form, for A/B runs)
     static const bool sparse_sync = [] { const char* e = getenv("DGM_RF_SPARSE"); return e && strcmp(e, "sync") == 0; }();
-    if (ulog < 6 && !sparse_sync)
-        hipLaunchKernelGGL(render_fwd_async_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
+    static const bool sparse_ring = [] { const char* e = getenv("DGM_RF_SPARSE"); return e && strcmp(e, "ring") == 0; }();
+    if (ulog < 6 && sparse_ring)
+        hipLaunchKernelGGL(render_fwd_ring_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
                            out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
+    else if (ulog < 6 && !sparse_sync)
+        hipLaunchKernelGGL(render_fwd_async_kernel, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
+                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live,
+                           no_order ? (const unsigned*)nullptr : tile_order);
     else if (ulog < 6)
         hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
                            out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);

@@ -103,6 +103,11 @@ def main():
               "| ends p10/p50/p90", [us(np.percentile(w0 + wd - base, p)) for p in (10, 50, 90)])
         print("wave lifetime us p10/p50/p90/max", [us(np.percentile(wd, p)) for p in (10, 50, 90, 100)], "| shader cycles p10/p50/p90/max", pc(dur),
               "| cycles before the first blend p10/p50/p90/max", pc(first[first > 0]) if (first > 0).any() else None)
+        loop16 = ((t[:, 1] >> 36) & 0xffff).astype(np.int64) * 16     # (render_fwd_async_kernel: cycles from entry to the end of the blend loop)
+        busy = np.argsort(dur)[-40:]
+        print("the 40 longest waves: lifetime cycles", pc(dur[busy], (0, 50, 100)), "| loop cycles", pc(loop16[busy], (0, 50, 100)), "| list length", pc(nlist[busy], (0, 50, 100)),
+              "| tested", pc(tested[busy], (0, 50, 100)), "| cycles per tested entry", pc((loop16[busy] - first[busy]) / np.maximum(tested[busy], 1), (0, 50, 100)),
+              "| cycles per LIST entry", pc(loop16[busy] / np.maximum(nlist[busy], 1), (0, 50, 100)))
         print("list length p10/p50/p90/max", pc(nlist), "| entries a wave tested p10/p50/p90/max", pc(tested),
               "| cycles per tested entry (after the first blend) p10/p50/p90", pc(((dur - first)[tested > 8] / tested[tested > 8]), (10, 50, 90)) if (tested > 8).any() else None)
         simd, cu, sh_, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
