@@ -24,6 +24,8 @@
 // Wave-cooperative rectangle expansion: a wave loads 64 Gaussians, then iterates over the lanes that own a
 // non-empty rectangle (scalar bit loop on the ballot mask) and lets all 64 lanes cover that rectangle's
 // tiles, so a Gaussian spanning thousands of tiles costs the same lane-cycles as many small ones.
+#include <stdlib.h>
+
 #include "dgm_common.hpp"
 
 namespace dgm {
@@ -147,6 +149,13 @@ count_tiles_kernel(int P, int chunk, int tiles, int gridx, const unsigned* __res
     for (int t = threadIdx.x; t < tiles; t += DGM_BIN_THREADS) row[t] = lds_hist[t];
 }
 
+// Length class of a tile for the ordered hand-out (class 0 = longest): steps of 8 entries up to 1024, of 32 up to 5120, one class
+// beyond -- the sparse frames' lists (tens to hundreds) and the dense frames' (one to a few thousand) both spread over many classes.
+__device__ __forceinline__ unsigned ord_bucket(const unsigned len) {
+    const unsigned k = len < 1024u ? len >> 3 : 128u + min((len - 1024u) >> 5, 127u);
+    return 255u - k;
+}
+
 // ---- column prefixes, tile totals, tile starts, `ranges` and the sort's worklists in ONE launch ------------------------------
 // (round 3: colscan + a single-workgroup scan + write_ranges, three launches and 22 us for 2 MB of histogram.)
 // A workgroup owns 64 tiles; lane = tile, so every load of a chunk row is a 256-byte segment.  Its four waves take a quarter of
@@ -235,7 +244,7 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
             if (t < tiles) {
                 tile_offset[t] = start;
                 ranges[t] = c[q] ? make_uint2(start, start + c[q]) : make_uint2(0u, 0u);
-                atomicAdd(&ohist[255u - min(c[q] >> 3, 255u)], 1u);
+                atomicAdd(&ohist[ord_bucket(c[q])], 1u);
                 // worklists (order irrelevant): "big" grows from the front of big_list, "mid" (kRadixCap + 1 .. small_cap entries) from its end
                 if (c[q] > (unsigned)small_cap) big_list[atomicAdd(big_count, 1u)] = (unsigned)t;
                 else if (c[q] > (unsigned)kRadixCap) big_list[tiles - 1 - (int)atomicAdd(big_count + 1, 1u)] = (unsigned)t;
@@ -246,14 +255,15 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
         __syncthreads();  // (wave_sum is rewritten by the next pass)
     }
     if (threadIdx.x == 0) tile_offset[tiles] = run_total, *total = run_total;  // (R: the host reads it back to size the binning buffer)
-    // Tiles in descending order of their list length (counting sort on length / 8, 256 buckets; the histogram was taken in the loop
-    // above), left in tile_count -- which nothing reads after this kernel -- for the sparse-frame forward blend: its workgroups are all
-    // resident at once, so the hardware cannot balance them, and a trained frame's long lists sit next to each other in raster order;
-    // handed out in this order, workgroups k, k + #CUs, k + 2 #CUs ... -- what one CU receives -- mix long and short lists
-    // (render_fwd_async_kernel: 0.085 -> 0.070 ms on the trained-like scene).  Only for frames that take that kernel (R < 2^20) and
-    // images of at most ORD_MAX tiles; otherwise the identity.
+    // Tiles in descending order of their list length (counting sort over 256 length classes, ord_bucket; the histogram was taken in
+    // the loop above), left in tile_count -- which nothing reads after this kernel -- for the forward blend, which hands workgroup k
+    // the k-th tile of this order.  A trained frame's long lists sit next to each other in raster order and its workgroups are all
+    // resident at once, so the hardware cannot balance them: in this order workgroups k, k + #CUs, k + 2 #CUs ... -- what one CU
+    // receives -- mix long and short lists (render_fwd_async_kernel 0.082 -> 0.069 ms on the trained-like scene).  A dense frame's
+    // workgroups are handed out as others retire; longest first shortens the tail (render_fwd_kernel 0.217 -> 0.204 ms on the
+    // initial scene).  Costs ~2 us here.  Images of more than ORD_MAX tiles get the identity.
     {
-        const bool ordered = run_total < (unsigned)DGM_FINE_UNITS_BELOW && tiles <= ORD_MAX;  // (workgroup-uniform)
+        const bool ordered = tiles <= ORD_MAX;  // (workgroup-uniform)
         __syncthreads();
         if (ordered) {
             if (threadIdx.x < 64) {  // exclusive scan of the 256 bins: four per lane
@@ -275,7 +285,7 @@ tile_scan_kernel(int tiles, int nchunks, int small_cap, unsigned* __restrict__ h
             }
 #pragma unroll
             for (int q = 0; q < K; q++)
-                if (t0 + q < tiles) oslot[atomicAdd(&ohist[255u - min(c[q] >> 3, 255u)], 1u)] = (unsigned short)(t0 + q);
+                if (t0 + q < tiles) oslot[atomicAdd(&ohist[ord_bucket(c[q])], 1u)] = (unsigned short)(t0 + q);
             __syncthreads();
             for (int i = threadIdx.x; i < tiles; i += 256) tile_count[i] = oslot[i];
         } else {

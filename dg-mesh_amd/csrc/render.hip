@@ -38,14 +38,14 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
                   float* __restrict__ final_T, unsigned* __restrict__ n_contrib, float4* __restrict__ ckpt,
                   float4* __restrict__ cfin, float4* __restrict__ ckpt64, unsigned* __restrict__ nproc_out, const int ulog,
                   unsigned* __restrict__ uctl, uint4* __restrict__ ulist_full, uint4* __restrict__ ulist_last,
-                  uint8_t* __restrict__ live) {
+                  uint8_t* __restrict__ live, const unsigned* __restrict__ tile_order) {
     // staged splats, 48 bytes each: x, y, conic a * -log2(e)/2, conic b * -log2(e) | conic c * -log2(e)/2, opacity, r, g | b
     // (one record per splat: the blend loop forms ONE address per entry for its three broadcast reads)
     __shared__ float4 sR[256 * 3];
     __shared__ unsigned long long sMask[4][4];  // [staging wave][quadrant]
     __shared__ unsigned sMaxC[4];               // per-wave maximum of last_contributor
     __shared__ unsigned sUnitBase;              // first slot of this tile's run of full units in the backward's work list
-    const int tile = blockIdx.x;
+    const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int tile_x = tile % gridx, tile_y = tile / gridx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tile_x * DGM_TILE + (wv & 1) * 8 + (lane & 7);
@@ -276,9 +276,14 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict__
 // blends), tested against its own 8 x 8 block only, no barrier inside the loop.  A tile then costs the maximum over its quadrants of
 // their own total work.  The price is four reads of the tile's list and records instead of one (L2 hits; a sparse frame leaves the
 // memory system idle).  Same per-pixel arithmetic, same order of the blends, same outputs as the kernel above -- bit-identical.
-// Measured on the trained-like scene (tools/raster_bench.py cfg2 --kind trained, one MI355X): 0.095 ms -> 0.079 ms.  (Tried on top and
+// Measured on the trained-like scene (tools/raster_bench.py cfg2 --kind trained, one MI355X): 0.095 ms -> 0.082 ms, and 0.069 ms with
+// the tiles handed out longest first (tile_order, written by tile_scan_kernel).  The trace of THIS kernel (-DRF_TRACE,
+// profiles/r06_render_fwd_async_trace.txt) shows what is left: all 2 500 workgroups are resident from the first microsecond, a wave's
+// end time follows the work of the SIMD it sits on (correlation 0.81 with the sum of entries tested by the waves sharing its SIMD),
+// i.e. the kernel is bound by instruction issue per SIMD times the imbalance between SIMDs, not by memory.  (Tried on top and
 // dropped: the NEXT pair's geometry -- LDS reads, exponent, exp, alpha, threshold ballots -- formed while the current pair blends, a
-// hand-made software pipeline of the bit loop: 0.090 ms; the loop's live state doubles and the scheduler serialises it anyway.)
+// hand-made software pipeline of the bit loop: 0.090 ms, the loop's live state doubles and the scheduler serialises it anyway;
+// records and list slices fetched one round further ahead: no change; render_fwd_ring_kernel below: 0.090 ms.)
 // Checkpoints: a wave writes its pixels' state at the unit boundaries it passes; a quadrant whose pixels have all terminated leaves the
 // loop, and after the tile's one barrier (which yields the replay bound) fills in the boundaries up to that bound with its final state
 // -- exactly the set the backward reads.
@@ -757,10 +762,12 @@ void launch_render_fwd(hipStream_t st, int tiles, const uint2* ranges, const uns
                            no_order ? (const unsigned*)nullptr : tile_order);
     else if (ulog < 6)
         hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
+                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live,
+                           (const unsigned*)nullptr);
     else
         hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(tiles), dim3(256), 0, st, ranges, point_list, W, H, gridx, rec, bg,
-                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live);
+                           out_color, final_T, n_contrib, ckpt, cfin, ckpt64, nproc, ulog, uctl, ulist_full, ulist_last, live,
+                           no_order ? (const unsigned*)nullptr : tile_order);
 }
 
 }  // namespace dgm
