@@ -1104,8 +1104,8 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     d.partial_db = nullptr;
     P4_LAUNCH((mlp_dw4_kernel<8, 1, 1024, 512, 128, 64>), CfgDwH::LDS, pl.chunks, st, d)
     ReduceDwBatch rb;
-    rb.emb_dim = p->emb_dim, rb.n_jobs = 8;
-    int rb_blocks = 0;
+    rb.emb_dim = p->emb_dim, rb.n_jobs = 0;
+    int rb_blocks = 0, n_pending = 0;
     auto add_job = [&](int slot, int chunks, int db_rows, int Kp, int in_features, int dst_off, const float* partial,
                        const float* partial_db, float* dWp, float* dbp) {
         ReduceDwJob& jb = rb.job[slot];
@@ -1194,11 +1194,10 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
             dgm::prof_end(DGM_STAGE_MLP_LAYER_DW, st);
         }
         if (paired && l == sk) {  // two reduction jobs: embedding rows (with the bias gradient), trunk rows
-            add_job(l, pl.chunks, 8 * pl.chunks, EW, layer_in(p, l), 0, part_emb, w.partial_db_l[l], dW[l], db[l]);
-            add_job(8, chunks_l, 0, MLP_W, layer_in(p, l), p->emb_dim, part_trunk, nullptr, dW[l], nullptr);
-            rb.n_jobs = 9;
+            add_job(n_pending++, pl.chunks, 8 * pl.chunks, EW, layer_in(p, l), 0, part_emb, w.partial_db_l[l], dW[l], db[l]);
+            add_job(n_pending++, chunks_l, 0, MLP_W, layer_in(p, l), p->emb_dim, part_trunk, nullptr, dW[l], nullptr);
         } else
-            add_job(l, chunks_l, 8 * chunks_l, Kp, layer_in(p, l), 0, w.partial_l[l], w.partial_db_l[l], dW[l], db[l]);
+            add_job(n_pending++, chunks_l, 8 * chunks_l, Kp, layer_in(p, l), 0, w.partial_l[l], w.partial_db_l[l], dW[l], db[l]);
         if (l >= 1) {
             unsigned char* t = G;
             G = Gn, Gn = t;
@@ -1210,8 +1209,12 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     // prologue: the launch grows by 9 us (87 -> 96), six launches, while this reduction only shrinks 87 -> 52 us: a net loss)
     // (tried, round 5: each layer's tiles summed by a launch of its own right behind the layer's paired launch, while they are still
     // in the 256 MB MALL -- nine launches of 23 us against this one of 89: a single layer's 256 workgroups do not fill the chip)
+    // (tried, round 6: TWO launches, layers 7 .. 4 reduced right behind layer 4's paired launch -- 130-160 MB of partial tiles each, a
+    // thousand workgroups each, so that the reads could hit the MALL: 304.3 / 304.1 it/s against 309.1 / 308.3 with the single launch,
+    // interleaved on one box, scripts/gpu_r6_rsplit.sh; the split at layer 3 or 5: 305.0 / 303.6)
     // (tried: each layer's reduction on a side stream under the next layer's launch -- its small workgroups do fit beside a
     // resident pair workgroup -- 265 vs 274 it/s: slower, the pair kernel's HBM-bound half gets the competition)
+    rb.n_jobs = n_pending;
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
     rb.h_dW = dWh, rb.h_db = dbh;
     hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, rb.n_jobs + 1), dim3(256), 0, st, rb);
