@@ -149,7 +149,8 @@ typedef struct {
     size_t clamped;       /* u8[P]      bit ch set = colour channel ch clamped at 0 */
     size_t block_sums;    /* u32[ceil(P/256)] tiles touched per 256 Gaussians (preprocess -> the count kernel's offs) */
     size_t hist;          /* u32[n_chunks][tiles] */
-    size_t tile_count;    /* u32[tiles] */
+    size_t tile_count;    /* u32[tiles]: per-tile list lengths during binning; after the forward call, the tiles in descending order of
+                             their list length class (the order in which the forward blend takes them) */
     size_t tile_offset;   /* u32[tiles+1] */
     size_t big_list;      /* u32[tiles] worklists: tiles with more than 4096 instances from the front, tiles with 2049 ..
                              4096 from the end */

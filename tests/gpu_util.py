@@ -53,6 +53,7 @@ def hip_forward(a, debug=False):
         tiles_touched=view(geom, lay.tiles_touched, np.uint32, P), offs=view(geom, lay.offs, np.uint32, P),
         cov3D=view(geom, lay.cov3D, np.float32, P * 6).reshape(P, 6), clamped=view(geom, lay.clamped, np.uint8, P),
         counters=view(geom, lay.counters, np.uint32, 8), uctl=view(geom, lay.counters + 32, np.uint32, 64),
+        tile_order=view(geom, lay.tile_count, np.uint32, tiles),
         nproc=view(img, lay.nproc, np.uint32, tiles), ulist_last=view(img, lay.ulist_last, np.uint32, tiles * 4).reshape(tiles, 4),
         final_T=view(img, lay.final_T, np.float32, W * H).reshape(H, W),
         n_contrib=view(img, lay.n_contrib, np.uint32, W * H).reshape(H, W),

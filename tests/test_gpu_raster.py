@@ -157,6 +157,53 @@ def test_replay_unit_lists_and_repeated_backward(orc, syn, kind, P, W, H, seed):
         assert np.array_equal(g1[k], g2[k]), k
 
 
+@pytest.mark.parametrize("kind,P,W,H,seed", [("init", 3000, 200, 136, 1), ("trained", 4000, 160, 160, 3), ("init", 20000, 400, 400, 0),
+                                             ("init", 60000, 800, 800, 2)])
+def test_tiles_are_handed_out_longest_first(syn, kind, P, W, H, seed):
+    """tile_scan_kernel leaves, where the per-tile counts were, the order in which the forward blend takes the tiles: a permutation
+    of the tiles in descending order of their list length class (steps of 8 entries up to 1024, of 32 up to 5120, one class beyond)."""
+    a = raster_args(syn, P, W, H, seed=seed, kind=kind)
+    f = G.hip_forward(a)
+    order = f["tile_order"].astype(np.int64)
+    tiles = f["ranges"].shape[0]
+    assert np.array_equal(np.sort(order), np.arange(tiles))
+    ln = (f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0])[order]
+    cls = np.where(ln < 1024, ln >> 3, 128 + np.minimum((ln - 1024) >> 5, 127))
+    assert (np.diff(cls) <= 0).all()
+    assert len(np.unique(cls)) > 8  # (the order is not vacuous: the lists spread over many classes)
+
+
+def test_hand_out_order_does_not_change_a_bit(syn, tmp_path):
+    """The same frames rendered and differentiated with the tiles taken in raster order (DGM_RF_ORDER=0, read once per process: two
+    child processes) -- images, n_contrib, final_T and all eight gradient tensors are bit-identical."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')\n"
+        "import conftest, gpu_util as G\n"
+        "syn = conftest.pkg('synthetic')\n"
+        "for kind, P, W, H, seed in (('trained', 4000, 160, 160, 3), ('init', 20000, 400, 400, 0), ('init', 60000, 800, 800, 2)):\n"
+        "    a = conftest.raster_args(syn, P, W, H, seed=seed, kind=kind)\n"
+        "    f = G.hip_forward(a)\n"
+        "    g = G.hip_backward(a, f, np.random.RandomState(seed).randn(3, H, W).astype(np.float32))\n"
+        "    h = hashlib.sha256()\n"
+        "    for v in (f['color'], f['n_contrib'], f['final_T'], f['point_list'], f['nproc']): h.update(np.ascontiguousarray(v).tobytes())\n"
+        "    for k in sorted(g): h.update(np.ascontiguousarray(g[k]).tobytes())\n"
+        "    print('HASH', kind, P, h.hexdigest(), int(f['tile_order'][0]))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for order in ("1", "0"):
+        env = dict(os.environ, DGM_RF_ORDER=order)
+        out = subprocess.run([sys.executable, "-c", code, root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                             timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:]
+        got[order] = [ln.split()[1:4] for ln in out.stdout.splitlines() if ln.startswith("HASH")]
+        assert len(got[order]) == 3, out.stdout[-2000:]
+    assert got["1"] == got["0"]
+
+
 def test_cfg2_full_size(orc, syn):
     """BASELINE cfg2 (800x800, 100k Gaussians): full-size parity against the oracle."""
     c = syn.CONFIGS["cfg2"]
