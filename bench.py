@@ -653,6 +653,28 @@ def main():
                          "ms_per_step": r["ms_per_step"], "frac_hbm": r["frac_hbm"], "frac_mfma_pipe": r.get("frac_mfma_pipe"),
                          "arithmetic": ("f16x3p: activations / gradients stored as 2 binary16 planes with one exponent per 32-row tile, "
                                         "split once by the producer, 3 MFMAs per product" if planes else "native fp32 MFMA")})
+        if best is not None and roof.get("bound") == "hbm" and not args.no_extras:
+            # context for `frac`: what a plain device-to-device copy moving the same number of bytes (half read, half written) reaches on
+            # THIS device in THIS run -- the practical rate of a read + write stream (torch's copy kernel, HIP events on its stream)
+            half = int(roof["algorithmic_bytes"] // 8) * 4
+            src_t, dst_t = torch.empty(half // 4, device=dev), torch.empty(half // 4, device=dev)
+            src_t.normal_()
+            for _ in range(3):
+                dst_t.copy_(src_t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dst_t.copy_(src_t)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_ms = e0.elapsed_time(e1) / 20
+            copy_gbs = 2.0 * half / (copy_ms * 1e-3) / 1e9
+            roof["device_copy_of_the_same_bytes"] = {"avg_ms": round(copy_ms, 5), "GBps": round(copy_gbs, 1),
+                                                     "kernel_rate_over_copy_rate": round(roof["achieved"] / copy_gbs, 4),
+                                                     "note": "informational: torch's device-to-device copy, half of the kernel's "
+                                                             "algorithmic bytes read and half written, same run; `frac` stays "
+                                                             "against the 8 TB/s of the data sheet"}
+            del src_t, dst_t
         rb_traffic, rb_src, _ = pmc_traffic("r06_pmc_render_bwd4.json", "render_bwd4_kernel")
         out = {
             "metric": ("train-step iters/sec (800x800, ~100k Gaussians)" if WORKLOAD == "cfg2"
