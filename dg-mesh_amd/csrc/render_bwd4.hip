@@ -173,6 +173,9 @@ render_bwd4_kernel(const uint2* __restrict__ ranges, const unsigned* __restrict_
         const bool is_last = t >= per_f;
         // (measured: consecutive units on consecutive XCDs -- u = 8 t + x -- instead of an eighth of the list per XCD: 0.0658 against
         // 0.0632 ms on the trained-like scene, 0.2764 against 0.2739 on the initial one; a Gaussian's rows then fill up in eight L2s)
+        // (measured, round 6: an XCD's share of either list taken back to front -- the forward now finishes its longest tiles last, so
+        // their units sit at the end -- 0.0644-0.0654 against 0.0648-0.0650 ms trained-like, 0.269-0.272 against 0.271-0.275 on the
+        // initial scene: the order of the list does not matter to this kernel)
         const unsigned u = is_last ? x * per_l + (t - per_f) : x * per_f + t;
         if (u >= (is_last ? nl : nf)) return;
         d = is_last ? ulist_last[u] : ulist_full[u];
