@@ -28,9 +28,9 @@ region at N = 1.  `roofline_render_bwd_trained` = the rasterizer backward on SUR
 distribution on which north_star's HBM target is approachable), measured here with the library's stage timers; `frac_valu` of
 the blend kernels comes from the committed PMC pass (VALU lane operations / 78.6 T lane-op/s).
 `cpu_baseline` = the same step on the host cores: the reference's OWN network and loss modules (utils/time_utils.py,
-utils/loss_utils.py, byte-compiled by oracle/build_ref.sh; `kind: "reference modules + oracle rasterizer"`) around the
-oracle rasterizer (the reference has no CPU rasterizer); this repo's torch restatement of the modules (`kind: "port"`)
-only when the byte-compiled files are absent or do not load.  Rank 0 at N=1 only, on a bounded sample; its scene is the
+utils/loss_utils.py, byte-compiled by oracle/build_ref.sh; `kind_detail: "reference modules + oracle rasterizer"`) around the
+oracle rasterizer (the reference has no CPU rasterizer, so `kind` is "port": the part that dominates the CPU step is the oracle's
+restatement); this repo's torch restatement of the modules only when the byte-compiled files are absent or do not load.  Rank 0 at N=1 only, on a bounded sample; its scene is the
 freshly initialised one (frame 0), the GPU headline's has taken ~35 Adam steps -- the two R values differ and `sample` says so.
 """
 import argparse
@@ -231,10 +231,10 @@ def cpu_baseline(P, W, H, max_threads=32, headline_R=None, frame=0, scene=None):
         f = one_step()
         n_steps += 1
     dt = (time.time() - t0) / n_steps
-    kind = "reference modules + oracle rasterizer" if ref is not None else "port"
+    detail = "reference modules + oracle rasterizer" if ref is not None else "torch restatement of the modules + oracle rasterizer"
     what = ("the reference's DeformNetworkNormal x 2 fwd+bwd and its l1_loss / ssim (utils/time_utils.py, utils/loss_utils.py, "
             "byte-compiled)" if ref is not None else "2 deformation MLPs fwd+bwd + L1/SSIM (this repo's torch restatement)")
-    return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": kind,
+    return {"value": 1.0 / dt, "unit": "it/s", "cores": cores, "kind": "port", "kind_detail": detail,
             "sample": f"{n_steps} full {WORKLOAD} train steps ({W}x{H}, P={P}, R={f['num_rendered']}): oracle rasterizer "
                       f"fwd+bwd (C/OpenMP; the reference has no CPU rasterizer) + {what} + torch.optim.Adam on PyTorch-CPU, "
                       f"{dt:.1f} s each.  " + ("The GPU headline's own Gaussians (copied to the host after its timed region) and its "
