@@ -435,9 +435,9 @@ def main():
     if world > 1:
         tr.exchange_events = []
     dev_allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
-    redos0 = RZ.OVERFLOW_REDOS
+    redos0 = RZ.OVERFLOW_REDOS + RZ.UNIT_REDOS
     elapsed, stages, blocked_s, pkg = timed(args.steps, it0 + args.warmup)
-    settle_s, redos = timed.settle_wait, RZ.OVERFLOW_REDOS - redos0
+    settle_s, redos = timed.settle_wait, RZ.OVERFLOW_REDOS + RZ.UNIT_REDOS - redos0
     # hipMalloc calls of torch's caching allocator inside the timed region: 0 at steady state; a scene whose R keeps setting new
     # maxima (cfg4 under the random targets) pays one multi-GB allocation per new size of the binning buffer
     dev_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - dev_allocs0

@@ -117,6 +117,7 @@ SYNC_FREE = _os.environ.get("DGM_SYNC_FREE") == "1"
 DEFER_SETTLE = False
 SETTLE_WAIT_SECONDS = 0.0       # host time spent waiting in settle() / the inline wait (bench.py reports it)
 OVERFLOW_REDOS = 0              # frames rendered again because R exceeded the capacity
+UNIT_REDOS = 0                  # frames rendered again because capacity and R sat on different sides of the replay-unit boundary
 INJECT_CAPACITY = 0             # test hook: the next capacity-mode forward uses this capacity (then the hook clears itself)
 _SF = {}                        # device index -> {"cap": capacity in instances, "words": pinned int32[4], "event": torch.cuda.Event}
 _PENDING = None                 # (device index, capacity) of a forward whose words have not been looked at yet
@@ -132,11 +133,20 @@ def _sf_state(dev):
     return st
 
 
+_UNIT_BOUNDARY = 1 << 20  # DGM_FINE_UNITS_BELOW (csrc/dgm_common.hpp): frames below it are replayed in units of 32 entries, else 64
+
+
 def _capacity_for(R):
-    """Capacity (tile instances) for a frame of R: 1.25 x, rounded up to m * 2^k, m in 8..15 -- the sizes _bucket() gives bytes."""
+    """Capacity (tile instances) for a frame of R: 1.25 x, rounded up to m * 2^k, m in 8..15 -- the sizes _bucket() gives bytes --
+    but never across the replay-unit boundary: the unit length follows the number the layout is sized for, and it decides how the
+    backward partitions its sums, so a frame is only ever accepted with its capacity on R's own side of the boundary (settle()):
+    every bit of the gradients is then what the synchronous protocol gives."""
     n = max(int(R) + int(R) // 4, 4096)
     k = max(n.bit_length() - 4, 0)
-    return ((n + (1 << k) - 1) >> k) << k
+    cap = ((n + (1 << k) - 1) >> k) << k
+    if int(R) < _UNIT_BOUNDARY <= cap:
+        cap = _UNIT_BOUNDARY - 1
+    return cap
 
 
 def _fixed_resizer(t, nbytes_cap):
@@ -157,7 +167,7 @@ def settle():
     """Look at the words of the most recent capacity-mode forward (waits for its event).  True: the frame is good (LAST_NUM_RENDERED
     is its R).  False: R exceeded the capacity -- the frame was neutralised on the device, the capacity has been raised, render it
     again.  No pending forward: True."""
-    global _PENDING, LAST_NUM_RENDERED, SETTLE_WAIT_SECONDS, OVERFLOW_REDOS
+    global _PENDING, LAST_NUM_RENDERED, SETTLE_WAIT_SECONDS, OVERFLOW_REDOS, UNIT_REDOS
     if _PENDING is None:
         return True
     idx, cap = _PENDING
@@ -173,6 +183,12 @@ def settle():
         return False
     if flags & 1:
         raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    if (R < _UNIT_BOUNDARY) != (cap < _UNIT_BOUNDARY):
+        # the capacity (left by a larger scene on this device) sits on the other side of the replay-unit boundary: the frame is
+        # correct, but its gradients would be summed in another partition than the synchronous protocol's -- render it again
+        st["cap"] = _capacity_for(R)
+        UNIT_REDOS += 1
+        return False
     if 4 * R < cap and not INJECT_CAPACITY:  # the scene shrank a lot (another scene on this device): follow it down
         st["cap"] = _capacity_for(R)
     LAST_NUM_RENDERED = R

@@ -620,6 +620,36 @@ def test_capacity_forward_equals_the_synchronous_one(orc, syn, sync_free, kind, 
     check_backward(orc, a, f_or, f2, seed=seed)
 
 
+def test_capacity_never_straddles_the_replay_unit_boundary(syn, sync_free):
+    """The replay-unit length (32 entries below 2^20 instances, else 64) follows the size the layout is made for.  A capacity left
+    by a larger scene (>= 2^20) is not accepted for a frame below the boundary: the frame is rendered again with a capacity on its
+    own side, so the gradients are bit-identical to the synchronous protocol's whatever was rendered before."""
+    R = sync_free
+    assert R._capacity_for(900_000) == (1 << 20) - 1 and R._capacity_for((1 << 20) + 5) >= (1 << 20) + 5
+    assert R._capacity_for(100_000) >= 125_000 and R._capacity_for(100_000) < (1 << 20)
+    big = raster_args(syn, 60000, 800, 800, seed=2, kind="init")
+    small = raster_args(syn, 20000, 400, 400, seed=0, kind="init")
+    R.SYNC_FREE = False
+    f0 = G.hip_forward(small)
+    assert f0["num_rendered"] < (1 << 20)
+    dL = np.random.RandomState(5).randn(3, 400, 400).astype(np.float32)
+    g0 = G.hip_backward(small, f0, dL)
+    R.SYNC_FREE = True
+    fb = G.hip_forward(big)
+    assert fb["num_rendered"] >= (1 << 20) and all(st["cap"] >= (1 << 20) for st in R._SF.values())
+    redos = R.UNIT_REDOS
+    f1 = G.hip_forward(small)   # capacity mode with the big scene's capacity: settled as "render again"
+    assert R.UNIT_REDOS == redos + 1 and all(st["cap"] < (1 << 20) for st in R._SF.values())
+    assert f1["unit_log2"] == f0["unit_log2"] == 5 and f1["num_rendered"] == f0["num_rendered"]
+    g1 = G.hip_backward(small, f1, dL)
+    for k in ("color", "radii", "point_list", "ranges", "n_contrib", "final_T"):
+        assert np.array_equal(f1[k], f0[k]), k
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+    f2 = G.hip_forward(small)   # steady state: no further redo
+    assert R.UNIT_REDOS == redos + 1 and f2["num_rendered"] == f0["num_rendered"]
+
+
 def test_capacity_overflow_is_caught_and_the_frame_rendered_again(orc, syn, sync_free):
     """A frame that does not fit its capacity (injected: a third of R) is neutralised on the device -- nothing is written beyond the
     buffer -- flagged, and rendered again by the wrapper with the raised capacity: the caller sees the correct frame."""
