@@ -728,7 +728,7 @@ struct Ws {
     uint4 *Wh4f, *Wh4b;
     float *wsc_hf, *wsc_hb;
     float *bias_s[8];           // round 6: biases times their layer's column scales (mlp_prep4c_kernel)
-    float *beff[2], *temb_row;  // round 6: biases of layer 0 / the skip layer with the call's time row folded in; that row (for the backward pass)
+    float *beff[2], *temb_row;  // round 6: the call's time row, kept for the backward pass (beff: the folded biases of the first version, unused -- they are formed where the biases are pre-scaled)
     size_t bytes;
 };
 int num_cus() {
@@ -960,27 +960,21 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     am.job[8].W = p->Wh, am.job[8].n = p->n_out * MLP_W;
     hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, temb_stride, p->t_dim,
                        (unsigned char*)w.emb, w.Eexp, am, w.matmax, EW);
-    if (fold) {
-        FoldBiasArgs f;
-        f.W[0] = p->W[0], f.b[0] = p->b[0], f.beff[0] = w.beff[0], f.in_features[0] = layer_in(p, 0);
-        f.W[1] = p->W[sk], f.b[1] = p->b[sk], f.beff[1] = w.beff[1], f.in_features[1] = layer_in(p, sk);
-        f.temb = temb, f.T = p->t_dim, f.temb_row = w.temb_row;
-        hipLaunchKernelGGL(mlp_fold_bias_kernel, dim3(2, 8), dim3(256), 0, st, f);
-    }
     if (fold) {  // every weight matrix as two binary16 planes, one power-of-two scale per OUTPUT COLUMN, biases pre-scaled
         Prep4cBatch pc;
         int nc = 0;
+        pc.temb = temb, pc.temb_row = w.temb_row, pc.T = p->t_dim;
         auto addc = [&](int mode, int Kp, int ncols, int in_features, int hoff, int k_valid, int col_valid, const float* Wp, uint4* Bp,
-                        float* inv_scale, const float* bias_in, float* bias_out) {
+                        float* inv_scale, const float* bias_in, float* bias_out, int fold_time = 0) {
             Prep4cJob& q = pc.job[nc++];
+            q.fold = fold_time;
             q.j.mode = mode, q.j.Kp = Kp, q.j.ncols = ncols, q.j.in_features = in_features, q.j.emb_dim = p->emb_dim, q.j.hoff = hoff;
             q.j.k_valid = k_valid, q.j.col_valid = col_valid, q.j.W = Wp, q.j.Bp = Bp, q.j.inv_scale = inv_scale;
             q.bias_in = bias_in, q.bias_out = bias_out;
         };
         for (int l = 0; l < 8; l++) {
             const int Kp = l == 0 ? 64 : (l == sk ? 320 : MLP_W);
-            const float* bin = l == 0 ? w.beff[0] : (l == sk ? w.beff[1] : p->b[l]);
-            addc(0, Kp, MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_f[l], bin, w.bias_s[l]);
+            addc(0, Kp, MLP_W, layer_in(p, l), 0, MLP_W, MLP_W, p->W[l], w.Wt3[l], w.wsc_f[l], p->b[l], w.bias_s[l], (l == 0 || l == sk) ? 1 : 0);
             if (l >= 1) addc(1, MLP_W, MLP_W, layer_in(p, l), l == sk ? p->emb_dim : 0, MLP_W, MLP_W, p->W[l], w.Wd3[l], w.wsc_d[l], nullptr, nullptr);
         }
         addc(0, MLP_W, 32, MLP_W, 0, MLP_W, p->n_out, p->Wh, w.Wh4f, w.wsc_hf, nullptr, nullptr);   // heads forward: B[k][o] = Wh[o][k]
@@ -1218,14 +1212,13 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     rb.h_chunks = pl.chunks, rb.h_bchunks = nt, rb.h_nout = p->n_out, rb.h_partial_W = w.partial_h, rb.h_partial_b = w.partial_hb;
     rb.h_dW = dWh, rb.h_db = dbh;
     hipLaunchKernelGGL(mlp_reduce_dw_all_kernel, dim3(rb_blocks, rb.n_jobs + 1), dim3(256), 0, st, rb);
-    if (fold) {  // the time columns of dW_0 / dW_skip: db (x) t_emb
+    if (fold) {  // the time columns of dW_0 / dW_skip: db (x) t_emb; and dL/dt_emb (one launch)
         FoldGradArgs f;
-        f.dW[0] = dW[0], f.db[0] = db[0], f.in_features[0] = layer_in(p, 0);
-        f.dW[1] = dW[sk], f.db[1] = db[sk], f.in_features[1] = layer_in(p, sk);
-        f.temb = w.temb_row, f.T = p->t_dim;
-        hipLaunchKernelGGL(mlp_fold_grad_kernel, dim3(2, p->t_dim), dim3(256), 0, st, f);
-    }
-    if (dtemb != nullptr && !per_row_t)
+        f.dW[0] = dW[0], f.db[0] = db[0], f.W[0] = p->W[0], f.in_features[0] = layer_in(p, 0);
+        f.dW[1] = dW[sk], f.db[1] = db[sk], f.W[1] = p->W[sk], f.in_features[1] = layer_in(p, sk);
+        f.temb = w.temb_row, f.T = p->t_dim, f.dtemb = (dtemb != nullptr && !per_row_t) ? dtemb : nullptr;
+        hipLaunchKernelGGL(mlp_fold_grad_kernel, dim3(f.dtemb != nullptr ? 3 : 2, p->t_dim), dim3(256), 0, st, f);
+    } else if (dtemb != nullptr && !per_row_t)
         hipLaunchKernelGGL(mlp_dtemb_bcast_kernel, dim3(p->t_dim), dim3(256), 0, st, p->t_dim, db[0], p->W[0], layer_in(p, 0),
                            db[sk], p->W[sk], layer_in(p, sk), dtemb);
     hipError_t e = hipGetLastError();

@@ -238,7 +238,7 @@ mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* _
         }
     }
     // x, the time embedding, the zero padding: 3 + (EW - 63) columns per row (EW = 64: no time columns -- one time value per call
-    // is folded into the biases, mlp_fold_bias_kernel -- just the zero column 63)
+    // is folded into the biases, mlp_prep4c_kernel -- just the zero column 63)
     const int rest = 3 + EW - 63;
     for (int i = tid; i < 32 * rest; i += 256) {
         const int rl = i / rest, j = i - rest * rl, r = r0 + rl;
@@ -334,9 +334,14 @@ struct Prep4cJob {
     Prep3Job j;             // j.inv_scale: [ncols] floats
     const float* bias_in;   // may be NULL
     float* bias_out;        // [ncols]
+    int fold;               // 1: the call's time row is folded into this layer's bias (layer 0 and the skip layer, one time value per call):
+                            //    bias[c] = bias_in[c] + sum_t W[c][63 + t] t_emb[t]   (R/utils/time_utils.py:104-129: h = cat([x_emb, t_emb]))
 };
 struct Prep4cBatch {
     Prep4cJob job[P4_MAX_JOBS];
+    const float* temb;      // the call's time row (fold jobs), T values
+    float* temb_row;        // ... copied here for the backward pass (dW's time columns are db (x) t_emb)
+    int T;
 };
 __global__ void __launch_bounds__(256)
 mlp_prep4c_kernel(const Prep4cBatch b) {
@@ -365,8 +370,18 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
     scale_from_max_bits(__float_as_uint(cm), sc, inv);
     if (slot == 0) {
         j.inv_scale[col] = inv;
-        if (pj.bias_out != nullptr) pj.bias_out[col] = (pj.bias_in != nullptr && col < j.col_valid) ? pj.bias_in[col] * sc : 0.f;
+        if (pj.bias_out != nullptr) {
+            float bv = (pj.bias_in != nullptr && col < j.col_valid) ? pj.bias_in[col] : 0.f;
+            if (pj.fold && col < j.col_valid) {  // (round 6, first version: a launch of its own in front of this one, mlp_fold_bias_kernel)
+                const float* wt = j.W + (size_t)col * j.in_features + 63;
+                float sacc = 0.f;
+                for (int t = 0; t < b.T; t++) sacc = fmaf(wt[t], b.temb[t], sacc);
+                bv += sacc;
+            }
+            pj.bias_out[col] = bv * sc;
+        }
     }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && b.temb_row != nullptr && tid < b.T) b.temb_row[tid] = b.temb[tid];
 #pragma unroll
     for (int it = 0; it < 6; it++) {
         const int kg = slot + 8 * it;

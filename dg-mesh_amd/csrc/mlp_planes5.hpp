@@ -8,7 +8,7 @@
 // at K = 256, 320 at K = 320), which is also what lets the skip layer run as ONE K = 320 GEMM:
 //   KS2 = 4: four more K steps over the 64-column embedding planes [x, PE(x), 0] (a second DMA stream into its own LDS rows) run
 //            FIRST; the accumulators are then rescaled by 2^(e_trunk - e_emb) (exact) and the 16 trunk steps follow.  The time
-//            embedding is one row per call (R/train.py:158) and sits in the bias (mlp_fold_bias_kernel) -- the 102 MB fp32 `Cin`
+//            embedding is one row per call (R/train.py:158) and sits in the bias (mlp_prep4c_kernel's fold jobs) -- the 102 MB fp32 `Cin`
 //            round trip of rounds 2-5 is gone.
 // Two independent accumulator chains alternate MFMA by MFMA, so the matrix pipe needs no second wave to stay busy; everything
 // else (E1 / E2 epilogue slices between the MFMAs, one vmcnt(0) per tile step at the mid barrier, three A buffers filled by
@@ -422,44 +422,36 @@ mlp_gemm5_kernel(const Gemm5Args a) {
 // ---- the time embedding as a bias -----------------------------------------------------------------------------------------------
 // With ONE time value per call (R/train.py:158: fid expanded over the Gaussians) the time columns of the two layers that consume
 // the embedding contribute the same vector to every row: beff[j] = b[j] + sum_t W[j][63 + t] t_emb[t]   (R/utils/time_utils.py:
-// 104-129: h = cat([x_emb, t_emb]) -> linear[0]; the skip re-injection feeds linear[5] the same way).  blockIdx.x = 0: layer 0,
-// 1: the skip layer.
-struct FoldBiasArgs {
-    const float* W[2];
-    const float* b[2];
-    float* beff[2];
-    int in_features[2];
-    const float* temb;
-    int T;
-    float* temb_row;  // the time row, kept for the backward pass (dW's time columns are db (x) t_emb)
-};
-// grid (2, 8): blockIdx.x = 0: layer 0, 1: the skip layer; a workgroup folds 32 output units, eight lanes per unit
-__global__ void __launch_bounds__(256)
-mlp_fold_bias_kernel(const FoldBiasArgs f) {
-    const int k = blockIdx.x, j = blockIdx.y * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
-    if (k == 0 && blockIdx.y == 0 && (int)threadIdx.x < f.T) f.temb_row[threadIdx.x] = f.temb[threadIdx.x];
-    const float* w = f.W[k] + (size_t)j * f.in_features[k] + 63;
-    float s = 0.f;
-    for (int t = sub; t < f.T; t += 8) s = fmaf(w[t], f.temb[t], s);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 1, 64);
-    if (sub == 0) f.beff[k][j] = f.b[k][j] + s;
-}
+// 104-129: h = cat([x_emb, t_emb]) -> linear[0]; the skip re-injection feeds linear[5] the same way).  The fold itself happens where
+// the two layers' biases are pre-scaled (mlp_prep4c_kernel, mlp_planes.hpp: `fold` jobs); first version: a launch of its own.
 
-// The adjoint of the fold for the weights: dW[j][63 + t] = db[j] t_emb[t] for the two layers (one launch, after the reduction
-// has produced db; grid (2, T)).  (dL/dt_emb itself is mlp_dtemb_bcast_kernel, mlp.hip.)
+// The adjoint of the fold (one launch, after the reduction has produced db; grid (3 or 2, T)):
+//   blockIdx.x = 0, 1: the weights' time columns of layer 0 / the skip layer, dW[j][63 + t] = db[j] t_emb[t];
+//   blockIdx.x = 2   : dL/dt_emb[t] = sum_j db0[j] W0[j][63 + t] + db5[j] W5[j][63 + t]  (first version: mlp_dtemb_bcast_kernel, a
+//                      launch of its own behind this one -- still the per-row-time path's; same summation order here).
 struct FoldGradArgs {
     float* dW[2];
     const float* db[2];
+    const float* W[2];
     int in_features[2];
     const float* temb;
+    float* dtemb;  // may be NULL (then the grid is (2, T))
     int T;
 };
 __global__ void __launch_bounds__(256)
 mlp_fold_grad_kernel(const FoldGradArgs f) {
+    __shared__ float red[4];
     const int k = blockIdx.x, t = blockIdx.y, j = threadIdx.x;
-    f.dW[k][(size_t)j * f.in_features[k] + 63 + t] = f.db[k][j] * f.temb[t];
+    if (k < 2) {  // (workgroup-uniform)
+        f.dW[k][(size_t)j * f.in_features[k] + 63 + t] = f.db[k][j] * f.temb[t];
+        return;
+    }
+    float v = f.db[0][j] * f.W[0][(size_t)j * f.in_features[0] + 63 + t] + f.db[1][j] * f.W[1][(size_t)j * f.in_features[1] + 63 + t];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((j & 63) == 0) red[j >> 6] = v;
+    __syncthreads();
+    if (j == 0) f.dtemb[t] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 }  // namespace dgm
