@@ -454,7 +454,10 @@ class Trainer:
                     loss = loss + t
                 if self._early is not None:
                     self._early.update(left=self._early["n"], work=None, views=None, armed=True)
-                loss.backward()
+                unit = getattr(self, "_unit_grad", None)  # (backward()'s implicit ones_like(loss) is a fill launch per step)
+                if unit is None or unit.shape != loss.shape or unit.dtype != loss.dtype or unit.device != loss.device:
+                    unit = self._unit_grad = torch.ones_like(loss)
+                loss.backward(unit)
                 if self._early is not None:
                     self._early["armed"] = False
             finally:
