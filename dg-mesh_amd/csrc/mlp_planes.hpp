@@ -345,7 +345,7 @@ struct Prep4cBatch {
 };
 __global__ void __launch_bounds__(256)
 mlp_prep4c_kernel(const Prep4cBatch b) {
-    __shared__ float smax[8][32];
+    __shared__ float smax[8][32], sfold[8][32];
     const Prep4cJob& pj = b.job[blockIdx.y];
     const Prep3Job& j = pj.j;
     if ((int)blockIdx.x * 32 >= j.ncols) return;
@@ -362,6 +362,14 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
         }
     }
     smax[slot][cl] = m;
+    if (pj.fold) {  // (workgroup-uniform) the fold's dot product, eight partial sums per column: t = slot, slot + 8, ...
+        float sacc = 0.f;
+        if (col < j.col_valid) {
+            const float* wt = j.W + (size_t)col * j.in_features + 63;
+            for (int t = slot; t < b.T; t += 8) sacc = fmaf(wt[t], b.temb[t], sacc);
+        }
+        sfold[slot][cl] = sacc;
+    }
     __syncthreads();
     float cm = smax[0][cl];
 #pragma unroll
@@ -372,12 +380,8 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
         j.inv_scale[col] = inv;
         if (pj.bias_out != nullptr) {
             float bv = (pj.bias_in != nullptr && col < j.col_valid) ? pj.bias_in[col] : 0.f;
-            if (pj.fold && col < j.col_valid) {  // (round 6, first version: a launch of its own in front of this one, mlp_fold_bias_kernel)
-                const float* wt = j.W + (size_t)col * j.in_features + 63;
-                float sacc = 0.f;
-                for (int t = 0; t < b.T; t++) sacc = fmaf(wt[t], b.temb[t], sacc);
-                bv += sacc;
-            }
+            if (pj.fold && col < j.col_valid)  // (round 6, first version: a launch of its own in front of this one, mlp_fold_bias_kernel)
+                bv += ((sfold[0][cl] + sfold[1][cl]) + (sfold[2][cl] + sfold[3][cl])) + ((sfold[4][cl] + sfold[5][cl]) + (sfold[6][cl] + sfold[7][cl]));
             pj.bias_out[col] = bv * sc;
         }
     }
