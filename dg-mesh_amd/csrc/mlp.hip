@@ -979,7 +979,7 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
         }
         addc(0, MLP_W, 32, MLP_W, 0, MLP_W, p->n_out, p->Wh, w.Wh4f, w.wsc_hf, nullptr, nullptr);   // heads forward: B[k][o] = Wh[o][k]
         addc(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh4b, w.wsc_hb, nullptr, nullptr);    // heads backward: B[o][c] = Wh[o][c]
-        hipLaunchKernelGGL(mlp_prep4c_kernel, dim3(8, nc), dim3(256), 0, st, pc);
+        hipLaunchKernelGGL(mlp_prep4c_kernel, dim3(MLP_W / P4C_COLS, nc), dim3(256), 0, st, pc);
     }
     // (rounds 3-5's forms: one power-of-two scale per matrix)
     Prep4Batch pb;

@@ -343,18 +343,22 @@ struct Prep4cBatch {
     float* temb_row;        // ... copied here for the backward pass (dW's time columns are db (x) t_emb)
     int T;
 };
+// A workgroup takes P4C_COLS = 16 output columns (lane = column within the block, 16 k-groups of 8 side by side): 16 workgroups per
+// 256-column matrix, 270 in the launch.  (First version: 32 columns per workgroup, 136 workgroups -- the launch lasted as long as one
+// CU needs for its 12 k scattered 32-byte row reads, 11.7 us; W is (out, in), a column of the GEMM operand is a row of W.)
+static constexpr int P4C_COLS = 16, P4C_SLOTS = 256 / P4C_COLS, P4C_ITERS = 48 / P4C_SLOTS;  // (48 k-groups: Kp <= 384)
 __global__ void __launch_bounds__(256)
 mlp_prep4c_kernel(const Prep4cBatch b) {
-    __shared__ float smax[8][32], sfold[8][32];
+    __shared__ float smax[P4C_SLOTS][P4C_COLS], sfold[8][P4C_COLS];
     const Prep4cJob& pj = b.job[blockIdx.y];
     const Prep3Job& j = pj.j;
-    if ((int)blockIdx.x * 32 >= j.ncols) return;
-    const int tid = threadIdx.x, cl = tid & 31, col = blockIdx.x * 32 + cl, slot = tid >> 5, nkg = j.Kp >> 3;
-    float e[6][8];
+    if ((int)blockIdx.x * P4C_COLS >= j.ncols) return;
+    const int tid = threadIdx.x, cl = tid % P4C_COLS, col = blockIdx.x * P4C_COLS + cl, slot = tid / P4C_COLS, nkg = j.Kp >> 3;
+    float e[P4C_ITERS][8];
     float m = 0.f;
 #pragma unroll
-    for (int it = 0; it < 6; it++) {
-        const int kg = slot + 8 * it;
+    for (int it = 0; it < P4C_ITERS; it++) {
+        const int kg = slot + P4C_SLOTS * it;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             e[it][i] = kg < nkg ? prep3_src(j, kg * 8 + i, col) : 0.f;
@@ -362,7 +366,7 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
         }
     }
     smax[slot][cl] = m;
-    if (pj.fold) {  // (workgroup-uniform) the fold's dot product, eight partial sums per column: t = slot, slot + 8, ...
+    if (pj.fold && slot < 8) {  // the fold's dot product, eight partial sums per column: t = slot, slot + 8, ...
         float sacc = 0.f;
         if (col < j.col_valid) {
             const float* wt = j.W + (size_t)col * j.in_features + 63;
@@ -373,7 +377,7 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
     __syncthreads();
     float cm = smax[0][cl];
 #pragma unroll
-    for (int q = 1; q < 8; q++) cm = fmaxf(cm, smax[q][cl]);
+    for (int q = 1; q < P4C_SLOTS; q++) cm = fmaxf(cm, smax[q][cl]);
     float sc, inv;
     scale_from_max_bits(__float_as_uint(cm), sc, inv);
     if (slot == 0) {
@@ -387,8 +391,8 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && b.temb_row != nullptr && tid < b.T) b.temb_row[tid] = b.temb[tid];
 #pragma unroll
-    for (int it = 0; it < 6; it++) {
-        const int kg = slot + 8 * it;
+    for (int it = 0; it < P4C_ITERS; it++) {
+        const int kg = slot + P4C_SLOTS * it;
         if (kg < nkg) {
             uint4 H, L;
             split2h(e[it][0] * sc, e[it][1] * sc, H.x, L.x);
