@@ -955,7 +955,7 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     const int EW = fold ? 64 : MLP_EMB;
     // embedding planes + the maxima of the nine weight tensors (W_0 .. W_7, Wh)
     AbsMaxBatch am;
-    am.n_jobs = 9;
+    am.n_jobs = fold ? 0 : 9;  // (round 6's forms scale per output column: mlp_prep4c_kernel takes its columns' maxima itself)
     for (int l = 0; l < 8; l++) am.job[l].W = p->W[l], am.job[l].n = MLP_W * layer_in(p, l);
     am.job[8].W = p->Wh, am.job[8].n = p->n_out * MLP_W;
     hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, temb_stride, p->t_dim,
