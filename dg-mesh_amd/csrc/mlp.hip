@@ -912,6 +912,7 @@ typedef Gemm4Cfg<1, 128, 64, 1, false, 8, true> CfgG7C;
 typedef Gemm5Cfg<0, 0> Cfg5Fwd;
 typedef Gemm5Cfg<0, 1> Cfg5Bwd;
 typedef Gemm5Cfg<4, 0> Cfg5Skip;
+typedef Gemm5Cfg<0, 2> Cfg5FwdH;
 typedef Dw4Cfg<2, 8, 256, 128, 1024, 512> CfgDwE64;
 typedef Dw4Cfg<8, 8, 1024, 512, 1024, 512> CfgDw;
 typedef Dw4Cfg<3, 8, 384, 192, 1024, 512> CfgDwE;
@@ -953,6 +954,11 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     const int nt = pl.ntiles, gx = nt < num_cus() ? nt : num_cus();
     const int sk = p->skip_layer;
     const int EW = fold ? 64 : MLP_EMB;
+    // the heads inside layer 7's launch (mlp_gemm5_kernel<0, 2>) instead of a launch of their own that reads Y_7 again: 64 us against
+    // 50 + 26, +0.95 % on the bench (308.8 / 309.4 / 309.3 against 306.0 / 306.1 / 306.5 it/s, interleaved on one box);
+    // DGM_MLP_HEADS_FUSED=0 restores the separate launch (A/B runs)
+    static const bool heads_env = [] { const char* e = getenv("DGM_MLP_HEADS_FUSED"); return !(e && atoi(e) == 0); }();
+    const bool heads_fused = fold && heads_env && p->n_out <= 16;
     // embedding planes + the maxima of the nine weight tensors (W_0 .. W_7, Wh)
     AbsMaxBatch am;
     am.n_jobs = fold ? 0 : 9;  // (round 6's forms scale per output column: mlp_prep4c_kernel takes its columns' maxima itself)
@@ -1022,6 +1028,10 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
                 b.A2 = (const unsigned char*)w.emb, b.A2exp = w.Eexp, b.bias = w.bias_s[sk];
                 P5_LAUNCH((mlp_gemm5_kernel<4, 0>), Cfg5Skip::LDS, gx, st, b)
                 b.A2 = nullptr, b.A2exp = nullptr;
+            } else if (l == 7 && heads_fused) {  // the last trunk layer with the heads riding along (one wave per SIMD: the form with the registers for it)
+                b.bias = w.bias_s[l];
+                b.hBp = w.Wh4f, b.h_inv = w.wsc_hf, b.h_bias = p->bh, b.h_out = out, b.h_nout = p->n_out;
+                P5_LAUNCH((mlp_gemm5_kernel<0, 2>), Cfg5FwdH::LDS, gx, st, b)
             } else if (all5) {
                 b.bias = w.bias_s[l];
                 dgm::prof_begin(DGM_STAGE_MLP_LAYER_FWD, st);
@@ -1060,7 +1070,8 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     // heads: out = Y7 Wh^T + bh (one computing wave per workgroup; HBM-bound: one pass over Y7)
     a.A = (const unsigned char*)w.Y[7], a.Aexp = w.Yexp[7], a.Bp = w.Wh4f, a.b_inv = w.wsc_hf, a.bias = p->bh;
     a.mask_out = nullptr, a.C = nullptr, a.Cexp = nullptr, a.out = out, a.ldo = p->n_out, a.n_valid = p->n_out;
-    if (fold) P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 3, false, 1, true>), CfgHeadsC::LDS, gx, st, a)
+    if (fold && heads_fused) {}  // (written by layer 7's launch)
+    else if (fold) P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 3, false, 1, true>), CfgHeadsC::LDS, gx, st, a)
     else P4_LAUNCH((mlp_gemm4_kernel<16, 1024, 512, 3, false, 1>), CfgHeads::LDS, gx, st, a)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mlp_fail(hipGetErrorString(e));

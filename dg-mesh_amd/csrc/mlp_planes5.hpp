@@ -47,6 +47,12 @@ struct Gemm5Args {
     unsigned char* C;           // output planes [Np][2][256]
     int* Cexp;                  // [ntiles]
     int exps_limit;             // tiles of a workgroup whose input exponents come from its LDS table; later ones from HBM
+    // EPI 2 (the last trunk layer with the output heads riding along): out[row][o] = Y[row] . Wh[o] + bh[o], o < h_nout <= 16
+    const uint4* hBp;           // heads' weight planes [16 K steps][2 halves | 2 planes][32 columns] (mlp_prep4c_kernel, ncols = 32)
+    const float* h_inv;         // [h_nout] inverse column scales of hBp
+    const float* h_bias;        // [h_nout]
+    float* h_out;               // [M][h_nout] fp32
+    int h_nout;
 };
 
 template <int KS2, int EPI>
@@ -60,18 +66,25 @@ struct Gemm5Cfg {
     static constexpr int MI_BYTES = EPI == 1 ? NBUF * 1024 : 0;      // mask blocks of the same three tiles (EPI 1)
     static constexpr int O_BYTES = 32768;                            // staging tile of the output planes
     static constexpr int EXPS = KS2 > 0 ? 64 : 128;                  // input exponents of the workgroup's tiles (>= 0.5 M rows on 256 CUs)
-    static constexpr int LDS = A_END + MI_BYTES + O_BYTES + 2 * 1024 + 64 + EXPS * 4 * (KS2 > 0 ? 2 : 1) + 1024 + 1024;  // (+ bias, + column scales)
+    static constexpr int H_BYTES = EPI == 2 ? 256 + 4 * 32 * 16 * 4 : 0;  // EPI 2: heads' scales and biases, the four waves' partial outputs
+    static constexpr int LDS = A_END + MI_BYTES + O_BYTES + 2 * 1024 + 64 + EXPS * 4 * (KS2 > 0 ? 2 : 1) + 1024 + 1024 + H_BYTES;  // (+ bias, + column scales)
     static_assert(LDS <= 160 * 1024, "LDS budget of a gfx950 CU");
 };
 
 // EPI 0: Y = relu(acc c + bias), planes + tile exponent + ReLU mask out     EPI 1: G' = mask ? acc c : 0 (backward data)
+// EPI 2: EPI 0 plus the output heads on the tile just produced (the last trunk layer): while a tile's staged planes wait in LDS for
+//        their row stores (the first half of the step after next), every wave multiplies ITS 64 columns of them with the heads'
+//        weights (4 K steps, 12 MFMAs, the staged rows read as B fragments through the staging swizzle), the four partial 32 x 16
+//        results meet in LDS at the mid barrier and leave as fp32 rows -- the heads launch and its 102 MB read of Y_7 are gone.
 // bx / G / tiles_in as in gemm4_body (tiles bx, bx + G, ...; tiles_in >= 0: exactly that many).
-template <int KS2, int EPI>
+template <int KS2, int EPI_>
 __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, const int G, unsigned char* smem, const int tiles_in = -1) {
-    using Cfg = Gemm5Cfg<KS2, EPI>;
+    using Cfg = Gemm5Cfg<KS2, EPI_>;
+    constexpr int EPI = EPI_ == 2 ? 0 : EPI_;  // (everything below that says EPI == 0 holds for the heads-carrying variant too)
+    constexpr bool HEADS = EPI_ == 2;
     constexpr int KS = Cfg::KS, P1 = Cfg::PITCH1, P2 = Cfg::PITCH2, ABYTES = Cfg::ABYTES, A1BYTES = Cfg::A1BYTES;
-    static_assert(EPI == 0 || EPI == 1, "plane-producing variants only");
-    static_assert(KS2 == 0 || (KS2 == 4 && EPI == 0), "the embedding steps belong to the forward skip layer");
+    static_assert(EPI_ == 0 || EPI_ == 1 || EPI_ == 2, "plane-producing variants only");
+    static_assert(KS2 == 0 || (KS2 == 4 && EPI_ == 0), "the embedding steps belong to the forward skip layer");
     unsigned char* Abuf = smem;                                                   // [3][ A1: 32 x P1 | A2: 32 x P2 ]
     unsigned char* Mibuf = smem + Cfg::A_END;                                     // [3][1024] mask blocks in (EPI 1)
     unsigned char* Obuf = Mibuf + Cfg::MI_BYTES;                                  // [32][1024] staging of the output planes (swizzled)
@@ -81,6 +94,9 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
     int* exps2 = exps + Cfg::EXPS;                                                // [EXPS] (KS2)
     float* biasl = reinterpret_cast<float*>(exps2 + (KS2 > 0 ? Cfg::EXPS : 0));   // [256]
     float* scl = biasl + 256;                                                     // [256] inverse column scales
+    float* hinv = scl + 256;                                                      // HEADS: [32] inverse column scales of the heads' planes
+    float* hbias = hinv + 32;                                                     //        [32] their biases
+    float* hp = hbias + 32;                                                       //        [4 waves][32 rows][16] partial outputs
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
     const int my_tiles = tiles_in >= 0 ? tiles_in : (a.ntiles - bx + G - 1) / G;
@@ -134,6 +150,7 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
     }
     if (EPI == 0) biasl[tid] = a.bias[tid];
     scl[tid] = a.b_inv[tid];
+    if (HEADS && tid < 32) hinv[tid] = tid < a.h_nout ? a.h_inv[tid] : 0.f, hbias[tid] = tid < a.h_nout ? a.h_bias[tid] : 0.f;
 
     // stationary weights: the M-side fragments of this wave's two 32-column blocks (blocks 2 wv, 2 wv + 1 of the eight)
     // The first P5_W_AGPR K steps' fragments are loaded straight into accumulation registers (an asm load with an "a" result:
@@ -154,8 +171,19 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
         }
     }
 
+    // HEADS: the heads' weight fragments of this wave's four K steps (columns 64 wv .. 64 wv + 63 of Y)
+    f16x8 hwh[HEADS ? 4 : 1], hwl[HEADS ? 4 : 1];
+    if (HEADS) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const uint4* hb = a.hBp + ((size_t)(4 * wv + kk) * 4 + g) * 32 + li;
+            hwh[HEADS ? kk : 0] = as_f16x8(hb[0]), hwl[HEADS ? kk : 0] = as_f16x8(hb[64]);
+        }
+    }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc0 = zero16, acc1 = zero16;
+    f32x16 hacc = zero16;  // HEADS: this wave's partial 32 x 16 (rows on the lanes; accumulator entries 0..7 are outputs (i & 3) + 8 (i >> 2) + 4 g)
+    int eo_hs = 0;         // HEADS: exponent of the tile whose staged planes the next step multiplies
     f16x8 fh[2], fl[2];  // fragments one K step ahead of their MFMAs
     // K step ks_ of the tile in buffer ps1_ / ps2_: the embedding steps first
 #define G5_FRAG(ks_)                                                                                                   \
@@ -311,6 +339,20 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
                         G5_SROW(6) G5_SROW(7)
                         if (EPI == 0 && wv == 3) reinterpret_cast<uint4*>(a.mask_out + (size_t)(tile - 2 * G) * 256)[lane] = smv;
                     }
+                    if (HEADS && ks >= 4 && ks < 8) {
+                        // K step 4 wv + kk of the heads on tile j-2's staged planes: columns 16 (4 wv + kk) + 8 g .. + 7 of row li are the
+                        // 8-byte chunks u0, u0 + 1 (u0 = 4 (4 wv + kk) + 2 g) of the row, stored at chunk u ^ (li & 15): one 16-byte read
+                        // at (u0 ^ (s & ~1)), its halves swapped when s is odd; the low plane 512 bytes further
+                        const int kk = ks - 4;
+                        const unsigned s_ = (unsigned)li & 15u;
+                        const unsigned char* pr = Obuf + li * 1024 + (((unsigned)(4 * (4 * wv + kk) + 2 * g) ^ (s_ & ~1u)) << 3);
+                        uint4 vh = *reinterpret_cast<const uint4*>(pr), vl = *reinterpret_cast<const uint4*>(pr + 512);
+                        if (s_ & 1u) vh = make_uint4(vh.z, vh.w, vh.x, vh.y), vl = make_uint4(vl.z, vl.w, vl.x, vl.y);
+                        const f16x8 bh_ = as_f16x8(vh), bl_ = as_f16x8(vl);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl[HEADS ? kk : 0], bh_, kk == 0 ? zero16 : hacc, 0, 0, 0);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh[HEADS ? kk : 0], bl_, hacc, 0, 0, 0);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh[HEADS ? kk : 0], bh_, hacc, 0, 0, 0);
+                    }
                 }
                 if (HE.value && !(P5_ABL & 8)) {
                     if (ks == 0) G5_E1(0)
@@ -331,8 +373,27 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
                             mw[0] = (unsigned short)bits0, mw[2] = (unsigned short)bits1;
                         }
                     }
+                    if (HEADS && HS.value) {  // this wave's partial heads of tile j-2: outputs 4 g .. 4 g + 3 and 8 + 4 g .. of row li
+                        float* hw_ = hp + ((size_t)wv * 32 + li) * 16 + 4 * g;
+                        *reinterpret_cast<float4*>(hw_) = make_float4(hacc[0], hacc[1], hacc[2], hacc[3]);
+                        *reinterpret_cast<float4*>(hw_ + 8) = make_float4(hacc[4], hacc[5], hacc[6], hacc[7]);
+                    }
                     P4_STEP_BARRIER();  // MID: the tile maximum needs all four waves; the vector memory issued a step ago is done
                     if (HE.value) t0 = *reinterpret_cast<const float4*>(tmaxs);
+                    if (HEADS && HS.value) {  // the four partials in wave order, unscaled, + bias: two outputs of one row per thread
+                        const int hr = tid >> 3, ho = (tid & 7) * 2;
+                        const float2 p0 = *reinterpret_cast<const float2*>(hp + ((size_t)0 * 32 + hr) * 16 + ho);
+                        const float2 p1 = *reinterpret_cast<const float2*>(hp + ((size_t)1 * 32 + hr) * 16 + ho);
+                        const float2 p2 = *reinterpret_cast<const float2*>(hp + ((size_t)2 * 32 + hr) * 16 + ho);
+                        const float2 p3 = *reinterpret_cast<const float2*>(hp + ((size_t)3 * 32 + hr) * 16 + ho);
+                        const float2 iv = *reinterpret_cast<const float2*>(hinv + ho), bv = *reinterpret_cast<const float2*>(hbias + ho);
+                        const float ch = p4_pow2(-eo_hs);
+                        const int row = (tile - 2 * G) * 32 + hr;
+                        if (row < a.M) {
+                            if (ho < a.h_nout) a.h_out[(size_t)row * a.h_nout + ho] = (((p0.x + p1.x) + p2.x) + p3.x) * (ch * iv.x) + bv.x;
+                            if (ho + 1 < a.h_nout) a.h_out[(size_t)row * a.h_nout + ho + 1] = (((p0.y + p1.y) + p2.y) + p3.y) * (ch * iv.y) + bv.y;
+                        }
+                    }
                 }
             } else {
                 const int s2 = ks - H1;
@@ -365,6 +426,7 @@ __device__ __forceinline__ void gemm5_body(const Gemm5Args& a, const int bx, con
 #undef G5_E2
 #undef G5_SREAD
 #undef G5_SROW
+        if (HEADS && HE.value) eo_hs = eo;  // (tile j-1's exponent: the next step multiplies its staged planes)
         if (HM.value) {
 #pragma unroll
             for (int i = 0; i < 16; i++) pv0[i] = acc0[i], pv1[i] = acc1[i];
