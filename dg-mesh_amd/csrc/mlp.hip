@@ -964,8 +964,9 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
     am.n_jobs = fold ? 0 : 9;  // (round 6's forms scale per output column: mlp_prep4c_kernel takes its columns' maxima itself)
     for (int l = 0; l < 8; l++) am.job[l].W = p->W[l], am.job[l].n = MLP_W * layer_in(p, l);
     am.job[8].W = p->Wh, am.job[8].n = p->n_out * MLP_W;
-    hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, temb_stride, p->t_dim,
-                       (unsigned char*)w.emb, w.Eexp, am, w.matmax, EW);
+    if (!fold)
+        hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt + 8 * am.n_jobs), dim3(256), 0, st, N, nt, x, temb, temb_stride, p->t_dim,
+                           (unsigned char*)w.emb, w.Eexp, am, w.matmax, EW);
     if (fold) {  // every weight matrix as two binary16 planes, one power-of-two scale per OUTPUT COLUMN, biases pre-scaled
         Prep4cBatch pc;
         int nc = 0;
@@ -985,7 +986,16 @@ int forward_planes(const dgm_mlp_params* p, int N, const float* x, const float* 
         }
         addc(0, MLP_W, 32, MLP_W, 0, MLP_W, p->n_out, p->Wh, w.Wh4f, w.wsc_hf, nullptr, nullptr);   // heads forward: B[k][o] = Wh[o][k]
         addc(1, 16, MLP_W, MLP_W, 0, p->n_out, MLP_W, p->Wh, w.Wh4b, w.wsc_hb, nullptr, nullptr);    // heads backward: B[o][c] = Wh[o][c]
-        hipLaunchKernelGGL(mlp_prep4c_kernel, dim3(MLP_W / P4C_COLS, nc), dim3(256), 0, st, pc);
+        // ... in ONE launch with the embedding planes (DGM_MLP_EMBED_MERGED=0: two launches, for A/B runs)
+        static const bool merged = [] { const char* e = getenv("DGM_MLP_EMBED_MERGED"); return !(e && atoi(e) == 0); }();
+        if (merged) {
+            const int n_prep = (MLP_W / P4C_COLS) * nc;
+            hipLaunchKernelGGL(mlp_embed4c_kernel, dim3(n_prep + nt), dim3(256), 0, st, N, x, (unsigned char*)w.emb, w.Eexp, EW, pc, n_prep);
+        } else {
+            hipLaunchKernelGGL(mlp_embed4_kernel, dim3(nt), dim3(256), 0, st, N, nt, x, temb, temb_stride, p->t_dim,
+                               (unsigned char*)w.emb, w.Eexp, am, w.matmax, EW);
+            hipLaunchKernelGGL(mlp_prep4c_kernel, dim3(MLP_W / P4C_COLS, nc), dim3(256), 0, st, pc);
+        }
     }
     // (rounds 3-5's forms: one power-of-two scale per matrix)
     Prep4Batch pb;

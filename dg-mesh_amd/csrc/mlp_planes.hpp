@@ -190,6 +190,9 @@ struct AbsMaxBatch {
 // Grid: 8 am.n_jobs workgroups that reduce max |W| of an eighth of one weight tensor each into matmax[job][8] (float bits; the
 // weight preparation folds the eight) -- the scales of the weight planes; riding along here saves a launch in front of the weight
 // preparation, which needs them -- followed by ntiles workgroups (one 32-row tile each).
+__device__ __forceinline__ void embed4_tile(const int N, const int tile, const float* __restrict__ x, const float* __restrict__ temb,
+                                            const int temb_stride, const int T, unsigned char* __restrict__ Ep, int* __restrict__ Eexp,
+                                            const int EW, float (*se)[96 + 1], float* smax);
 __global__ void __launch_bounds__(256)
 mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* __restrict__ temb, int temb_stride, int T,
                   unsigned char* __restrict__ Ep, int* __restrict__ Eexp, const AbsMaxBatch am, unsigned* __restrict__ matmax,
@@ -223,7 +226,13 @@ mlp_embed4_kernel(int N, int ntiles, const float* __restrict__ x, const float* _
         if (tid == 0) matmax[job * AS + part] = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
         return;
     }
-    const int tile = (int)blockIdx.x - n_am, r0 = tile * 32;
+    embed4_tile(N, (int)blockIdx.x - n_am, x, temb, temb_stride, T, Ep, Eexp, EW, se, smax);
+}
+__device__ __forceinline__ void embed4_tile(const int N, const int tile, const float* __restrict__ x, const float* __restrict__ temb,
+                                            const int temb_stride, const int T, unsigned char* __restrict__ Ep, int* __restrict__ Eexp,
+                                            const int EW, float (*se)[96 + 1], float* smax) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = tile * 32;
     float mx = 0.f;
     // sin / cos: lane < 60 of wave w evaluates one (row, frequency, axis) triple of rows 8 w + 2 it + {0, 1}
 #pragma unroll
@@ -347,13 +356,12 @@ struct Prep4cBatch {
 // 256-column matrix, 270 in the launch.  (First version: 32 columns per workgroup, 136 workgroups -- the launch lasted as long as one
 // CU needs for its 12 k scattered 32-byte row reads, 11.7 us; W is (out, in), a column of the GEMM operand is a row of W.)
 static constexpr int P4C_COLS = 16, P4C_SLOTS = 256 / P4C_COLS, P4C_ITERS = 48 / P4C_SLOTS;  // (48 k-groups: Kp <= 384)
-__global__ void __launch_bounds__(256)
-mlp_prep4c_kernel(const Prep4cBatch b) {
+__device__ __forceinline__ void prep4c_block(const Prep4cBatch& b, const int bx, const int by) {
     __shared__ float smax[P4C_SLOTS][P4C_COLS], sfold[8][P4C_COLS];
-    const Prep4cJob& pj = b.job[blockIdx.y];
+    const Prep4cJob& pj = b.job[by];
     const Prep3Job& j = pj.j;
-    if ((int)blockIdx.x * P4C_COLS >= j.ncols) return;
-    const int tid = threadIdx.x, cl = tid % P4C_COLS, col = blockIdx.x * P4C_COLS + cl, slot = tid / P4C_COLS, nkg = j.Kp >> 3;
+    if (bx * P4C_COLS >= j.ncols) return;
+    const int tid = threadIdx.x, cl = tid % P4C_COLS, col = bx * P4C_COLS + cl, slot = tid / P4C_COLS, nkg = j.Kp >> 3;
     float e[P4C_ITERS][8];
     float m = 0.f;
 #pragma unroll
@@ -389,7 +397,7 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
             pj.bias_out[col] = bv * sc;
         }
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && b.temb_row != nullptr && tid < b.T) b.temb_row[tid] = b.temb[tid];
+    if (bx == 0 && by == 0 && b.temb_row != nullptr && tid < b.T) b.temb_row[tid] = b.temb[tid];
 #pragma unroll
     for (int it = 0; it < P4C_ITERS; it++) {
         const int kg = slot + P4C_SLOTS * it;
@@ -404,6 +412,25 @@ mlp_prep4c_kernel(const Prep4cBatch b) {
             dst[2 * j.ncols] = L;
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+mlp_prep4c_kernel(const Prep4cBatch b) {
+    prep4c_block(b, (int)blockIdx.x, (int)blockIdx.y);
+}
+// The embedding planes and the weight preparation in ONE launch (round 6's forms: neither needs anything of the other): the first
+// n_prep = 16 x jobs workgroups prepare the weights (dispatched first: their scattered row reads are the longer chain), the rest take
+// one 32-row tile of the embedding each.  (Two launches: 13.1 + 10.2 us.)
+__global__ void __launch_bounds__(256)
+mlp_embed4c_kernel(const int N, const float* __restrict__ x, unsigned char* __restrict__ Ep, int* __restrict__ Eexp, const int EW,
+                   const Prep4cBatch b, const int n_prep) {
+    if ((int)blockIdx.x < n_prep) {  // (workgroup-uniform)
+        prep4c_block(b, (int)blockIdx.x % (256 / P4C_COLS), (int)blockIdx.x / (256 / P4C_COLS));
+        return;
+    }
+    __shared__ float se[32][96 + 1];
+    __shared__ float smax[4];
+    embed4_tile(N, (int)blockIdx.x - n_prep, x, nullptr, 0, 0, Ep, Eexp, EW, se, smax);
 }
 
 // ---- dOut (N, n_out) fp32 -> planes [Np][2][32] + exponents, and the heads' bias-gradient partial sums --------------------
