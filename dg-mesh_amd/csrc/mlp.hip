@@ -1105,18 +1105,20 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     a.ntiles = nt, a.M = N, a.exps_limit = p4_exps_limit();
     // G_7 = (dOut Wh) masked by layer 7's ReLU
     a.A = w.Dp, a.Aexp = w.Dexp, a.Bp = w.Wh4b, a.b_inv = w.wsc_hb, a.mask_in = w.mask[7], a.C = G, a.Cexp = Ge;
-    {   // one K step per tile: nothing to hide the epilogue's barriers under, so two workgroups per CU (104 VGPRs, 54 KB of LDS)
-        static const int mult = [] { const char* e = getenv("DGM_P4_G7_MULT"); return e ? atoi(e) : 2; }();
-        const int g7 = nt < mult * num_cus() ? nt : mult * num_cus();
-        if (fold) P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8, true>), CfgG7C::LDS, g7, st, a)
-        else P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8>), CfgG7::LDS, g7, st, a)
-    }
     Dw4Args d;
     memset(&d, 0, sizeof(d));
     d.ntiles = nt, d.tiles_per_chunk = pl.tiles_per_chunk;
     // heads' weight gradient: dWh[o][c] = sum_r dOut[r][o] Y7[r][c]
     d.X = (const unsigned char*)w.Y[7], d.Xexp = w.Yexp[7], d.G = w.Dp, d.Gexp = w.Dexp, d.partial = w.partial_h, d.chunk_stride = 0;
     d.partial_db = nullptr;
+    // (tried, round 6: this launch on a side stream beside the G_7 launch -- a read stream over Y_7 beside a write stream, joined again in
+    // front of the reduction; G_7 with one or two workgroups per CU: 308.8 / 309.0 and 306.3 / 308.2 it/s against 311.7 / 311.8 in order)
+    {   // one K step per tile: nothing to hide the epilogue's barriers under, so two workgroups per CU (104 VGPRs, 54 KB of LDS)
+        static const int mult = [] { const char* e = getenv("DGM_P4_G7_MULT"); return e ? atoi(e) : 2; }();
+        const int g7 = nt < mult * num_cus() ? nt : mult * num_cus();
+        if (fold) P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8, true>), CfgG7C::LDS, g7, st, a)
+        else P4_LAUNCH((mlp_gemm4_kernel<1, 128, 64, 1, false, 8>), CfgG7::LDS, g7, st, a)
+    }
     P4_LAUNCH((mlp_dw4_kernel<8, 1, 1024, 512, 128, 64>), CfgDwH::LDS, pl.chunks, st, d)
     ReduceDwBatch rb;
     rb.emb_dim = p->emb_dim, rb.n_jobs = 0;
