@@ -487,7 +487,9 @@ mlp_gemm5_kernel(const Gemm5Args a) {
 // 104-129: h = cat([x_emb, t_emb]) -> linear[0]; the skip re-injection feeds linear[5] the same way).  The fold itself happens where
 // the two layers' biases are pre-scaled (mlp_prep4c_kernel, mlp_planes.hpp: `fold` jobs); first version: a launch of its own.
 
-// The adjoint of the fold (one launch, after the reduction has produced db; grid (3 or 2, T)):
+// The adjoint of the fold (one launch, after the reduction has produced db; grid (3 or 2, T)).  (Tried: the same work inside
+// mlp_reduce_dw_all_kernel -- its bias-reducing workgroups writing the time columns, the last of them to arrive dL/dt_emb -- saves this
+// launch and costs the HBM-bound reduction more than that: 304.0 / 302.5 / 304.0 against 309.8 / 310.7 / 310.6 it/s.):
 //   blockIdx.x = 0, 1: the weights' time columns of layer 0 / the skip layer, dW[j][63 + t] = db[j] t_emb[t];
 //   blockIdx.x = 2   : dL/dt_emb[t] = sum_j db0[j] W0[j][63 + t] + db5[j] W5[j][63 + t]  (first version: mlp_dtemb_bcast_kernel, a
 //                      launch of its own behind this one -- still the per-row-time path's; same summation order here).
