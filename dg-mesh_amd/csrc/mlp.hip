@@ -1229,6 +1229,11 @@ int backward_planes(const dgm_mlp_params* p, int N, const float* dOut, int temb_
     // (tried, round 6: TWO launches, layers 7 .. 4 reduced right behind layer 4's paired launch -- 130-160 MB of partial tiles each, a
     // thousand workgroups each, so that the reads could hit the MALL: 304.3 / 304.1 it/s against 309.1 / 308.3 with the single launch,
     // interleaved on one box, scripts/gpu_r6_rsplit.sh; the split at layer 3 or 5: 305.0 / 303.6)
+    // (tried, round 6: this launch and what follows it on a side stream -- a second entry point running the pass in two pieces, the
+    // trainer joining the streams before it looks at a gradient -- so that the first network's reduction runs beside the rasterizer's
+    // VALU-bound backward: 305.5 / 305.6 / 305.4 it/s against 309.8 / 309.0 / 309.6 on one stream, and every consumer of a gradient
+    // becomes a place to race; an unsafe timing run with NO join at all, the second network's reduction under Adam and the next
+    // forward pass, showed +2 % -- that overlap is not available to a correct step)
     // (tried: each layer's reduction on a side stream under the next layer's launch -- its small workgroups do fit beside a
     // resident pair workgroup -- 265 vs 274 it/s: slower, the pair kernel's HBM-bound half gets the competition)
     rb.n_jobs = n_pending;
